@@ -1,0 +1,139 @@
+/*
+ * twopaco_hip.h -- C-ABI of the MI355X junction-enumeration library (libtwopaco_hip.so).
+ *
+ * This is the drop-in boundary for TwoPaCo's two-pass junction enumeration.  The reference
+ * has no FFI: its operator boundary is the C++ factory TwoPaCo::CreateEnumerator
+ * (reference src/graphconstructor/vertexenumerator.h:37-46) whose constructor
+ * (vertexenumerator.h:122-466) runs the worker classes below on CPU threads.  Each entry
+ * point here replaces one of those workers / data structures; twopaco_amd/host/ keeps the
+ * CreateEnumerator signature and calls only this ABI.  Reference paths are relative to
+ * /root/reference/src ; VE.h = graphconstructor/vertexenumerator.h.
+ *
+ * Conventions: plain C, opaque context, int status (0 = ok, <0 = error, text via
+ * tpc_last_error).  The caller owns every host buffer; the library owns device memory
+ * until tpc_ctx_destroy.  One host thread per context; calls are synchronous with respect
+ * to their outputs.  Device pointers (the *_dev entry points) are raw HIP device addresses.
+ *
+ * Text model.  The reference streams each FASTA record as 'N' + bases + 'N' in overlapping
+ * Tasks (VE.h:1108-1226).  The library works on the equivalent global text
+ *     T = N rec0 N rec1 N ... rec(S-1) N
+ * indexed by a global position g (uint64): base g is the 2-bit code (A0 C1 G2 T3,
+ * dnachar.cpp:18-33) at bits 2*(g%32) of bases[g/32] -- the CompressedString layout
+ * (compressedstring.h:188-195) -- and bit g%32 of nmask[g/32] is set when T[g] is 'N'
+ * (any non-ACGT character, VE.h:1174, and the separators).  A "vertex position" g is the
+ * k-mer window T[g..g+k); its sequence coordinate is g - rec_start.
+ */
+#ifndef TWOPACO_HIP_H_
+#define TWOPACO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tpc_ctx tpc_ctx;
+
+#define TPC_MAX_Q 8                    /* hash functions supported by the kernels        */
+#define TPC_MAX_K 600                  /* CAPACITY < 20 words, VE.h:4                    */
+#define TPC_INVALID_VERTEX INT64_MAX   /* graphconstructor/common.cpp:5                  */
+
+/* Kernel ids for tpc_kernel_ms (hipEvent-timed duration of the last launch of each). */
+enum {
+    TPC_K_FILTER_RESET = 0, /* ConcurrentBitVector ctor zeroing, concurrentbitvector.cpp:11-24 */
+    TPC_K_INSERT = 1,       /* FilterFillerWorker, VE.h:995-1105                               */
+    TPC_K_QUERY = 2,        /* CandidateCheckingWorker, VE.h:586-704                           */
+    TPC_K_COMPACT = 3,      /* candidate mask -> position list (replaces candidate_<r>.tmp)    */
+    TPC_K_FILTER2 = 4,      /* CandidateFinalFilteringWorker, VE.h:708-829                     */
+    TPC_K_SCAN2 = 5,        /* TrueBifurcations, VE.h:1228-1256                                */
+    TPC_K_SORT = 6,         /* BifurcationStorage::Init sort, bifurcationstorage.h:65          */
+    TPC_K_EMIT = 7,         /* EdgeConstructionWorker id lookup, VE.h:927-958                  */
+    TPC_K_SPLIT = 8,        /* InitialFilterFillerWorker, VE.h:503-583                         */
+    TPC_K_COUNT = 9
+};
+
+/* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:
+ * there is no CPU fallback behind this ABI. */
+int tpc_ctx_create(int device, tpc_ctx **out);
+void tpc_ctx_destroy(tpc_ctx *ctx);
+const char *tpc_last_error(const tpc_ctx *ctx);
+
+/* Hash parameters: vertex length k, filter bits L (filter has 2^L bits), q functions and
+ * their character tables seed_table[q][5] (A,C,G,T,N) -- the only entries of
+ * CharacterHash::hashvalues the path ever reads (characterhash.h:41-59).  Replaces
+ * VertexRollingHashSeed (vertexrollinghash.h:13-52). */
+int tpc_set_params(tpc_ctx *ctx, int k, int L, int q, const uint64_t *seed_table);
+
+/* Parse-once replacement for DistributeTasks (VE.h:1108-1226): upload the packed global
+ * text.  bases has ceil(n_text/32) uint64 words, nmask ceil(n_text/32) uint32 words;
+ * T[0] and T[n_text-1] must be 'N'. */
+int tpc_seq_upload(tpc_ctx *ctx, const uint64_t *bases, const uint32_t *nmask, uint64_t n_text);
+
+/* ConcurrentBitVector(2^L) construction = zero fill (concurrentbitvector.cpp:11-24, VE.h:257). */
+int tpc_filter_reset(tpc_ctx *ctx);
+
+/* First-pass insert, FilterFillerWorker (VE.h:995-1105): every canonical (k+1)-mer edge of
+ * every N-free vertex (A/T dummy edges beside N), gated by the round's vertex-hash range
+ * [lo,hi] inclusive (VE.h:1063-1073).  n_kmers (may be NULL) receives the number of vertex
+ * positions hashed. */
+int tpc_pass1_insert(tpc_ctx *ctx, uint64_t lo, uint64_t hi, uint64_t *n_kmers);
+
+/* Split pass histogram, InitialFilterFillerWorker (VE.h:503-583): uses (and overwrites) the
+ * filter as scratch; bins_host receives 2^24 counters (VE.h:471).  records: global start
+ * and length of every dispatched record (len >= k), n_rec of them. */
+int tpc_pass1_split_hist(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec,
+                         uint32_t *bins_host);
+
+/* First-pass query, CandidateCheckingWorker (VE.h:586-704): sets this round's candidate
+ * mask (bit g) and returns the number of marks ("Candidate marks count", VE.h:387). */
+int tpc_pass1_query(tpc_ctx *ctx, uint64_t lo, uint64_t hi, uint64_t *n_marks);
+
+/* Second-pass exact filter over this round's marks, CandidateFinalFilteringWorker
+ * (VE.h:708-829) + TrueBifurcations (VE.h:1228-1256): appends the round's junction keys,
+ * ORs the round mask into the run-wide mask (MergeOr, VE.h:909-913). Counters as logged at
+ * VE.h:384-386. */
+int tpc_pass2_filter(tpc_ctx *ctx, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
+
+/* BifurcationStorage::Init (bifurcationstorage.h:27-66): sort all junction keys in
+ * CompressedString::Less order (compressedstring.h:93-104) and build the id index. */
+int tpc_junctions_finalize(tpc_ctx *ctx, uint64_t *n_junctions);
+
+/* Capacity in 64-bit words of one key: CalculateNeededCapacity (candidateoccurence.h:129-133). */
+int tpc_key_words(const tpc_ctx *ctx);
+
+/* Sorted junction keys, n_junctions x key_words uint64 (what bifurcations.bin holds, sorted). */
+int tpc_junction_keys(tpc_ctx *ctx, uint64_t *keys_host);
+
+/* BifurcationStorage::GetId (bifurcationstorage.h:100-127) for one k-mer given as k ASCII
+ * characters: +(rank+1), -(rank+1) or TPC_INVALID_VERTEX.  Host-side binary search over the
+ * downloaded keys (VertexEnumerator::GetId is a cold query API, VE.h:99-102). */
+int64_t tpc_get_id(tpc_ctx *ctx, const char *kmer);
+
+/* Output pass id lookup, EdgeConstructionWorker (VE.h:927-940): for every marked N-free
+ * position of the run-wide mask, in increasing g, its junction id (or TPC_INVALID_VERTEX for
+ * a Bloom false positive).  Results stay in device memory; n_marked = list length, n_valid =
+ * entries with a real id. */
+int tpc_emit(tpc_ctx *ctx, uint64_t *n_marked, uint64_t *n_valid);
+/* Copy the emit lists to the host: g_host[n_marked], id_host[n_marked]. */
+int tpc_emit_fetch(tpc_ctx *ctx, uint64_t *g_host, int64_t *id_host);
+
+/* ---- parity taps (debug; used by tests/) ---------------------------------------------- */
+uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 */
+int tpc_filter_download(tpc_ctx *ctx, uint32_t *words_host); /* tpc_filter_words words       */
+uint64_t tpc_mask_words(const tpc_ctx *ctx);                 /* n_text/32 + 1                 */
+int tpc_mask_download(tpc_ctx *ctx, int run_wide, uint32_t *words_host);
+/* Vertex hashes of the windows at g0..g0+n-1: out[(g-g0)*2q + 2i] = pos_i, +1 = neg_i. */
+int tpc_hash_dump(tpc_ctx *ctx, uint64_t g0, uint64_t n, uint64_t *out_host);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* Duration in ms of the most recent launch(es) of kernel `which`, measured with hipEvents on
+ * the stream the kernel ran on; <0 if it has not run. */
+double tpc_kernel_ms(const tpc_ctx *ctx, int which);
+/* Insert-kernel variant: 0 = atomicOr per address, 1 = test-then-atomicOr (VE.h:1088). */
+int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWOPACO_HIP_H_ */

@@ -1,0 +1,306 @@
+"""ctypes bindings over libtwopaco_hip.so (device C-ABI, include/twopaco_hip.h) and
+libtwopaco_host.so (C wrappers over the C++ host layer).  Plumbing only: every compute call
+goes to the HIP library; if it is missing this module raises -- there is no fallback."""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import lib_dir
+
+INVALID_VERTEX = (1 << 63) - 1
+KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8}
+
+# every symbol include/twopaco_hip.h declares
+HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
+               "tpc_filter_reset", "tpc_pass1_insert", "tpc_pass1_split_hist", "tpc_pass1_query", "tpc_pass2_filter",
+               "tpc_junctions_finalize", "tpc_key_words", "tpc_junction_keys", "tpc_get_id", "tpc_emit",
+               "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
+               "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option"]
+
+_hip = None
+_host = None
+
+
+def _load(name):
+    path = os.path.join(lib_dir(), name)
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback)" % path)
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        L = _load("libtwopaco_hip.so")
+        u64, i64, p, ci = ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        L.tpc_ctx_create.argtypes = [ci, ctypes.POINTER(p)]
+        L.tpc_ctx_destroy.argtypes = [p]
+        L.tpc_last_error.restype = ctypes.c_char_p
+        L.tpc_last_error.argtypes = [p]
+        L.tpc_set_params.argtypes = [p, ci, ci, ci, p]
+        L.tpc_seq_upload.argtypes = [p, p, p, u64]
+        L.tpc_filter_reset.argtypes = [p]
+        L.tpc_pass1_insert.argtypes = [p, u64, u64, p]
+        L.tpc_pass1_split_hist.argtypes = [p, p, p, ctypes.c_uint32, p]
+        L.tpc_pass1_query.argtypes = [p, u64, u64, p]
+        L.tpc_pass2_filter.argtypes = [p, u64, p, p, p]
+        L.tpc_junctions_finalize.argtypes = [p, p]
+        L.tpc_key_words.argtypes = [p]
+        L.tpc_junction_keys.argtypes = [p, p]
+        L.tpc_get_id.restype = i64
+        L.tpc_get_id.argtypes = [p, ctypes.c_char_p]
+        L.tpc_emit.argtypes = [p, p, p]
+        L.tpc_emit_fetch.argtypes = [p, p, p]
+        L.tpc_filter_words.restype = u64
+        L.tpc_filter_words.argtypes = [p]
+        L.tpc_filter_download.argtypes = [p, p]
+        L.tpc_mask_words.restype = u64
+        L.tpc_mask_words.argtypes = [p]
+        L.tpc_mask_download.argtypes = [p, ci, p]
+        L.tpc_hash_dump.argtypes = [p, u64, u64, p]
+        L.tpc_kernel_ms.restype = ctypes.c_double
+        L.tpc_kernel_ms.argtypes = [p, ci]
+        L.tpc_set_option.argtypes = [p, ctypes.c_char_p, i64]
+        _hip = L
+    return _hip
+
+
+def host():
+    global _host
+    if _host is None:
+        hip()  # dependency of the host library
+        L = _load("libtwopaco_host.so")
+        u64, i64, p, ci = ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        L.tpch_last_error.restype = ctypes.c_char_p
+        L.tpch_free.argtypes = [p]
+        L.tpch_seed_table.argtypes = [u64, ci, ci, ci, p]
+        L.tpch_text_new.restype = p
+        L.tpch_text_free.argtypes = [p]
+        L.tpch_text_add_fasta.argtypes = [p, ctypes.POINTER(ctypes.c_char_p), ci, ci]
+        L.tpch_text_add_codes.argtypes = [p, p, u64]
+        for name, res in [("tpch_text_length", u64), ("tpch_text_words", u64), ("tpch_text_bases", p), ("tpch_text_nmask", p),
+                          ("tpch_text_records", ctypes.c_uint32), ("tpch_text_rec_start", p), ("tpch_text_rec_length", p)]:
+            getattr(L, name).restype = res
+            getattr(L, name).argtypes = [p]
+        L.tpch_create_enumerator.restype = p
+        L.tpch_create_enumerator.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, u64, u64, u64, u64, u64, u64, ctypes.c_char_p,
+                                             ctypes.c_char_p, ci, u64, ci, ci, ctypes.POINTER(p)]
+        L.tpch_enumerator_free.argtypes = [p]
+        L.tpch_vertices_count.restype = u64
+        L.tpch_vertices_count.argtypes = [p]
+        L.tpch_get_id.restype = i64
+        L.tpch_get_id.argtypes = [p, ctypes.c_char_p]
+        L.tpch_hash_seed.argtypes = [p, p]
+        _host = L
+    return _host
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+def seed_table(q, bits, seed=None):
+    """q x 5 (A,C,G,T,N) character tables; seed=None draws from /dev/urandom like the reference."""
+    t = np.zeros((q, 5), dtype=np.uint64)
+    if host().tpch_seed_table(0 if seed is None else seed, 0 if seed is None else 1, q, bits, t.ctypes.data) != 0:
+        raise RuntimeError(host().tpch_last_error().decode())
+    return t
+
+
+class PackedText:
+    """The packed global text T = N rec0 N rec1 N ... (host/textpack.h)."""
+
+    def __init__(self):
+        self._h = host().tpch_text_new()
+
+    def close(self):
+        if self._h:
+            host().tpch_text_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @classmethod
+    def from_fasta(cls, files, threads=1):
+        t = cls()
+        arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
+        if host().tpch_text_add_fasta(t._h, arr, len(files), threads) != 0:
+            raise RuntimeError(host().tpch_last_error().decode())
+        return t
+
+    @classmethod
+    def from_codes(cls, records):
+        """records: iterable of uint8 arrays with codes 0..3 (ACGT) and 4 (N)."""
+        t = cls()
+        for r in records:
+            r = np.ascontiguousarray(r, dtype=np.uint8)
+            host().tpch_text_add_codes(t._h, r.ctypes.data, r.size)
+        return t
+
+    @property
+    def length(self):
+        return host().tpch_text_length(self._h)
+
+    @property
+    def bases(self):
+        return _view(host().tpch_text_bases(self._h), host().tpch_text_words(self._h), np.uint64)
+
+    @property
+    def nmask(self):
+        return _view(host().tpch_text_nmask(self._h), host().tpch_text_words(self._h), np.uint32)
+
+    @property
+    def rec_start(self):
+        return _view(host().tpch_text_rec_start(self._h), host().tpch_text_records(self._h), np.uint64).copy()
+
+    @property
+    def rec_length(self):
+        return _view(host().tpch_text_rec_length(self._h), host().tpch_text_records(self._h), np.uint64).copy()
+
+
+class Context:
+    """One device context of the C-ABI (include/twopaco_hip.h)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        rc = hip().tpc_ctx_create(device, ctypes.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RuntimeError("tpc_ctx_create failed (%d): no HIP device -- there is no CPU fallback" % rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            hip().tpc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("twopaco_hip: %s (%d)" % (hip().tpc_last_error(self._h).decode(), rc))
+
+    def set_option(self, name, value):
+        self._ck(hip().tpc_set_option(self._h, name.encode(), int(value)))
+
+    def set_params(self, k, L, q, table):
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        assert table.shape == (q, 5)
+        self.k, self.L, self.q = k, L, q
+        self._ck(hip().tpc_set_params(self._h, k, L, q, table.ctypes.data))
+
+    def seq_upload(self, text):
+        b, n = np.ascontiguousarray(text.bases), np.ascontiguousarray(text.nmask)
+        self._ck(hip().tpc_seq_upload(self._h, b.ctypes.data, n.ctypes.data, text.length))
+
+    def filter_reset(self):
+        self._ck(hip().tpc_filter_reset(self._h))
+
+    def pass1_insert(self, lo=0, hi=None, count=True):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass1_insert(self._h, lo, (1 << self.L) if hi is None else hi, ctypes.byref(n) if count else None))
+        return n.value
+
+    def pass1_split_hist(self, rec_start, rec_len):
+        rs = np.ascontiguousarray(rec_start, dtype=np.uint64)
+        rl = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        bins = np.zeros(1 << 24, dtype=np.uint32)
+        self._ck(hip().tpc_pass1_split_hist(self._h, rs.ctypes.data, rl.ctypes.data, rs.size, bins.ctypes.data))
+        return bins
+
+    def pass1_query(self, lo=0, hi=None):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass1_query(self._h, lo, (1 << self.L) if hi is None else hi, ctypes.byref(n)))
+        return n.value
+
+    def pass2_filter(self, abundance=(1 << 64) - 1):
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass2_filter(self._h, abundance, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"true": a.value, "false": b.value, "table": c.value}
+
+    def junctions_finalize(self):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_junctions_finalize(self._h, ctypes.byref(n)))
+        self.n_junctions = n.value
+        return n.value
+
+    def junction_keys(self):
+        C = hip().tpc_key_words(self._h)
+        keys = np.zeros((self.n_junctions, C), dtype=np.uint64)
+        self._ck(hip().tpc_junction_keys(self._h, keys.ctypes.data))
+        return keys
+
+    def get_id(self, kmer):
+        return hip().tpc_get_id(self._h, kmer.encode())
+
+    def emit(self):
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(hip().tpc_emit(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self.n_marked, self.n_valid = a.value, b.value
+        return a.value, b.value
+
+    def emit_fetch(self):
+        g = np.zeros(self.n_marked, dtype=np.uint64)
+        ids = np.zeros(self.n_marked, dtype=np.int64)
+        self._ck(hip().tpc_emit_fetch(self._h, g.ctypes.data, ids.ctypes.data))
+        return g, ids
+
+    def filter_download(self):
+        w = np.zeros(hip().tpc_filter_words(self._h), dtype=np.uint32)
+        self._ck(hip().tpc_filter_download(self._h, w.ctypes.data))
+        return w
+
+    def mask_download(self, run_wide=False):
+        w = np.zeros(hip().tpc_mask_words(self._h), dtype=np.uint32)
+        self._ck(hip().tpc_mask_download(self._h, 1 if run_wide else 0, w.ctypes.data))
+        return w
+
+    def hash_dump(self, g0, n):
+        out = np.zeros((n, self.q, 2), dtype=np.uint64)
+        self._ck(hip().tpc_hash_dump(self._h, g0, n, out.ctypes.data))
+        return out
+
+    def kernel_ms(self, name):
+        return hip().tpc_kernel_ms(self._h, KERNELS[name])
+
+
+class Enumerator:
+    """TwoPaCo::CreateEnumerator through the C++ host layer (host/vertexenumerator.h)."""
+
+    def __init__(self, files, k, filter_bits, q=5, rounds=1, threads=1, abundance=(1 << 64) - 1, tmpdir=".",
+                 out="de_bruijn.bin", seed=None, device=0, test_first=False):
+        arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
+        log = ctypes.c_void_p()
+        self._h = host().tpch_create_enumerator(arr, len(files), k, filter_bits, q, rounds, threads, abundance, tmpdir.encode(),
+                                                out.encode(), 0 if seed is None else 1, 0 if seed is None else seed, device,
+                                                1 if test_first else 0, ctypes.byref(log))
+        self.log = ctypes.string_at(log.value).decode() if log.value else ""
+        if log.value:
+            host().tpch_free(log)
+        if not self._h:
+            raise RuntimeError(host().tpch_last_error().decode())
+        self.k, self.q = k, q
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host().tpch_enumerator_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def vertices_count(self):
+        return host().tpch_vertices_count(self._h)
+
+    def get_id(self, kmer):
+        return host().tpch_get_id(self._h, kmer.encode())
+
+    def hash_seed(self):
+        t = np.zeros((self.q, 5), dtype=np.uint64)
+        host().tpch_hash_seed(self._h, t.ctypes.data)
+        return t

@@ -1,0 +1,560 @@
+// tpc_capi.hip -- the C-ABI of include/twopaco_hip.h: context, device memory, pass orchestration.
+// No CPU fallback: every entry point needs a HIP device.
+#include "../../include/twopaco_hip.h"
+#include "tpc_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct tpc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // parameters
+    bool have_params = false;
+    TpcHashParams P{};
+    uint64_t tab_host[TPC_TAB_WORDS]{};
+    uint64_t *tab = nullptr;
+    int C = 1;
+    // text
+    uint64_t *bases = nullptr;
+    uint32_t *nmask = nullptr;
+    uint64_t n_text = 0, n_words = 0, n_words_alloc = 0, n_tiles = 0;
+    // filter + masks
+    uint32_t *filter = nullptr;
+    uint64_t filter_words = 0;
+    uint32_t *rmask = nullptr, *mask = nullptr;
+    bool mask_dirty = false;   // run-wide mask holds more than one round
+    int rounds_done = 0;
+    // marks of the current round / final list
+    uint64_t *marks = nullptr;
+    uint64_t marks_cap = 0, n_marks = 0;
+    bool marks_valid = false;  // marks[] is the compaction of rmask
+    uint64_t *block_sums = nullptr;
+    // exact filter table
+    void *table = nullptr;
+    uint64_t table_cap = 0, table_alloc = 0;
+    // junction keys
+    uint64_t *keys = nullptr;
+    uint64_t n_keys = 0, keys_cap = 0;
+    bool finalized = false;
+    std::vector<uint64_t> keys_host;
+    uint32_t *idtab = nullptr;
+    uint64_t idtab_cap = 0;
+    // emit
+    uint64_t *emit_g = nullptr;
+    int64_t *emit_id = nullptr;
+    uint64_t emit_cap = 0, n_emit = 0;
+    bool emit_uses_marks = false;
+    // scalars
+    unsigned long long *counters = nullptr;  // device, 8 words
+    // options
+    int opt_test_first = 0;
+    // timing
+    hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
+    bool ev_used[TPC_K_COUNT]{};
+};
+
+namespace {
+
+int fail(tpc_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(c, -10, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Timed {
+    tpc_ctx *c;
+    int which;
+    Timed(tpc_ctx *c_, int w) : c(c_), which(w) { (void)hipEventRecord(c->ev0[w], c->stream); }
+    ~Timed() { (void)hipEventRecord(c->ev1[which], c->stream); c->ev_used[which] = true; }
+};
+
+TpcLaunch make_launch(const tpc_ctx *c)
+{
+    TpcLaunch a;
+    a.P = c->P; a.tab = c->tab; a.bases = c->bases; a.nmask = c->nmask; a.n_text = c->n_text;
+    a.n_tiles = c->n_tiles; a.filter = c->filter; a.stream = c->stream;
+    return a;
+}
+
+uint64_t rotln_host(uint64_t x, int L, int r)
+{   // cyclichash.h:42-44
+    if (r == 0) return x;
+    const uint64_t maskn = (1ull << (L - r)) - 1ull;
+    return ((x & maskn) << r) | (x >> (L - r));
+}
+
+template <typename T>
+int ensure(tpc_ctx *c, T *&p, uint64_t &cap, uint64_t need)
+{
+    if (need <= cap && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    uint64_t n = need + need / 8 + 16;
+    HIPCHK(c, hipMalloc((void **)&p, n * sizeof(T)));
+    cap = n;
+    return 0;
+}
+
+int read_counter(tpc_ctx *c, int i, uint64_t *out)
+{
+    unsigned long long v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->counters + i, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = v;
+    return 0;
+}
+
+int compact_mask(tpc_ctx *c, const uint32_t *m)
+{   // ordered list of the set bits of m -> c->marks / c->n_marks
+    Timed t(c, TPC_K_COMPACT);
+    tpc_launch_mask_count(c->stream, m, c->n_words, c->block_sums, c->counters + 2);
+    uint64_t n = 0;
+    int rc = read_counter(c, 2, &n);
+    if (rc) return rc;
+    rc = ensure(c, c->marks, c->marks_cap, n);
+    if (rc) return rc;
+    if (n) tpc_launch_mask_scatter(c->stream, m, c->n_words, c->block_sums, c->marks);
+    c->n_marks = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tpc_ctx_create(int device, tpc_ctx **out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -2;  // no GPU: fail loudly, no CPU path
+    if (device < 0 || device >= n) return -3;
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    tpc_ctx *c = new tpc_ctx();
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
+    for (int i = 0; i < TPC_K_COUNT; i++) {
+        if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { delete c; return -5; }
+    }
+    if (hipMalloc((void **)&c->tab, TPC_TAB_WORDS * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return -6; }
+    *out = c;
+    return 0;
+}
+
+void tpc_ctx_destroy(tpc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
+                     c->keys, c->idtab, c->emit_id, c->counters };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
+    for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *tpc_last_error(const tpc_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return -1;
+    if (!strcmp(name, "insert_test_first")) { c->opt_test_first = value != 0; return 0; }
+    return fail(c, -1, "unknown option %s", name);
+}
+
+int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
+{
+    if (!c || !seed_table) return -1;
+    if (q < 1 || q > TPC_MAX_Q) return fail(c, -1, "q=%d unsupported (1..%d)", q, TPC_MAX_Q);
+    if (L < 2 || L > 62) return fail(c, -1, "filter bits L=%d unsupported (2..62)", L);
+    if (k < 1) return fail(c, -1, "k must be positive");
+    const int C = (k + 4 + 31) / 32;  // CalculateNeededCapacity, candidateoccurence.h:129-133
+    if (C >= 20)                      // vertexenumerator.cpp:56-70
+        return fail(c, -1, "The value of K is too big. Please refer to documentaion how to increase the max supported value of K.");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->P.k = k; c->P.L = L; c->P.q = q; c->P.rk = k % L; c->P.lmask = (1ull << L) - 1ull;
+    c->C = C;
+    memset(c->tab_host, 0, sizeof c->tab_host);
+    for (int i = 0; i < q; i++)
+        for (int ch = 0; ch < 5; ch++) {
+            const uint64_t h = seed_table[i * 5 + ch];
+            if (h > c->P.lmask) return fail(c, -1, "seed table entry exceeds L bits");
+            c->tab_host[i * 5 + ch] = h;
+            c->tab_host[TPC_TAB_HK + i * 5 + ch] = rotln_host(h, L, c->P.rk);
+        }
+    HIPCHK(c, hipMemcpy(c->tab, c->tab_host, sizeof c->tab_host, hipMemcpyHostToDevice));
+    const uint64_t fw = ((1ull << L) >> 5) + 1;  // concurrentbitvector.cpp:12
+    if (fw != c->filter_words) {
+        if (c->filter) (void)hipFree(c->filter);
+        c->filter = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->filter, fw * sizeof(uint32_t)));
+        c->filter_words = fw;
+    }
+    c->have_params = true;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    return 0;
+}
+
+int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uint64_t n_text)
+{
+    if (!c || !bases || !nmask || n_text < 2) return fail(c, -1, "bad text");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nw = (n_text + 31) / 32;
+    if (!((nmask[0] & 1u) && ((nmask[(n_text - 1) >> 5] >> ((n_text - 1) & 31)) & 1u)))
+        return fail(c, -1, "text must start and end with the N separator");
+    const uint64_t tiles = (nw + TPC_TILE_THREADS - 1) / TPC_TILE_THREADS;
+    const uint64_t alloc = tiles * TPC_TILE_THREADS + TPC_XW_MAX + 2;
+    for (void *p : { (void *)c->bases, (void *)c->nmask, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
+        if (p) (void)hipFree(p);
+    c->bases = nullptr; c->nmask = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->bases, alloc * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void **)&c->nmask, alloc * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->rmask, alloc * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->mask, alloc * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->block_sums, (alloc / 256 + 2) * sizeof(uint64_t)));
+    HIPCHK(c, hipMemsetAsync(c->bases, 0, alloc * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nmask, 0xFF, alloc * sizeof(uint32_t), c->stream));  // padding = N
+    HIPCHK(c, hipMemsetAsync(c->rmask, 0, alloc * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->mask, 0, alloc * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bases, bases, nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    // the last word may be partial: mark the bits past n_text as N
+    std::vector<uint32_t> nm(nmask, nmask + nw);
+    if (n_text & 31) nm[nw - 1] |= ~0u << (n_text & 31);
+    HIPCHK(c, hipMemcpyAsync(c->nmask, nm.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_text = n_text; c->n_words = (n_text >> 5) + 1; c->n_words_alloc = alloc; c->n_tiles = tiles;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    return 0;
+}
+
+int tpc_filter_reset(tpc_ctx *c)
+{
+    if (!c || !c->have_params) return fail(c, -1, "set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    Timed t(c, TPC_K_FILTER_RESET);
+    HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
+    return 0;
+}
+
+int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
+{
+    if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+    {
+        Timed t(c, TPC_K_INSERT);
+        if (tpc_launch_insert(make_launch(c), lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
+            return fail(c, -1, "insert launch failed");
+    }
+    HIPCHK(c, hipGetLastError());
+    if (n_kmers) return read_counter(c, 0, n_kmers);
+    return 0;
+}
+
+int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint32_t *bins_host)
+{
+    if (!c || !c->have_params || !c->bases || !bins_host) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t BINS = 1ull << 24;  // VE.h:471
+    // positions where a (k+1)-mer of 'N'+record+'N' starts, for dispatched records only (VE.h:1177)
+    std::vector<uint32_t> em(c->n_words_alloc, 0u);
+    for (uint32_t r = 0; r < n_rec; r++) {
+        if (rec_len[r] < (uint64_t)c->P.k) continue;
+        const uint64_t a = rec_start[r] - 1, b = rec_start[r] + rec_len[r] - c->P.k;  // inclusive
+        for (uint64_t g = a; g <= b;) {
+            const uint64_t w = g >> 5, o = g & 31;
+            const uint64_t last = std::min<uint64_t>(b, (w << 5) + 31);
+            const uint32_t len = (uint32_t)(last - g + 1);
+            em[w] |= (len == 32 ? ~0u : ((1u << len) - 1u)) << o;
+            g = last + 1;
+        }
+    }
+    uint32_t *d_em = nullptr, *d_bins = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_em, em.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&d_bins, BINS * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpyAsync(d_em, em.data(), em.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_bins, 0, BINS * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
+    const uint64_t real = 1ull << c->P.L;
+    const uint64_t bin_size = std::max<uint64_t>(1, real / BINS);  // VE.h:169
+    {
+        Timed t(c, TPC_K_SPLIT);
+        tpc_launch_split(make_launch(c), d_em, d_bins, bin_size);
+    }
+    HIPCHK(c, hipMemcpyAsync(bins_host, d_bins, BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_em);
+    (void)hipFree(d_bins);
+    return 0;
+}
+
+int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
+{
+    if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
+    {
+        Timed t(c, TPC_K_QUERY);
+        if (tpc_launch_query(make_launch(c), c->rmask, lo, hi, gated, c->counters + 1)) return fail(c, -1, "query launch failed");
+    }
+    HIPCHK(c, hipGetLastError());
+    c->marks_valid = false;
+    uint64_t n = 0;
+    int rc = read_counter(c, 1, &n);
+    if (rc) return rc;
+    if (n_marks) *n_marks = n;
+    return 0;
+}
+
+int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+{
+    if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = compact_mask(c, c->rmask);
+    if (rc) return rc;
+    c->marks_valid = true;
+    // table: power of two >= 2 x marks
+    uint64_t cap = 1024;
+    while (cap < 2 * c->n_marks + 2) cap <<= 1;
+    const size_t sb = tpc_table_slot_bytes(c->C);
+    if (cap > c->table_alloc) {
+        if (c->table) (void)hipFree(c->table);
+        c->table = nullptr;
+        HIPCHK(c, hipMalloc(&c->table, cap * sb));
+        c->table_alloc = cap;
+    }
+    c->table_cap = cap;
+    TpcLaunch a = make_launch(c);
+    {
+        Timed t(c, TPC_K_FILTER2);
+        // key = EMPTY (all ones), meta = 0
+        tpc_launch_table_init(c->stream, c->table, cap);
+        if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap)) return fail(c, -1, "filter2 launch failed");
+    }
+    uint64_t tp = 0, used = 0;
+    {
+        Timed t(c, TPC_K_SCAN2);
+        HIPCHK(c, hipMemsetAsync(c->counters + 4, 0, 3 * sizeof(unsigned long long), c->stream));
+        if (tpc_launch_scan2(a, c->C, c->marks, c->table, cap, abundance, c->counters + 4, nullptr, nullptr)) return fail(c, -1, "scan2 launch failed");
+        if ((rc = read_counter(c, 4, &tp))) return rc;
+        if ((rc = read_counter(c, 5, &used))) return rc;
+        if (tp) {
+            const uint64_t need = c->n_keys + tp;
+            if (need > c->keys_cap) {
+                uint64_t *nk = nullptr;
+                const uint64_t ncap = need + need / 4 + 1024;
+                HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
+                if (c->n_keys) HIPCHK(c, hipMemcpyAsync(nk, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->keys) (void)hipFree(c->keys);
+                c->keys = nk;
+                c->keys_cap = ncap;
+            }
+            if (tpc_launch_scan2(a, c->C, c->marks, c->table, cap, abundance, c->counters + 4, c->keys + c->n_keys * c->C, c->counters + 6))
+                return fail(c, -1, "scan2 launch failed");
+            c->n_keys += tp;
+        }
+    }
+    // MergeOr into the run-wide mask (VE.h:909-913)
+    if (c->rounds_done == 0) {
+        HIPCHK(c, hipMemcpyAsync(c->mask, c->rmask, c->n_words_alloc * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        tpc_launch_mask_or(c->stream, c->mask, c->rmask, c->n_words_alloc);
+        c->mask_dirty = true;
+    }
+    c->rounds_done++;
+    c->finalized = false;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_true) *n_true = tp;
+    if (n_false) *n_false = used - tp;
+    if (table_size) *table_size = used;
+    return 0;
+}
+
+int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
+{
+    if (!c || !c->have_params) return fail(c, -1, "set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        Timed t(c, TPC_K_SORT);
+        int rc = tpc_launch_sort_keys(c->stream, c->C, c->P.k, c->keys, c->n_keys, nullptr, 0);
+        if (rc) return fail(c, rc, "key sort failed (%d)", rc);
+        uint64_t cap = 1024;
+        while (cap < 2 * c->n_keys + 2) cap <<= 1;
+        if (cap > c->idtab_cap) {
+            if (c->idtab) (void)hipFree(c->idtab);
+            c->idtab = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->idtab, cap * sizeof(uint32_t)));
+        }
+        c->idtab_cap = cap;
+        HIPCHK(c, hipMemsetAsync(c->idtab, 0, cap * sizeof(uint32_t), c->stream));
+        if (c->n_keys >= 0xFFFFFFFFull) return fail(c, -1, "too many junctions for the 32-bit id index");
+        tpc_launch_idtab_build(c->stream, c->C, c->keys, c->n_keys, c->idtab, cap);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->finalized = true;
+    c->keys_host.clear();
+    if (n_junctions) *n_junctions = c->n_keys;
+    return 0;
+}
+
+int tpc_key_words(const tpc_ctx *c) { return c ? c->C : 0; }
+
+int tpc_junction_keys(tpc_ctx *c, uint64_t *keys_host)
+{
+    if (!c || !c->finalized) return fail(c, -1, "junctions_finalize first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_keys) HIPCHK(c, hipMemcpy(keys_host, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t tpc_get_id(tpc_ctx *c, const char *kmer)
+{   // BifurcationStorage::GetId, bifurcationstorage.h:100-127 (host-side: cold query API)
+    if (!c || !c->finalized || !kmer) return TPC_INVALID_VERTEX;
+    const int k = c->P.k, C = c->C;
+    if (c->keys_host.size() != c->n_keys * C) {
+        c->keys_host.resize(c->n_keys * C);
+        if (tpc_junction_keys(c, c->keys_host.data())) return TPC_INVALID_VERTEX;
+    }
+    std::vector<uint64_t> fw(C, 0), rc(C, 0);
+    for (int i = 0; i < k; i++) {
+        int code;
+        switch (kmer[i]) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: return TPC_INVALID_VERTEX; }
+        fw[i >> 5] |= (uint64_t)code << (2 * (i & 31));
+        const int j = k - 1 - i;
+        rc[j >> 5] |= (uint64_t)(3 - code) << (2 * (j & 31));
+    }
+    auto find = [&](const std::vector<uint64_t> &key) -> int64_t {
+        uint64_t lo = 0, hi = c->n_keys;
+        auto less = [&](const uint64_t *a, const uint64_t *b) {  // CompressedString::Less
+            for (int w = 0; w < C; w++) if (a[w] != b[w]) return a[w] < b[w];
+            return false;
+        };
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (less(&c->keys_host[mid * C], key.data())) lo = mid + 1; else hi = mid;
+        }
+        if (lo < c->n_keys && !less(key.data(), &c->keys_host[lo * C]) && !less(&c->keys_host[lo * C], key.data())) return (int64_t)lo;
+        return -1;
+    };
+    int64_t r = find(fw);
+    if (r >= 0) return r + 1;
+    r = find(rc);
+    if (r >= 0) return -(r + 1);
+    return TPC_INVALID_VERTEX;
+}
+
+int tpc_emit(tpc_ctx *c, uint64_t *n_marked, uint64_t *n_valid)
+{
+    if (!c || !c->finalized) return fail(c, -1, "junctions_finalize first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    // one round: the round's list is the run-wide list; otherwise compact the merged mask
+    if (c->mask_dirty || !c->marks_valid) {
+        if ((rc = compact_mask(c, c->mask))) return rc;
+        c->marks_valid = false;
+    }
+    if (c->n_marks > c->emit_cap || !c->emit_id) {
+        if (c->emit_id) (void)hipFree(c->emit_id);
+        c->emit_id = nullptr;
+        const uint64_t cap = c->n_marks + c->n_marks / 8 + 16;
+        HIPCHK(c, hipMalloc((void **)&c->emit_id, cap * sizeof(int64_t)));
+        c->emit_cap = cap;
+    }
+    HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, sizeof(unsigned long long), c->stream));
+    {
+        Timed t(c, TPC_K_EMIT);
+        if (tpc_launch_emit(make_launch(c), c->C, c->marks, c->n_marks, c->keys, c->n_keys, c->idtab, c->idtab_cap, c->emit_id, c->counters + 3))
+            return fail(c, -1, "emit launch failed");
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t nv = 0;
+    if ((rc = read_counter(c, 3, &nv))) return rc;
+    c->n_emit = c->n_marks;
+    if (n_marked) *n_marked = c->n_marks;
+    if (n_valid) *n_valid = nv;
+    return 0;
+}
+
+int tpc_emit_fetch(tpc_ctx *c, uint64_t *g_host, int64_t *id_host)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_emit) {
+        HIPCHK(c, hipMemcpy(g_host, c->marks, c->n_emit * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(id_host, c->emit_id, c->n_emit * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+uint64_t tpc_filter_words(const tpc_ctx *c) { return c ? c->filter_words : 0; }
+
+int tpc_filter_download(tpc_ctx *c, uint32_t *words_host)
+{
+    if (!c || !c->filter) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(words_host, c->filter, c->filter_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+uint64_t tpc_mask_words(const tpc_ctx *c) { return c ? c->n_words : 0; }
+
+int tpc_mask_download(tpc_ctx *c, int run_wide, uint32_t *words_host)
+{
+    if (!c || !c->rmask) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(words_host, run_wide ? c->mask : c->rmask, c->n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tpc_hash_dump(tpc_ctx *c, uint64_t g0, uint64_t n, uint64_t *out_host)
+{
+    if (!c || !c->have_params || !c->bases) return -1;
+    if (g0 + n + c->P.k > c->n_text) return fail(c, -1, "range past the text");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *d = nullptr;
+    const size_t bytes = n * 2 * c->P.q * sizeof(uint64_t);
+    HIPCHK(c, hipMalloc((void **)&d, bytes));
+    tpc_launch_hash_dump(make_launch(c), g0, n, d);
+    HIPCHK(c, hipMemcpy(out_host, d, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
+
+double tpc_kernel_ms(const tpc_ctx *c, int which)
+{
+    if (!c || which < 0 || which >= TPC_K_COUNT || !c->ev_used[which]) return -1.0;
+    if (hipEventSynchronize(c->ev1[which]) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0[which], c->ev1[which]) != hipSuccess) return -1.0;
+    return ms;
+}
+
+}  // extern "C"

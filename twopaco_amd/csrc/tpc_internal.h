@@ -1,0 +1,51 @@
+// tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi.hip) and the kernels.
+#pragma once
+#include "tpc_device.h"
+
+#define TPC_TAB_MAXQ 8
+#define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[8][5] then hk[8][5]
+#define TPC_TAB_WORDS (2 * TPC_TAB_MAXQ * 5)
+
+struct TpcLaunch {
+    TpcHashParams P;
+    const uint64_t *tab;    // device: character tables
+    const uint64_t *bases;  // device: packed text
+    const uint32_t *nmask;  // device: N mask
+    uint64_t n_text;
+    uint64_t n_tiles;       // workgroups of 8192 positions covering the text
+    uint32_t *filter;       // device: Bloom filter words
+    hipStream_t stream;
+};
+
+// pass 1 (tpc_pass1.hip)
+int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);
+int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks);
+int tpc_launch_split(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, uint64_t bin_size);
+int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *out);
+
+// pass 2 / output (tpc_pass2.hip)
+// Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of
+// n_words/256+2 uint64; *n_out (device) receives the list length; list must hold it (two-phase:
+// call with list == nullptr to count only).
+int tpc_launch_mask_count(hipStream_t s, const uint32_t *mask, uint64_t n_words, uint64_t *block_sums, unsigned long long *n_out);
+int tpc_launch_mask_scatter(hipStream_t s, const uint32_t *mask, uint64_t n_words, const uint64_t *block_sums, uint64_t *list);
+int tpc_launch_mask_or(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64_t n_words);
+
+// Exact filter.  Table slot = C key words (C == 1) or one representative mark index (C > 1) plus a
+// meta word; see tpc_pass2.hip.
+size_t tpc_table_slot_bytes(int C);
+int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap);
+// counters[0]=true junctions, [1]=table size; keys_out may be nullptr (count only)
+int tpc_launch_scan2(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance,
+                     unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor);
+
+// Sort junction keys (J x C) in CompressedString::Less order; tmp buffers managed by caller via
+// query: returns required scratch bytes when scratch == nullptr.
+size_t tpc_sort_scratch_bytes(int C, uint64_t J, int k);
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void *scratch, size_t scratch_bytes);
+
+// id index over sorted keys + output-pass lookup
+int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap);
+int tpc_launch_emit(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
+                    const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid);

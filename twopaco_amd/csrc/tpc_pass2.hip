@@ -1,0 +1,493 @@
+// tpc_pass2.hip -- second pass and output-pass kernels on gfx950: candidate-mask compaction,
+// exact open-addressing filter over canonical 2-bit keys, junction key sort and id lookup.
+//
+// Reference (paths relative to /root/reference/src, VE.h = graphconstructor/vertexenumerator.h):
+//   CandidateFinalFilteringWorker VE.h:708-829, CandidateOccurence candidateoccurence.h:8-126
+//   TrueBifurcations VE.h:1228-1256, BifurcationStorage bifurcationstorage.h:27-153
+//   EdgeConstructionWorker VE.h:856-993 (id lookup part), CompressedString compressedstring.h
+//
+// Order independence of the bifurcation flag.  The reference keeps the first occurrence's
+// (prev,next) and flags a key when a later occurrence differs or both have N on one side
+// (VE.h:778-796).  With P / X the sets of prev / next letters (N a letter) of a key,
+//     isBif <=> count >= 2 && (|P| > 1 || |X| > 1 || N in P || N in X),
+// so each slot carries two 5-bit letter sets (atomicOr) and a count (atomicAdd).
+#include "tpc_device.h"
+#include "tpc_internal.h"
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr uint64_t EMPTY = ~0ull;
+constexpr int META_NEXT_SHIFT = 5;
+constexpr int META_COUNT_SHIFT = 16;
+
+struct Slot { uint64_t key; uint64_t meta; };  // C == 1: key = canonical packed k-mer; C > 1: key = representative mark index
+
+// ---------------------------------------------------------------- block / wave scan helpers
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < wv; i++) base += s_w[i];
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ __forceinline__ void wave_add64(unsigned long long *dst, unsigned v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// ---------------------------------------------------------------- mask -> ordered position list
+__global__ void __launch_bounds__(256) k_mask_count(const uint32_t *__restrict__ mask, uint64_t n_words, uint64_t *block_sums)
+{
+    __shared__ uint32_t s_w[4];
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = w < n_words ? __popc(mask[w]) : 0;
+    uint32_t total;
+    block_excl_scan256(c, s_w, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of block_sums in place, total to *n_out
+__global__ void __launch_bounds__(256) k_scan_sums(uint64_t *block_sums, uint64_t n, unsigned long long *n_out)
+{
+    __shared__ uint32_t s_w[4];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += 256) {
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? (uint32_t)block_sums[i] : 0;  // per-block sums are <= 8192
+        uint32_t total;
+        const uint32_t ex = block_excl_scan256(v, s_w, total);
+        if (i < n) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *n_out = carry;
+}
+
+__global__ void __launch_bounds__(256) k_mask_scatter(const uint32_t *__restrict__ mask, uint64_t n_words,
+                                                      const uint64_t *__restrict__ block_sums, uint64_t *__restrict__ list)
+{
+    __shared__ uint32_t s_w[4];
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t m = w < n_words ? mask[w] : 0;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan256(__popc(m), s_w, total);
+    uint64_t o = block_sums[blockIdx.x] + ex;
+    while (m) {
+        const int b = __ffs(m) - 1;
+        list[o++] = w * 32 + b;
+        m &= m - 1;
+    }
+}
+
+__global__ void k_mask_or(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n_words)
+{   // ConcurrentBitVector::MergeOr, concurrentbitvector.cpp:115-122
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] |= src[i];
+}
+
+// ---------------------------------------------------------------- k-mer -> canonical key
+template <int C>
+__device__ __forceinline__ void load_kmer(const uint64_t *__restrict__ bases, uint64_t g, int k, uint64_t (&fw)[C])
+{   // CompressedString::CopyFromString, compressedstring.h:252-264
+#pragma unroll
+    for (int w = 0; w < C; w++) {
+        const int rem = k - 32 * w;
+        uint64_t x = rem > 0 ? tpc_text_word(bases, g + 32 * w) : 0ull;
+        if (rem > 0 && rem < 32) x &= (1ull << (2 * rem)) - 1ull;
+        fw[w] = x;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void revcomp_kmer(const uint64_t (&fw)[C], int k, uint64_t (&rc)[C])
+{   // CompressedString::CopyFromReverseString, compressedstring.h:266-269
+    uint64_t R[C + 2];
+#pragma unroll
+    for (int w = 0; w < C; w++) R[w] = tpc_revcomp_word(fw[C - 1 - w]);
+    R[C] = 0; R[C + 1] = 0;
+    const int s = 64 * C - 2 * k;  // < 72 because k + 4 > 32 (C - 1)
+    const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int w = 0; w < C; w++) {
+        const uint64_t lo = ws ? R[w + 1] : R[w];
+        const uint64_t hi = ws ? R[w + 2] : R[w + 1];
+        rc[w] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ uint64_t fold_h0(const uint64_t (&x)[C], int k, const uint64_t *s_h0, int L, uint64_t lmask)
+{   // CyclicHash::eat over the packed string, cyclichash.h:106-109
+    uint64_t h = 0;
+#pragma unroll
+    for (int w = 0; w < C; w++) {
+        int n = k - 32 * w;
+        n = n > 32 ? 32 : n;
+        uint64_t y = x[w];
+        for (int t = 0; t < n; t++) { h = tpc_rotl1(h, L, lmask) ^ s_h0[y & 3]; y >>= 2; }
+    }
+    return h;
+}
+
+template <int C>
+__device__ __forceinline__ bool keys_equal(const uint64_t (&a)[C], const uint64_t (&b)[C])
+{
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < C; w++) eq = eq && a[w] == b[w];
+    return eq;
+}
+
+// forward strand stored iff posHash0 < negHash0, tie -> LessSelfReverseComplement
+// (candidateoccurence.h:34, dnachar.cpp:98-114: first differing base decides, A<C<G<T)
+template <int C>
+__device__ __forceinline__ bool forward_is_canonical(const uint64_t (&fw)[C], const uint64_t (&rc)[C], int k,
+                                                     const uint64_t *s_h0, int L, uint64_t lmask)
+{
+    const uint64_t hp = fold_h0<C>(fw, k, s_h0, L, lmask);
+    const uint64_t hn = fold_h0<C>(rc, k, s_h0, L, lmask);
+    if (hp != hn) return hp < hn;
+#pragma unroll
+    for (int w = 0; w < C; w++) {
+        const uint64_t d = fw[w] ^ rc[w];
+        if (d) {
+            const int grp = (__ffsll((unsigned long long)d) - 1) >> 1;
+            return ((fw[w] >> (2 * grp)) & 3) < ((rc[w] >> (2 * grp)) & 3);
+        }
+    }
+    return false;
+}
+
+template <int C>
+__device__ __forceinline__ uint64_t key_hash(const uint64_t (&key)[C])
+{
+    uint64_t h = 0;
+#pragma unroll
+    for (int w = 0; w < C; w++) h = tpc_mix64(h ^ key[w]);
+    return h;
+}
+
+// ---------------------------------------------------------------- exact filter (a9)
+__global__ void k_table_init(Slot *table, uint64_t cap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) { table[i].key = EMPTY; table[i].meta = 0; }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+          const uint32_t *__restrict__ nmask, const uint64_t *__restrict__ marks, uint64_t n_marks, Slot *table, uint64_t cap)
+{
+    __shared__ uint64_t s_h0[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_marks) return;
+    const uint64_t g = marks[idx];
+    uint64_t fw[C], rc[C];
+    load_kmer<C>(bases, g, P.k, fw);
+    revcomp_kmer<C>(fw, P.k, rc);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    int prev = tpc_text_char(bases, nmask, g - 1);
+    int next = tpc_text_char(bases, nmask, g + P.k);
+    if (!fwd) {  // candidateoccurence.h:43-45
+        const int t = prev;
+        prev = tpc_rc(next);
+        next = tpc_rc(t);
+    }
+    uint64_t ck[C];
+#pragma unroll
+    for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
+    const uint64_t mask = cap - 1;
+    uint64_t slot = key_hash<C>(ck) & mask;
+    if (C == 1) {
+        for (;;) {
+            const uint64_t cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)ck[0]);
+            if (cur == EMPTY || cur == ck[0]) break;
+            slot = (slot + 1) & mask;
+        }
+    } else {
+        // slot key = index of the first mark that claimed it; equality is decided on the immutable
+        // text: same k-mer up to reverse complement <=> same canonical key
+        for (;;) {
+            const uint64_t cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)idx);
+            if (cur == EMPTY) break;
+            uint64_t ofw[C], orc[C];
+            load_kmer<C>(bases, marks[cur], P.k, ofw);
+            if (keys_equal<C>(ofw, ck)) break;
+            revcomp_kmer<C>(ofw, P.k, orc);
+            if (keys_equal<C>(orc, ck)) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    unsigned long long *meta = (unsigned long long *)&table[slot].meta;
+    atomicOr(meta, (1ull << prev) | (1ull << (META_NEXT_SHIFT + next)));
+    atomicAdd(meta, 1ull << META_COUNT_SHIFT);  // CandidateOccurence::Inc, candidateoccurence.h:64-67
+}
+
+// TrueBifurcations (VE.h:1228-1256): count and (optionally) append the junction keys.
+template <int C>
+__global__ void __launch_bounds__(256)
+k_scan2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+        const uint64_t *__restrict__ marks, const Slot *__restrict__ table, uint64_t cap, uint64_t abundance,
+        unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor)
+{
+    __shared__ uint64_t s_h0[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned used = 0, tp = 0;
+    if (s < cap) {
+        const Slot sl = table[s];
+        if (sl.key != EMPTY) {
+            used = 1;
+            const uint64_t cnt = sl.meta >> META_COUNT_SHIFT;
+            const unsigned pm = (unsigned)sl.meta & 31u, nm = (unsigned)(sl.meta >> META_NEXT_SHIFT) & 31u;
+            const bool bif = cnt >= 2 && (__popc(pm) > 1 || __popc(nm) > 1 || (pm & 16u) || (nm & 16u));
+            if (bif && cnt <= abundance) {
+                tp = 1;
+                if (keys_out) {
+                    const unsigned long long o = atomicAdd(cursor, 1ull);
+                    if (C == 1) {
+                        keys_out[o] = sl.key;
+                    } else {
+                        uint64_t fw[C], rc[C];
+                        load_kmer<C>(bases, marks[sl.key], P.k, fw);
+                        revcomp_kmer<C>(fw, P.k, rc);
+                        const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+#pragma unroll
+                        for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
+                    }
+                }
+            }
+        }
+    }
+    if (!keys_out) {
+        wave_add64(&counters[0], tp);
+        wave_add64(&counters[1], used);
+    }
+}
+
+// ---------------------------------------------------------------- id index + output lookup
+template <int C>
+__global__ void __launch_bounds__(256) k_idtab_build(const uint64_t *__restrict__ keys, uint64_t J, uint32_t *idtab, uint64_t cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= J) return;
+    uint64_t key[C];
+#pragma unroll
+    for (int w = 0; w < C; w++) key[w] = keys[i * C + w];
+    const uint64_t mask = cap - 1;
+    uint64_t slot = key_hash<C>(key) & mask;
+    while (atomicCAS(&idtab[slot], 0u, (uint32_t)(i + 1)) != 0u) slot = (slot + 1) & mask;
+}
+
+// BifurcationStorage::GetId (bifurcationstorage.h:100-127) for every marked position: + if the
+// forward packed form is the stored key, - if its reverse complement is.
+template <int C>
+__global__ void __launch_bounds__(256)
+k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+       const uint64_t *__restrict__ marks, uint64_t n_marks, const uint64_t *__restrict__ keys, uint64_t J,
+       const uint32_t *__restrict__ idtab, uint64_t cap, int64_t *__restrict__ ids, unsigned long long *n_valid)
+{
+    __shared__ uint64_t s_h0[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned valid = 0;
+    if (idx < n_marks) {
+        int64_t id = INT64_MAX;
+        if (J > 0) {
+            const uint64_t g = marks[idx];
+            uint64_t fw[C], rc[C], ck[C];
+            load_kmer<C>(bases, g, P.k, fw);
+            revcomp_kmer<C>(fw, P.k, rc);
+            const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+#pragma unroll
+            for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
+            const uint64_t mask = cap - 1;
+            uint64_t slot = key_hash<C>(ck) & mask;
+            for (;;) {
+                const uint32_t r = idtab[slot];
+                if (r == 0) break;
+                uint64_t sk[C];
+#pragma unroll
+                for (int w = 0; w < C; w++) sk[w] = keys[(uint64_t)(r - 1) * C + w];
+                if (keys_equal<C>(sk, ck)) {
+                    id = keys_equal<C>(ck, fw) ? (int64_t)r : -(int64_t)r;
+                    valid = 1;
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
+        }
+        ids[idx] = id;
+    }
+    wave_add64(n_valid, valid);
+}
+
+// gather / permutation helpers for the multi-word key sort
+__global__ void k_iota(uint32_t *p, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_gather_word(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, uint64_t n, int C, int w, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = keys[(uint64_t)perm[i] * C + w];
+}
+__global__ void k_gather_keys(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, uint64_t n, int C, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        for (int w = 0; w < C; w++) out[i * C + w] = keys[(uint64_t)perm[i] * C + w];
+}
+
+inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace
+
+#define TPC_DISPATCH_C(C_, CALL)                                                                  \
+    switch (C_) {                                                                                 \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;       \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;       \
+    case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+    case 17: CALL(17); break; case 18: CALL(18); break; case 19: CALL(19); break;                 \
+    default: return -1;                                                                           \
+    }
+
+int tpc_launch_mask_count(hipStream_t s, const uint32_t *mask, uint64_t n_words, uint64_t *block_sums, unsigned long long *n_out)
+{
+    const unsigned nb = nblk(n_words, 256);
+    hipLaunchKernelGGL(k_mask_count, dim3(nb), dim3(256), 0, s, mask, n_words, block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, block_sums, (uint64_t)nb, n_out);
+    return 0;
+}
+
+int tpc_launch_mask_scatter(hipStream_t s, const uint32_t *mask, uint64_t n_words, const uint64_t *block_sums, uint64_t *list)
+{
+    hipLaunchKernelGGL(k_mask_scatter, dim3(nblk(n_words, 256)), dim3(256), 0, s, mask, n_words, block_sums, list);
+    return 0;
+}
+
+int tpc_launch_mask_or(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64_t n_words)
+{
+    hipLaunchKernelGGL(k_mask_or, dim3(2048), dim3(256), 0, s, dst, src, n_words);
+    return 0;
+}
+
+size_t tpc_table_slot_bytes(int) { return sizeof(Slot); }
+
+int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap)
+{
+    hipLaunchKernelGGL(k_table_init, dim3(2048), dim3(256), 0, s, (Slot *)table, cap);
+    return 0;
+}
+
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap)
+{
+    if (n_marks == 0) return 0;
+#define CALL(C_) hipLaunchKernelGGL((k_filter2<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, n_marks, (Slot *)table, cap)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_scan2(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance,
+                     unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor)
+{
+#define CALL(C_) hipLaunchKernelGGL((k_scan2<C_>), dim3(nblk(cap, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, abundance, counters, keys_out, cursor)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void *, size_t)
+{
+    if (J < 2) return 0;
+    hipError_t e;
+    if (C == 1) {
+        uint64_t *out = nullptr;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        int end_bit = 2 * k;
+        if (end_bit > 64) end_bit = 64;
+        if ((e = rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, out, J, 0, end_bit, s)) != hipSuccess) return -2;
+        if (hipMalloc(&out, J * sizeof(uint64_t)) != hipSuccess) return -3;
+        if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8) != hipSuccess) { (void)hipFree(out); return -3; }
+        e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys, out, J, 0, end_bit, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(keys, out, J * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(out);
+        (void)hipFree(tmp);
+        return e == hipSuccess ? 0 : -2;
+    }
+    // C > 1: CompressedString::Less compares word 0 first (compressedstring.h:93-104), so an LSD
+    // pass sequence sorts by word C-1 first and word 0 last, each pass stable.
+    uint64_t *kw = nullptr, *kw2 = nullptr, *out = nullptr;
+    uint32_t *perm = nullptr, *perm2 = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, kw, kw2, perm, perm2, J, 0, 64, s) != hipSuccess) return -2;
+    if (hipMalloc(&kw, J * 8) != hipSuccess || hipMalloc(&kw2, J * 8) != hipSuccess || hipMalloc(&out, J * C * 8) != hipSuccess ||
+        hipMalloc(&perm, J * 4) != hipSuccess || hipMalloc(&perm2, J * 4) != hipSuccess || hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8) != hipSuccess) {
+        rc = -3;
+    } else {
+        hipLaunchKernelGGL(k_iota, dim3(nblk(J, 256)), dim3(256), 0, s, perm, J);
+        for (int w = C - 1; w >= 0 && rc == 0; w--) {
+            hipLaunchKernelGGL(k_gather_word, dim3(nblk(J, 256)), dim3(256), 0, s, keys, perm, J, C, w, kw);
+            if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kw, kw2, perm, perm2, J, 0, 64, s) != hipSuccess) rc = -2;
+            uint32_t *t = perm; perm = perm2; perm2 = t;
+        }
+        if (rc == 0) {
+            hipLaunchKernelGGL(k_gather_keys, dim3(nblk(J, 256)), dim3(256), 0, s, keys, perm, J, C, out);
+            if (hipMemcpyAsync(keys, out, J * C * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = -2;
+        }
+        (void)hipStreamSynchronize(s);
+    }
+    (void)hipFree(kw); (void)hipFree(kw2); (void)hipFree(out); (void)hipFree(perm); (void)hipFree(perm2); (void)hipFree(tmp);
+    return rc;
+}
+
+size_t tpc_sort_scratch_bytes(int, uint64_t, int) { return 0; }
+
+int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap)
+{
+    if (J == 0) return 0;
+#define CALL(C_) hipLaunchKernelGGL((k_idtab_build<C_>), dim3(nblk(J, 256)), dim3(256), 0, s, keys, J, idtab, cap)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_emit(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
+                    const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid)
+{
+    if (n_marks == 0) return 0;
+#define CALL(C_) hipLaunchKernelGGL((k_emit<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, keys, J, idtab, cap, ids, n_valid)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}

@@ -1,0 +1,307 @@
+#include "vertexenumerator.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <ctime>
+#include <numeric>
+#include <stdexcept>
+
+#include "../../include/twopaco_hip.h"
+#include "streamfastaparser.h"
+#include "textpack.h"
+
+namespace TwoPaCo
+{
+	const int64_t INVALID_VERTEX = INT64_MAX;
+
+	namespace
+	{
+		const uint64_t BINS_COUNT = uint64_t(1) << 24;  // reference vertexenumerator.h:471
+
+		class HipVertexEnumerator : public VertexEnumerator
+		{
+		public:
+			HipVertexEnumerator() : ctx_(0), vertices_(0) {}
+			~HipVertexEnumerator()
+			{
+				if (ctx_) tpc_ctx_destroy(ctx_);
+			}
+
+			size_t GetVerticesCount() const { return vertices_; }
+			int64_t GetId(const std::string & vertex) const
+			{
+				if (vertex.size() < seed_.VertexLength()) return INVALID_VERTEX;
+				return tpc_get_id(ctx_, vertex.c_str());
+			}
+
+			const VertexRollingHashSeed & GetHashSeed() const { return seed_; }
+
+			void Check(int rc, const char * what)
+			{
+				if (rc != 0)
+				{
+					std::string msg = ctx_ ? tpc_last_error(ctx_) : "";
+					throw std::runtime_error(std::string(what) + (msg.empty() ? "" : ": " + msg));
+				}
+			}
+
+			// The body of the reference constructor, vertexenumerator.h:122-466.
+			void Run(const std::vector<std::string> & fileName,
+				size_t vertexLength,
+				size_t filterSize,
+				size_t hashFunctions,
+				size_t rounds,
+				size_t threads,
+				size_t abundance,
+				const std::string & outFileName,
+				std::ostream & logStream,
+				const EnumeratorOptions & options)
+			{
+				if (filterSize < 2 || filterSize > 62)
+				{
+					throw std::runtime_error("Unsupported filter size");
+				}
+
+				if (rounds < 1)
+				{
+					throw std::runtime_error("The number of rounds must be positive");
+				}
+
+				const size_t capacity = (vertexLength + 4 + 31) / 32;  // CalculateNeededCapacity
+				if (capacity >= 20)
+				{
+					throw std::runtime_error("The value of K is too big. Please refer to documentaion how to increase the max supported value of K.");
+				}
+
+				const uint64_t realSize = uint64_t(1) << filterSize;
+				logStream << "Threads = " << threads << std::endl;
+				logStream << "Vertex length = " << vertexLength << std::endl;
+				logStream << "Hash functions = " << hashFunctions << std::endl;
+				logStream << "Filter size = " << realSize << std::endl;
+				logStream << "Capacity = " << capacity << std::endl;
+				logStream << "Files: " << std::endl;
+				for (const std::string & fn : fileName)
+				{
+					logStream << fn << std::endl;
+				}
+
+				std::vector<uint64_t> table = MakeSeedTable(hashFunctions, filterSize, options.pinnedSeed, options.seed);
+				seed_ = VertexRollingHashSeed(hashFunctions, vertexLength, filterSize, table);
+
+				PackedText text;
+				PackFastaFiles(fileName, threads, text);
+
+				int rc = tpc_ctx_create(options.device, &ctx_);
+				if (rc != 0)
+				{
+					throw std::runtime_error("Can't create a GPU context (no MI355X visible?)");
+				}
+
+				Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
+				Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
+				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
+
+				// records the reference dispatches: at least k bases (vertexenumerator.h:1177)
+				std::vector<uint64_t> dispStart, dispLength;
+				for (size_t r = 0; r < text.recStart.size(); r++)
+				{
+					if (text.recLength[r] >= vertexLength)
+					{
+						dispStart.push_back(text.recStart[r]);
+						dispLength.push_back(text.recLength[r]);
+					}
+				}
+
+				const uint64_t BIN_SIZE = std::max(uint64_t(1), realSize / BINS_COUNT);
+				std::vector<uint32_t> binCounter;
+				double roundSize = 0;
+				if (rounds > 1)
+				{
+					logStream << "Splitting the input kmers set..." << std::endl;
+					binCounter.resize(BINS_COUNT);
+					Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
+					roundSize = double(std::accumulate(binCounter.begin(), binCounter.end(), size_t(0))) / rounds;
+				}
+
+				logStream << std::string(80, '-') << std::endl;
+				uint64_t low = 0;
+				uint64_t high = realSize;
+				uint64_t lowBoundary = 0;
+				uint64_t verticesCount = 0;
+				time_t mark;
+				for (size_t round = 0; round < rounds; round++)
+				{
+					mark = time(0);
+					if (rounds > 1)
+					{
+						// reference vertexenumerator.h:234-250
+						uint64_t accumulated = binCounter[lowBoundary];
+						for (++lowBoundary; lowBoundary < BINS_COUNT; ++lowBoundary)
+						{
+							if (accumulated <= roundSize || round + 1 == rounds)
+							{
+								accumulated += binCounter[lowBoundary];
+							}
+							else
+							{
+								break;
+							}
+						}
+
+						high = lowBoundary * BIN_SIZE;
+					}
+					else
+					{
+						high = realSize;
+					}
+
+					logStream << "Round " << round << ", " << low << ":" << high << std::endl;
+					logStream << "Pass\tFilling\tFiltering" << std::endl << "1\t";
+					Check(tpc_filter_reset(ctx_), "filter_reset");
+					uint64_t kmers = 0;
+					Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+					logStream << time(0) - mark << "\t";
+					mark = time(0);
+					uint64_t marks = 0;
+					Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
+					logStream << time(0) - mark << "\t" << std::endl;
+
+					mark = time(0);
+					logStream << "2\t";
+					uint64_t truePositives = 0, falsePositives = 0, hashTableSize = 0;
+					Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
+					logStream << time(0) - mark << "\t";
+					mark = time(0);
+					logStream << time(0) - mark << std::endl;
+					logStream << "True junctions count = " << truePositives << std::endl;
+					logStream << "False junctions count = " << falsePositives << std::endl;
+					logStream << "Hash table size = " << hashTableSize << std::endl;
+					logStream << "Candidate marks count = " << marks << std::endl;
+					logStream << std::string(80, '-') << std::endl;
+					verticesCount += truePositives;
+					low = high + 1;
+				}
+
+				mark = time(0);
+				uint64_t junctions = 0;
+				Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
+				vertices_ = junctions;
+				logStream << "Reallocating bifurcations time: " << time(0) - mark << std::endl;
+
+				mark = time(0);
+				uint64_t marked = 0, valid = 0;
+				Check(tpc_emit(ctx_, &marked, &valid), "emit");
+				std::vector<uint64_t> g(marked);
+				std::vector<int64_t> id(marked);
+				Check(tpc_emit_fetch(ctx_, g.data(), id.data()), "emit_fetch");
+
+				// EdgeConstructionWorker, reference vertexenumerator.h:927-958, in (sequence, position)
+				// order -- the order the reference's -t 1 run assigns stub ids in.
+				uint64_t occurence = 0;
+				uint64_t currentStubVertexId = verticesCount + 42;  // vertexenumerator.h:419
+				JunctionPositionWriter posWriter(outFileName);
+				size_t cur = 0;
+				for (size_t r = 0; r < text.recStart.size(); r++)
+				{
+					const uint64_t len = text.recLength[r];
+					if (len < vertexLength)
+					{
+						continue;
+					}
+
+					const uint64_t first = text.recStart[r];
+					const uint64_t last = first + len - vertexLength;
+					while (cur < marked && g[cur] < first) ++cur;
+					size_t end = cur;
+					bool firstValid = false, lastValid = false;
+					for (; end < marked && g[end] <= last; ++end)
+					{
+						if (id[end] != INVALID_VERTEX)
+						{
+							firstValid = firstValid || g[end] == first;
+							lastValid = lastValid || g[end] == last;
+						}
+					}
+
+					// first / last k-mer of the sequence without a junction id get a stub id (vertexenumerator.h:942-948)
+					if (!firstValid)
+					{
+						++occurence;
+						posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(0), int64_t(currentStubVertexId++)));
+					}
+
+					for (size_t i = cur; i < end; i++)
+					{
+						if (id[i] != INVALID_VERTEX)
+						{
+							++occurence;
+							posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(g[i] - first), id[i]));
+						}
+					}
+
+					if (last != first && !lastValid)
+					{
+						++occurence;
+						posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(last - first), int64_t(currentStubVertexId++)));
+					}
+
+					cur = end;
+				}
+
+				logStream << "True marks count: " << occurence << std::endl;
+				logStream << "Edges construction time: " << time(0) - mark << std::endl;
+				logStream << std::string(80, '-') << std::endl;
+			}
+
+		private:
+			tpc_ctx * ctx_;
+			size_t vertices_;
+			VertexRollingHashSeed seed_;
+		};
+	}
+
+	std::unique_ptr<VertexEnumerator> CreateEnumerator(const std::vector<std::string> & fileName,
+		size_t vertexLength,
+		size_t filterSize,
+		size_t hashFunctions,
+		size_t rounds,
+		size_t threads,
+		size_t abundance,
+		const std::string & tmpFileName,
+		const std::string & outFileName,
+		std::ostream & logStream,
+		const EnumeratorOptions & options)
+	{
+		(void)tmpFileName;  // candidate masks and junction keys stay in HBM: no scratch files
+		std::unique_ptr<HipVertexEnumerator> ret(new HipVertexEnumerator());
+		ret->Run(fileName, vertexLength, filterSize, hashFunctions, rounds, threads, abundance, outFileName, logStream, options);
+		return std::unique_ptr<VertexEnumerator>(ret.release());
+	}
+
+	std::unique_ptr<VertexEnumerator> CreateEnumerator(const std::vector<std::string> & fileName,
+		size_t vertexLength,
+		size_t filterSize,
+		size_t hashFunctions,
+		size_t rounds,
+		size_t threads,
+		size_t abundance,
+		const std::string & tmpFileName,
+		const std::string & outFileName,
+		std::ostream & logStream)
+	{
+		EnumeratorOptions options;
+		if (const char * s = std::getenv("TWOPACO_SEED"))
+		{
+			options.pinnedSeed = true;
+			options.seed = std::strtoull(s, 0, 0);
+		}
+
+		if (const char * d = std::getenv("TWOPACO_DEVICE"))
+		{
+			options.device = std::atoi(d);
+		}
+
+		return CreateEnumerator(fileName, vertexLength, filterSize, hashFunctions, rounds, threads, abundance, tmpFileName, outFileName, logStream, options);
+	}
+}

@@ -1,0 +1,66 @@
+// vertexenumerator.h -- the operator boundary of the junction-enumeration hot path, source
+// compatible with the reference (reference src/graphconstructor/vertexenumerator.h:23-46):
+// same abstract class, same factory signature, same side effects (junction stream written to
+// outFileName through JunctionPositionWriter, progress text on logStream, runtime_error on
+// failure).  The work the reference's constructor does on CPU threads
+// (vertexenumerator.h:122-466) runs on one MI355X through the C-ABI of include/twopaco_hip.h.
+#ifndef _VERTEX_ENUMERATOR_H_
+#define _VERTEX_ENUMERATOR_H_
+
+#include <cstdint>
+#include <memory>
+#include <ostream>
+#include <string>
+#include <vector>
+
+#include "junctionapi.h"
+#include "seed.h"
+
+namespace TwoPaCo
+{
+	extern const int64_t INVALID_VERTEX;  // reference graphconstructor/common.cpp:5
+
+	class VertexEnumerator
+	{
+	public:
+		virtual size_t GetVerticesCount() const = 0;
+		virtual int64_t GetId(const std::string & vertex) const = 0;
+		virtual const VertexRollingHashSeed & GetHashSeed() const = 0;
+		virtual ~VertexEnumerator() {}
+	};
+
+	// Knobs that do not exist in the reference; defaults reproduce its behaviour.
+	struct EnumeratorOptions
+	{
+		bool pinnedSeed;      // false: hash tables from /dev/urandom like the reference
+		uint64_t seed;        // with pinnedSeed: the TPC_URANDOM_SEED of oracle/urandom_shim.c
+		int device;           // HIP device ordinal
+		bool insertTestFirst; // test-then-set insert (reference vertexenumerator.h:1088) instead of plain atomicOr
+		EnumeratorOptions() : pinnedSeed(false), seed(0), device(0), insertTestFirst(false) {}
+	};
+
+	std::unique_ptr<VertexEnumerator> CreateEnumerator(const std::vector<std::string> & fileName,
+		size_t vertexLength,
+		size_t filterSize,
+		size_t hashFunctions,
+		size_t rounds,
+		size_t threads,
+		size_t abundance,
+		const std::string & tmpFileName,
+		const std::string & outFileName,
+		std::ostream & logStream);
+
+	std::unique_ptr<VertexEnumerator> CreateEnumerator(const std::vector<std::string> & fileName,
+		size_t vertexLength,
+		size_t filterSize,
+		size_t hashFunctions,
+		size_t rounds,
+		size_t threads,
+		size_t abundance,
+		const std::string & tmpFileName,
+		const std::string & outFileName,
+		std::ostream & logStream,
+		const EnumeratorOptions & options);
+}
+
+#endif
