@@ -56,6 +56,7 @@ def lib():
         L.orc_round_stat.argtypes = [p, ctypes.c_int, ctypes.c_int]
         L.orc_hash_dump.argtypes = [p, u64, p, ctypes.c_int, p]
         L.orc_fill_only.argtypes = [p, u64, u64]
+        L.orc_split_bins.argtypes = [p, p]
         L.orc_check_only.restype = u64
         L.orc_check_only.argtypes = [p, u64, u64]
         _lib = L
@@ -111,6 +112,11 @@ class Oracle:
 
     def fill_only(self, low=0, high=None):
         lib().orc_fill_only(self._h, low, (1 << self.L) if high is None else high)
+
+    def split_bins(self):
+        bins = np.zeros(1 << 24, dtype=np.uint32)
+        lib().orc_split_bins(self._h, bins.ctypes.data)
+        return bins
 
     def check_only(self, low=0, high=None):
         return lib().orc_check_only(self._h, low, (1 << self.L) if high is None else high)

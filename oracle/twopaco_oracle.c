@@ -771,6 +771,17 @@ void orc_hash_dump(const orc_run *R, uint64_t g, uint64_t *posneg, int c, uint64
     if (c >= 0 && c <= 4) edge_out(R, &v, c, addr);
 }
 
+/* Split-pass bins only (2^24 counters, caller-provided). */
+int orc_split_bins(orc_run *R, uint32_t *bins)
+{
+    const uint64_t BINS = 1ull << 24;
+    uint64_t real_size = 1ull << R->L;
+    uint64_t bin_size = real_size / BINS > 1 ? real_size / BINS : 1;
+    memset(bins, 0, BINS * sizeof(uint32_t));
+    split_pass(R, bins, bin_size);
+    return 0;
+}
+
 /* Fill only (for filter-bitmap parity and the cpu_baseline insert timing). */
 int orc_fill_only(orc_run *R, uint64_t low, uint64_t high)
 {

@@ -1,0 +1,166 @@
+"""Regenerates tests/golden/ from the REAL reference binary (oracle/_ref, built from
+/root/reference by oracle/Makefile) with /dev/urandom pinned by oracle/urandom_shim.c and -t 1.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+Committed outputs: the small FASTA inputs, each case's de_bruijn.bin (or its sha256 for the big
+synthetic cases), and the reference's own log counters / round ranges in cases.json.
+"""
+import hashlib
+import json
+import os
+import re
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from twopaco_amd import synth  # noqa: E402
+
+SEED = 20240229
+
+
+def write_edge_fa(path):
+    """Hand-made edge cases (SURVEY 8a' item 4): record of exactly k=5 bases, shorter than k, k+1,
+    empty record, leading NN, lower case + IUPAC letters, duplicated records (shared first/last
+    k-mers: stub vs real id), palindromic (k+1)-mers (strand tie), N runs."""
+    recs = [
+        ("len_k", "ACGTA"),
+        ("short", "ACG"),
+        ("len_k1", "ACGTAC"),
+        ("empty", ""),
+        ("lead_nn", "NNACGTACGGTTACNNNNTTGACCA"),
+        ("lower_iupac", "acgtRYacgtkmacgtacgtswbdhvnacgtacca"),
+        ("dup_a", "GATTACAGATTACATTTGGGCCCAAATTTGGGCCC"),
+        ("dup_b", "GATTACAGATTACATTTGGGCCCAAATTTGGGCCC"),
+        ("palin", "AACGTTAACGTTGGATCCGGATCCAATTAATT"),
+        ("branch", "TTTTTACGTAGGGGGACGTACCCCCACGTATTTTT"),
+        ("n_inside", "ACGTACGTNACGTACGTNNACGTACGTACGT"),
+        ("one_n", "N"),
+        ("x_v_u", "ACGTXACGTVACGTUACGT"),
+    ]
+    with open(path, "w") as f:
+        for name, s in recs:
+            f.write(">%s some description\n" % name)
+            for i in range(0, len(s), 17):
+                f.write(s[i:i + 17] + "\n")
+            if name == "lead_nn":
+                f.write("\n  \n")  # blank / whitespace lines are skipped
+
+
+def write_rand_fa(path, n, nchr, seed, n_rate=1 / 500.0, change=0.05, indel_frac=0.9):
+    """The self-test's input shape (reference test.cpp:20-67): chr0 random with N, the others =
+    chr0 with 5 % edits, 10 % of them substitutions, the rest insertions/deletions."""
+    base = synth.random_genome(n, seed)
+    r = synth._stream(seed, n, 7)
+    base = base.copy()
+    base[r < np.uint64(int(n_rate * 2.0 ** 64))] = 4
+    recs = [base]
+    for c in range(1, nchr):
+        ev = synth._stream(seed + c, n, 8)
+        kind = synth._stream(seed + c, n, 9) % np.uint64(100)
+        letter = (synth._stream(seed + c, n, 10) >> np.uint64(62)).astype(np.uint8)
+        out = []
+        edit = ev < np.uint64(int(change * 2.0 ** 64))
+        for i in range(n):
+            if edit[i]:
+                kd = int(kind[i])
+                if kd < 10:
+                    out.append(letter[i])
+                elif kd < 55:
+                    out.append(base[i]); out.append(letter[i])
+                # else deletion
+            else:
+                out.append(base[i])
+        recs.append(np.array(out, dtype=np.uint8))
+    synth.write_fasta(path, recs, width=60)
+
+
+def parse_log(log):
+    rounds = []
+    for m in re.finditer(r"Round (\d+), (\d+):(\d+)", log):
+        rounds.append({"low": int(m.group(2)), "high": int(m.group(3))})
+    for key, pat in [("true", r"True junctions count = (\d+)"), ("false", r"False junctions count = (\d+)"),
+                     ("table", r"Hash table size = (\d+)"), ("marks", r"Candidate marks count = (\d+)")]:
+        for i, m in enumerate(re.finditer(pat, log)):
+            rounds[i][key] = int(m.group(1))
+    return {"rounds": rounds, "true_marks": int(re.search(r"True marks count: (\d+)", log).group(1)),
+            "distinct": int(re.search(r"Distinct junctions = (\d+)", log).group(1))}
+
+
+def main():
+    O.build()
+    tmp = tempfile.mkdtemp()
+    shutil.copy("/root/reference/example/example.fa", os.path.join(HERE, "example.fa"))
+    write_edge_fa(os.path.join(HERE, "edge.fa"))
+    write_rand_fa(os.path.join(HERE, "rand6.fa"), 3000, 6, 11)
+    write_rand_fa(os.path.join(HERE, "c2.fa"), 2500, 3, 12, n_rate=1 / 900.0, change=0.03)
+
+    cases = []
+
+    def case(name, fasta, k, L, q=5, rounds=1, debug=False, abundance=None, keep_bin=True, synth_spec=None, files=None):
+        if files is None:
+            files = [os.path.join(HERE, fasta)]
+        out = os.path.join(tmp, name + ".bin")
+        log, _ = O.run_reference(files, k, L, q=q, rounds=rounds, threads=1, seed=SEED, out=out, tmpdir=tmp, debug=debug,
+                                 abundance=abundance)
+        data = open(out, "rb").read()
+        c = {"name": name, "fasta": fasta, "k": k, "L": L, "q": q, "n_rounds": rounds, "seed": SEED, "ref_debug_build": debug,
+             "abundance": abundance, "bin_sha256": hashlib.sha256(data).hexdigest(), "bin_bytes": len(data)}
+        if synth_spec:
+            c["synth"] = synth_spec
+        c.update(parse_log(log))
+        if keep_bin:
+            with open(os.path.join(HERE, name + ".bin"), "wb") as f:
+                f.write(data)
+            c["bin"] = name + ".bin"
+        cases.append(c)
+        print(name, len(data), c["distinct"], [r.get("false") for r in c["rounds"]])
+
+    case("example_k11", "example.fa", 11, 20)
+    case("example_k15_r3", "example.fa", 15, 20, rounds=3)
+    case("example_k15_dbg", "example.fa", 15, 20, debug=True)
+    case("example_k25_dbg_r2", "example.fa", 25, 24, rounds=2, debug=True)
+    case("edge_k5", "edge.fa", 5, 16)
+    case("edge_k5_dbg", "edge.fa", 5, 16, debug=True)
+    case("edge_k7_fp_r2", "edge.fa", 7, 10, rounds=2)
+    case("edge_k3", "edge.fa", 3, 12)
+    case("rand6_k9_fp", "rand6.fa", 9, 14)
+    case("rand6_k9_fp_r4", "rand6.fa", 9, 14, rounds=4)
+    case("rand6_k9_dbg", "rand6.fa", 9, 20, debug=True)
+    case("rand6_k25_q3", "rand6.fa", 25, 24, q=3)
+    case("rand6_k3", "rand6.fa", 3, 12)
+    case("rand6_k9_q1", "rand6.fa", 9, 16, q=1)
+    case("rand6_k9_q8", "rand6.fa", 9, 18, q=8)
+    case("rand6_k9_a3", "rand6.fa", 9, 20, abundance=3)
+    case("rand6_k9_L33", "rand6.fa", 9, 33)
+    case("rand6_k27", "rand6.fa", 27, 22)
+    case("c2_k29", "c2.fa", 29, 22)
+    case("c2_k35", "c2.fa", 35, 22)
+    case("c2_k51_r2", "c2.fa", 51, 22, rounds=2)
+    case("c2_k61", "c2.fa", 61, 22)
+    case("c2_k125", "c2.fa", 125, 22)
+
+    # synthetic workloads of BASELINE.json's configs (FASTA regenerated from twopaco_amd/synth.py)
+    for name, wl, scale in [("m1_small", "m1", 0.02), ("m1_full", "m1", 1.0), ("m2_small", "m2", 0.004)]:
+        recs, p = synth.workload(wl, seed=12345, scale=scale)
+        L = p["L"] if scale == 1.0 else 26
+        files = []
+        for i, r in enumerate(recs):
+            path = os.path.join(tmp, "%s_%d.fa" % (name, i))
+            synth.write_fasta(path, [r], first_id=i)
+            files.append(path)
+        case(name, None, p["k"], L, q=p["q"], keep_bin=False, synth_spec={"workload": wl, "seed": 12345, "scale": scale}, files=files)
+
+    with open(os.path.join(HERE, "cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()

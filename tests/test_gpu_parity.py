@@ -1,0 +1,185 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same inputs
+and against the golden vectors of the real reference.  Bit-exact everywhere: filter bitmap,
+candidate mask, counters, sorted junction keys, junction ids, de_bruijn.bin bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, case_files, golden_cases, parse_log, sha256_file, text_codes
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_cases()
+SMALL = [c for c in CASES if c.get("fasta")]
+MAXU = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from twopaco_amd import capi as m
+    m.hip()
+    m.host()
+    return m
+
+
+def _oracle_for(case, tmp_path):
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in case_files(case, tmp_path):
+        o.add_fasta(f)
+    return o
+
+
+def test_library_is_the_hip_one(capi):
+    ctx = capi.Context(0)  # raises without a GPU: no fallback
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["rand6_k9_fp", "rand6_k9_L33", "c2_k51_r2", "edge_k5"])
+def test_vertex_hashes(capi, tmp_path, name):
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    assert (text_codes(text.bases, text.nmask, text.length) == o.text).all()
+    ctx = capi.Context(0)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    n = min(400, text.length - case["k"] - 1)
+    got = ctx.hash_dump(1, n)
+    for i in range(0, n, 7):
+        pn, _ = o.hash_dump(1 + i)
+        assert (got[i] == pn).all(), (name, i)
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
+def test_passes_match_oracle(capi, tmp_path, case):
+    """Every pass through the C-ABI == the oracle's state after the same pass."""
+    abundance = case["abundance"] if case["abundance"] is not None else MAXU
+    o = _oracle_for(case, tmp_path)
+    o.enumerate(rounds=case["n_rounds"], abundance=abundance)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    table = capi.seed_table(case["q"], case["L"], seed=case["seed"])
+    assert (table == o.table).all()
+    ctx.set_params(case["k"], case["L"], case["q"], table)
+    ctx.seq_upload(text)
+    for r in range(case["n_rounds"]):
+        st = o.round_stats(r)
+        ctx.filter_reset()
+        ctx.pass1_insert(st["low"], st["high"])
+        if r == case["n_rounds"] - 1:
+            assert (ctx.filter_download() == o.filter).all(), "Bloom filter bitmap differs"
+        marks = ctx.pass1_query(st["low"], st["high"])
+        assert marks == st["marks"] == case["rounds"][r]["marks"]
+        if r == case["n_rounds"] - 1:
+            assert (ctx.mask_download(False) == o.round_mask).all(), "candidate mask differs"
+        got = ctx.pass2_filter(abundance)
+        assert got == {"true": st["true"], "false": st["false"], "table": st["table"]}
+    assert (ctx.mask_download(True) == o.mask).all()
+    J = ctx.junctions_finalize()
+    assert J == case["distinct"]
+    assert (ctx.junction_keys() == o.keys).all(), "sorted junction keys differ"
+    n_marked, n_valid = ctx.emit()
+    g, ids = ctx.emit_fetch()
+    seq, pos, oid = o.records
+    real = np.abs(oid) <= J
+    og = o.rec_start[seq[real]] + pos[real].astype(np.uint64)
+    valid = ids != capi.INVALID_VERTEX
+    assert n_valid == int(valid.sum()) == int(real.sum())
+    assert (g[valid] == og).all() and (ids[valid] == oid[real]).all()
+    # GetId for every junction key and its reverse complement
+    letters = "ACGT"
+    for row in o.keys[:50]:
+        kmer = "".join(letters[(int(row[i >> 5]) >> (2 * (i & 31))) & 3] for i in range(case["k"]))
+        assert ctx.get_id(kmer) == o.get_id(kmer) != capi.INVALID_VERTEX
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] != "m1_full"], ids=[c["name"] for c in CASES if c["name"] != "m1_full"])
+def test_enumerator_matches_reference_golden(capi, tmp_path, case):
+    """CreateEnumerator (C++ host layer -> C-ABI -> HIP) writes the reference's bytes."""
+    out = str(tmp_path / "gpu.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"])
+    assert os.path.getsize(out) == case["bin_bytes"]
+    assert sha256_file(out) == case["bin_sha256"]
+    if case.get("bin"):
+        assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()
+    assert e.vertices_count() == case["distinct"]
+    log = parse_log(e.log)
+    assert log["true_marks"] == case["true_marks"]
+    if case["n_rounds"] == 1:
+        assert log["rounds"] == case["rounds"]
+    else:
+        # round boundaries come from a first-seen histogram whose arrival order is the hardware's
+        # (the reference's own boundaries move with -t); the per-round totals must still add up
+        assert sum(r["true"] for r in log["rounds"]) == case["distinct"]
+    e.close()
+
+
+def test_test_first_variant_same_filter(capi, tmp_path):
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp"][0]
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    filters = []
+    for tf in (0, 1):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_test_first", tf)
+        ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        filters.append(ctx.filter_download())
+        ctx.pass1_insert()  # idempotence: inserting again changes nothing
+        assert (ctx.filter_download() == filters[-1]).all()
+        ctx.close()
+    assert (filters[0] == filters[1]).all()
+
+
+def test_split_histogram_close_to_sequential(capi, tmp_path):
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp_r4"][0]
+    o = _oracle_for(case, tmp_path)
+    bins = o.split_bins()
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    rs, rl = text.rec_start, text.rec_length
+    keep = rl >= case["k"]
+    got = ctx.pass1_split_hist(rs[keep], rl[keep])
+    # same scratch filter (OR is order independent) ...
+    # ... and the same number of first-seen edges up to Bloom-collision order effects
+    assert abs(int(got.sum()) - int(bins.sum())) <= 0.02 * int(bins.sum()) + 4
+    ctx.close()
+
+
+def test_m1_full_size_bytes_equal_reference(capi, tmp_path):
+    """BASELINE.json configs[1] at full size (8 x 5 Mbp, k=25, f=32): the sha256 of the GPU path's
+    de_bruijn.bin equals the one the real reference produced (tests/golden/make_golden.py)."""
+    case = [c for c in CASES if c["name"] == "m1_full"][0]
+    out = str(tmp_path / "m1.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], threads=8)
+    assert os.path.getsize(out) == case["bin_bytes"]
+    assert sha256_file(out) == case["bin_sha256"]
+    assert parse_log(e.log)["rounds"] == case["rounds"]
+    e.close()
+
+
+def test_naive_positions_seed_free(capi, tmp_path):
+    """Random seeds (like the reference's own --test, test.cpp:163-254): positions == naive oracle."""
+    fa = os.path.join(GOLDEN, "rand6.fa")
+    chrs = O.read_fasta_records(fa)
+    for k, rounds in [(5, 1), (9, 2), (11, 3)]:
+        out = str(tmp_path / ("n%d.bin" % k))
+        e = capi.Enumerator([fa], k, 20, q=2, rounds=rounds, tmpdir=str(tmp_path), out=out, seed=None)
+        junction, marks = O.naive_junction_marks(chrs, k)
+        got = [np.zeros(len(c), dtype=bool) for c in chrs]
+        for s, p, _ in O.read_bin(out):
+            got[s][p] = True
+        for i in range(len(chrs)):
+            assert (got[i] == marks[i]).all()
+        for v in list(junction)[:200]:
+            assert e.get_id(v) != capi.INVALID_VERTEX
+        e.close()

@@ -1,0 +1,130 @@
+"""CPU: host-side logic and the C-ABI library surface (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, golden_cases, text_codes
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi(built):
+    from twopaco_amd import capi as m
+    return m
+
+
+def test_abi_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "twopaco_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(tpc_[a-z0-9_]+)\s*\(", header)) - {"tpc_urandom_word"})
+    assert declared == sorted(capi.HIP_SYMBOLS)
+    lib = capi.hip()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback_without_gpu(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        capi.Context(0)
+
+
+@pytest.mark.parametrize("L", [12, 20, 31, 32, 33, 36, 40])
+def test_seed_table_matches_oracle(capi, L):
+    for q in (1, 5, 8):
+        assert (capi.seed_table(q, L, seed=99) == O.seed_table(99, q, L)).all()
+    t = capi.seed_table(5, L)  # /dev/urandom
+    assert int(t.max()) < (1 << L)
+
+
+@pytest.mark.parametrize("fa", ["example.fa", "edge.fa", "rand6.fa", "c2.fa"])
+def test_text_packer_matches_oracle(capi, fa):
+    path = os.path.join(GOLDEN, fa)
+    t = capi.PackedText.from_fasta([path])
+    o = O.Oracle(5, 16, 1, O.seed_table(1, 1, 16))
+    o.add_fasta(path)
+    assert t.length == len(o.text)
+    assert (text_codes(t.bases, t.nmask, t.length) == o.text).all()
+    assert (t.rec_start == o.rec_start).all() and (t.rec_length == o.rec_len).all()
+    # N positions carry code 0 in the packed words
+    g = np.nonzero(o.text == 4)[0].astype(np.uint64)
+    assert (((t.bases[g >> np.uint64(5)] >> (np.uint64(2) * (g & np.uint64(31)))) & np.uint64(3)) == 0).all()
+
+
+def test_text_packer_from_codes_and_threads(capi, tmp_path):
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.001)
+    files = []
+    for i, r in enumerate(recs):
+        p = str(tmp_path / ("g%d.fa" % i))
+        synth.write_fasta(p, [r], first_id=i)
+        files.append(p)
+    a = capi.PackedText.from_codes(recs)
+    b = capi.PackedText.from_fasta(files, threads=4)
+    assert a.length == b.length and (a.bases == b.bases).all() and (a.nmask == b.nmask).all()
+    assert synth.n_kmers(recs, 25) == sum(r.size - 24 for r in recs)
+
+
+def test_fasta_errors(capi, tmp_path):
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">x\nACGT!ACGT\n")
+    with pytest.raises(RuntimeError, match="invalid character"):
+        capi.PackedText.from_fasta([str(bad)])
+    nohdr = tmp_path / "nohdr.fa"
+    nohdr.write_text("ACGT\n")
+    with pytest.raises(RuntimeError, match="should start with"):
+        capi.PackedText.from_fasta([str(nohdr)])
+    with pytest.raises(RuntimeError, match="Can't open"):
+        capi.PackedText.from_fasta([str(tmp_path / "missing.fa")])
+
+
+def test_cli_flags_and_errors(built):
+    exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
+    fa = os.path.join(GOLDEN, "example.fa")
+    r = subprocess.run([exe, "-k", "12", "-f", "20", fa], capture_output=True, text=True)
+    assert r.returncode == 1 and "value of K must be odd" in r.stderr
+    r = subprocess.run([exe, "-k", "11", fa], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error:" in r.stderr
+    r = subprocess.run([exe, "-k", "11", "-f", "20", "--filtermemory", "1", fa], capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([exe, "-f", "20"], capture_output=True, text=True)
+    assert r.returncode == 1 and "filenames" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "-k", "11", "-f", "20", fa], capture_output=True, text=True)
+        assert r.returncode == 1 and "GPU" in r.stderr  # fails loudly, no CPU path
+        assert "Vertex length = 11" in r.stdout
+
+
+def test_junction_api_header_roundtrip(built, tmp_path):
+    """host/junctionapi.h reads the reference's bytes and writes them back unchanged."""
+    src = r'''
+    #include "junctionapi.h"
+    #include <iostream>
+    int main(int argc, char ** argv) {
+        TwoPaCo::JunctionPositionReader reader(argv[1]);
+        TwoPaCo::JunctionPositionWriter writer(argv[2]);
+        TwoPaCo::JunctionPosition pos;
+        size_t n = 0;
+        while (reader.NextJunctionPosition(pos)) { writer.WriteJunction(pos); ++n; }
+        std::cout << n << std::endl;
+        return 0;
+    }'''
+    cpp = tmp_path / "rt.cpp"
+    cpp.write_text(src)
+    exe = str(tmp_path / "rt")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "twopaco_amd", "host"), str(cpp), "-o", exe])
+    for case in golden_cases():
+        if not case.get("bin"):
+            continue
+        out = str(tmp_path / "copy.bin")
+        n = subprocess.check_output([exe, os.path.join(GOLDEN, case["bin"]), out]).decode().strip()
+        assert int(n) == case["true_marks"]
+        assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()

@@ -1,0 +1,107 @@
+"""Seeded synthetic genome workloads shaped like BASELINE.json's configs.
+
+Real assemblies cannot be fetched (no network), so every workload is generated from a
+counter-based integer hash (splitmix64 finaliser over the base index): fully deterministic,
+independent of numpy's RNG streams, cheap to regenerate on the GPU box.
+
+  m1: 8 genomes x 5 Mbp, genome 0 uniform ACGT, genomes 1..7 = genome 0 with 1 % i.i.d.
+      substitutions (BASELINE.json configs[1], k=25 f=32)
+  m2: 62 E. coli-like genomes x 5 Mbp: 6 clades at 2 % from the root, members at 0.2 % from
+      their clade ancestor, N runs (length 1..100) covering ~0.1 % (configs[2], k=25 f=36)
+Codes: A0 C1 G2 T3, N = 4.
+"""
+import numpy as np
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix(x):
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= _M1
+        x ^= x >> np.uint64(27)
+        x *= _M2
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def _stream(seed, n, salt=0):
+    with np.errstate(over="ignore"):
+        base = np.uint64((seed * 0x9E3779B97F4A7C15 + salt * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
+        return _mix(np.arange(n, dtype=np.uint64) * _G + base)
+
+
+def random_genome(n, seed):
+    return (_stream(seed, n) >> np.uint64(62)).astype(np.uint8)
+
+
+def substitute(codes, rate, seed):
+    """i.i.d. substitutions at `rate`, uniform over the three other letters."""
+    r = _stream(seed, codes.size, 1)
+    hit = r < np.uint64(int(rate * 2.0 ** 64))
+    shift = (_stream(seed, codes.size, 2) % np.uint64(3)).astype(np.uint8) + np.uint8(1)
+    out = codes.copy()
+    out[hit] = (codes[hit] + shift[hit]) & np.uint8(3)
+    return out
+
+
+def add_n_runs(codes, start_rate, seed, max_len=100):
+    r = _stream(seed, codes.size, 3)
+    starts = np.nonzero(r < np.uint64(int(start_rate * 2.0 ** 64)))[0]
+    lens = (_stream(seed, starts.size, 4) % np.uint64(max_len)).astype(np.int64) + 1
+    out = codes.copy()
+    for s, l in zip(starts, lens):
+        out[s:s + l] = 4
+    return out
+
+
+def workload(name, seed=12345, scale=1.0):
+    """Returns (list of uint8 code arrays, dict(k, L, q)).  scale shrinks the genome length."""
+    if name == "m1":
+        n = int(5_000_000 * scale)
+        base = random_genome(n, seed)
+        recs = [base] + [substitute(base, 0.01, seed + 100 + i) for i in range(1, 8)]
+        return recs, dict(k=25, L=32, q=5)
+    if name == "m2":
+        n = int(5_000_000 * scale)
+        root = random_genome(n, seed)
+        recs = []
+        for g in range(62):
+            clade = g % 6
+            anc = substitute(root, 0.02, seed + 1000 + clade)
+            mem = substitute(anc, 0.002, seed + 2000 + g)
+            recs.append(add_n_runs(mem, 2e-5, seed + 3000 + g))
+        return recs, dict(k=25, L=36, q=5)
+    raise ValueError("unknown workload " + name)
+
+
+def n_kmers(recs, k):
+    """Vertex positions with an N-free window (what the first pass hashes)."""
+    total = 0
+    for r in recs:
+        if r.size < k:
+            continue
+        bad = np.concatenate([[0], np.cumsum(r == 4)])
+        total += int(np.count_nonzero(bad[k:] - bad[:-k] == 0))
+    return total
+
+
+_LETTERS = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def write_fasta(path, recs, first_id=0, width=80):
+    with open(path, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">%d\n" % (first_id + i))
+            s = _LETTERS[r]
+            full = (s.size // width) * width
+            if full:
+                body = np.empty((full // width, width + 1), dtype=np.uint8)
+                body[:, :width] = s[:full].reshape(-1, width)
+                body[:, width] = 10
+                f.write(body.tobytes())
+            if s.size > full:
+                f.write(s[full:].tobytes() + b"\n")
