@@ -70,6 +70,10 @@ int tpc_set_params(tpc_ctx *ctx, int k, int L, int q, const uint64_t *seed_table
  * T[0] and T[n_text-1] must be 'N'. */
 int tpc_seq_upload(tpc_ctx *ctx, const uint64_t *bases, const uint32_t *nmask, uint64_t n_text);
 
+/* Start a new enumeration over the uploaded text: forgets the junction keys, masks and round
+ * state of the previous run (the reference builds a fresh VertexEnumerator per run, VE.h:122). */
+int tpc_run_begin(tpc_ctx *ctx);
+
 /* ConcurrentBitVector(2^L) construction = zero fill (concurrentbitvector.cpp:11-24, VE.h:257). */
 int tpc_filter_reset(tpc_ctx *ctx);
 

@@ -13,7 +13,7 @@ KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 
 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
-               "tpc_filter_reset", "tpc_pass1_insert", "tpc_pass1_split_hist", "tpc_pass1_query", "tpc_pass2_filter",
+               "tpc_run_begin", "tpc_filter_reset", "tpc_pass1_insert", "tpc_pass1_split_hist", "tpc_pass1_query", "tpc_pass2_filter",
                "tpc_junctions_finalize", "tpc_key_words", "tpc_junction_keys", "tpc_get_id", "tpc_emit",
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option"]
@@ -41,6 +41,7 @@ def hip():
         L.tpc_set_params.argtypes = [p, ci, ci, ci, p]
         L.tpc_seq_upload.argtypes = [p, p, p, u64]
         L.tpc_filter_reset.argtypes = [p]
+        L.tpc_run_begin.argtypes = [p]
         L.tpc_pass1_insert.argtypes = [p, u64, u64, p]
         L.tpc_pass1_split_hist.argtypes = [p, p, p, ctypes.c_uint32, p]
         L.tpc_pass1_query.argtypes = [p, u64, u64, p]
@@ -197,6 +198,9 @@ class Context:
     def seq_upload(self, text):
         b, n = np.ascontiguousarray(text.bases), np.ascontiguousarray(text.nmask)
         self._ck(hip().tpc_seq_upload(self._h, b.ctypes.data, n.ctypes.data, text.length))
+
+    def run_begin(self):
+        self._ck(hip().tpc_run_begin(self._h))
 
     def filter_reset(self):
         self._ck(hip().tpc_filter_reset(self._h))

@@ -248,6 +248,14 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     return 0;
 }
 
+int tpc_run_begin(tpc_ctx *c)
+{
+    if (!c) return -1;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    c->n_marks = 0; c->n_emit = 0; c->keys_host.clear();
+    return 0;
+}
+
 int tpc_filter_reset(tpc_ctx *c)
 {
     if (!c || !c->have_params) return fail(c, -1, "set_params first");

@@ -102,6 +102,8 @@ namespace TwoPaCo
 				Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
 
+				Check(tpc_run_begin(ctx_), "run_begin");
+
 				// records the reference dispatches: at least k bases (vertexenumerator.h:1177)
 				std::vector<uint64_t> dispStart, dispLength;
 				for (size_t r = 0; r < text.recStart.size(); r++)
