@@ -137,6 +137,54 @@ def test_test_first_variant_same_filter(capi, tmp_path):
     assert (filters[0] == filters[1]).all()
 
 
+@pytest.mark.parametrize("name,slice_bits", [("rand6_k9_fp", 8), ("rand6_k9_fp", 10), ("rand6_k9_q8", 9), ("rand6_k9_q1", 12),
+                                             ("rand6_k25_q3", 12), ("rand6_k9_L33", 20), ("c2_k51_r2", 16), ("edge_k5", 7),
+                                             ("rand6_k9_fp_r4", 9)])
+def test_partitioned_insert_matches_oracle(capi, tmp_path, name, slice_bits):
+    """The LDS write-combining insert (tpc_partition.hip) builds the same filter bitmap as the
+    oracle's FilterFillerWorker, for the whole range and for a gated round range."""
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    ctx.set_option("insert_mode", 2)
+    ctx.set_option("slice_bits", slice_bits)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+    for lo, hi in ranges:
+        o.fill_only(lo, hi)
+        ctx.filter_reset()
+        n = ctx.pass1_insert(lo, hi)
+        assert (ctx.filter_download() == o.filter).all(), (name, lo, hi)
+        # accumulate mode: inserting again into the non-empty filter changes nothing
+        ctx.pass1_insert(lo, hi)
+        assert (ctx.filter_download() == o.filter).all()
+    from twopaco_amd import synth
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [3000, 3000000])
+def test_partitioned_insert_adversarial_skew(capi, n):
+    """poly-A: every address lands in the same bins -> LDS bins and regions overflow -> overflow list
+    (n small) or the direct-kernel fallback (n large).  Same bitmap as the direct kernel."""
+    recs = [np.zeros(n, dtype=np.uint8), np.full(500, 3, dtype=np.uint8)]
+    text = capi.PackedText.from_codes(recs)
+    filters = []
+    for mode in (1, 2):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_option("slice_bits", 12)
+        ctx.set_params(25, 24, 5, capi.seed_table(5, 24, seed=3))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        assert ctx.pass1_insert() == n - 24 + 500 - 24
+        filters.append(ctx.filter_download())
+        ctx.close()
+    assert (filters[0] == filters[1]).all()
+    assert 5 <= int(np.unpackbits(filters[0].view(np.uint8)).sum()) <= 40
+
+
 def test_split_histogram_close_to_sequential(capi, tmp_path):
     case = [c for c in CASES if c["name"] == "rand6_k9_fp_r4"][0]
     o = _oracle_for(case, tmp_path)

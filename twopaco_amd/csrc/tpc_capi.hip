@@ -54,6 +54,13 @@ struct tpc_ctx {
     unsigned long long *counters = nullptr;  // device, 8 words
     // options
     int opt_test_first = 0;
+    int opt_insert_mode = 0;   // 0 auto, 1 direct atomicOr, 2 partitioned (LDS write-combining)
+    int opt_slice_bits = 20;
+    // partitioned insert
+    bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
+    void *pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t pbytes[6] = {0, 0, 0, 0, 0, 0};
+    int last_insert_mode = 0;
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
@@ -122,6 +129,15 @@ int read_counter(tpc_ctx *c, int i, uint64_t *out)
     return 0;
 }
 
+int materialize_reset(tpc_ctx *c)
+{   // a pending tpc_filter_reset becomes a real zero fill before anything reads the filter
+    if (!c->filter_zero_pending) return 0;
+    Timed t(c, TPC_K_FILTER_RESET);
+    HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
+    c->filter_zero_pending = false;
+    return 0;
+}
+
 int compact_mask(tpc_ctx *c, const uint32_t *m)
 {   // ordered list of the set bits of m -> c->marks / c->n_marks
     Timed t(c, TPC_K_COMPACT);
@@ -166,7 +182,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->counters };
+                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -180,6 +196,8 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return -1;
     if (!strcmp(name, "insert_test_first")) { c->opt_test_first = value != 0; return 0; }
+    if (!strcmp(name, "insert_mode")) { c->opt_insert_mode = (int)value; return 0; }
+    if (!strcmp(name, "slice_bits")) { c->opt_slice_bits = (int)value; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -224,7 +242,7 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     if (!((nmask[0] & 1u) && ((nmask[(n_text - 1) >> 5] >> ((n_text - 1) & 31)) & 1u)))
         return fail(c, -1, "text must start and end with the N separator");
     const uint64_t tiles = (nw + TPC_TILE_THREADS - 1) / TPC_TILE_THREADS;
-    const uint64_t alloc = tiles * TPC_TILE_THREADS + TPC_XW_MAX + 2;
+    const uint64_t alloc = ((nw + 511) / 512) * 512 + TPC_XW_MAX + 2;  // covers the 256- and 512-word tilings
     for (void *p : { (void *)c->bases, (void *)c->nmask, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
         if (p) (void)hipFree(p);
     c->bases = nullptr; c->nmask = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
@@ -259,9 +277,10 @@ int tpc_run_begin(tpc_ctx *c)
 int tpc_filter_reset(tpc_ctx *c)
 {
     if (!c || !c->have_params) return fail(c, -1, "set_params first");
-    HIPCHK(c, hipSetDevice(c->device));
-    Timed t(c, TPC_K_FILTER_RESET);
-    HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
+    // Lazy: the partitioned insert writes every slice of the filter itself, so the zero fill is
+    // only materialised (hipMemsetAsync, timed as TPC_K_FILTER_RESET) when something else needs it.
+    c->filter_zero_pending = true;
+    c->ev_used[TPC_K_FILTER_RESET] = false;
     return 0;
 }
 
@@ -271,11 +290,54 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+    TpcPartPlan pl;
+    bool part = c->opt_insert_mode != 1 && tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, c->n_text, pl);
+    if (c->opt_insert_mode == 0 && c->P.L < 28) part = false;  // small filters: the direct kernel is as fast
+    if (part) {
+        const size_t need[6] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                                 pl.ovf_cap * sizeof(uint64_t), 2 * sizeof(unsigned long long) };
+        for (int i = 0; i < 6; i++) {
+            if (need[i] > c->pbytes[i]) {
+                if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
+                c->pbuf[i] = nullptr; c->pbytes[i] = 0;
+                if (hipMalloc(&c->pbuf[i], need[i]) != hipSuccess) { part = false; break; }  // not enough HBM: direct path
+                c->pbytes[i] = need[i];
+            }
+        }
+    }
+    if (part) {
+        pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
+        pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        const bool fresh = c->filter_zero_pending;
+        unsigned long long ov[2] = {0, 0};
+        {
+            Timed t(c, TPC_K_INSERT);
+            HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 2 * sizeof(unsigned long long), c->stream));
+            if (fresh) HIPCHK(c, hipMemsetAsync(c->filter + (c->filter_words - 1), 0, sizeof(uint32_t), c->stream));
+            if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
+                return fail(c, -1, "partitioned insert launch failed");
+        }
+        c->filter_zero_pending = false;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->last_insert_mode = 2;
+        if (ov[1] == 0) {
+            if (n_kmers) return read_counter(c, 0, n_kmers);
+            return 0;
+        }
+        // the overflow list itself overflowed (pathological skew): OR is idempotent, so running the
+        // direct kernel on top completes the filter
+        if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+    }
+    int rc = materialize_reset(c);
+    if (rc) return rc;
     {
         Timed t(c, TPC_K_INSERT);
         if (tpc_launch_insert(make_launch(c), lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
             return fail(c, -1, "insert launch failed");
     }
+    c->last_insert_mode = 1;
     HIPCHK(c, hipGetLastError());
     if (n_kmers) return read_counter(c, 0, n_kmers);
     return 0;
@@ -286,6 +348,7 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     if (!c || !c->have_params || !c->bases || !bins_host) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t BINS = 1ull << 24;  // VE.h:471
+    c->filter_zero_pending = false;  // the split pass zeroes its scratch filter itself
     // positions where a (k+1)-mer of 'N'+record+'N' starts, for dispatched records only (VE.h:1177)
     std::vector<uint32_t> em(c->n_words_alloc, 0u);
     for (uint32_t r = 0; r < n_rec; r++) {
@@ -323,6 +386,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
     {
         Timed t(c, TPC_K_QUERY);
@@ -526,6 +590,7 @@ int tpc_filter_download(tpc_ctx *c, uint32_t *words_host)
 {
     if (!c || !c->filter) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(words_host, c->filter, c->filter_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;

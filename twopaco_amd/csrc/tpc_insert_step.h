@@ -1,0 +1,101 @@
+// tpc_insert_step.h -- the per-position body of the first-pass insert, shared by the direct
+// (atomicOr) kernel and the partitioned (LDS write-combining) kernel so that the parity-critical
+// logic exists once.  Restates FilterFillerWorker::operator(), reference
+// src/graphconstructor/vertexenumerator.h:1035-1083.
+#pragma once
+#include "tpc_device.h"
+
+// Rolling state of one thread's run of consecutive vertex positions.
+template <int Q>
+struct TpcRoll {
+    TpcVHash<Q> v;
+    int ncnt;     // N characters inside the current window (k - definiteCount, VE.h:1033)
+    int c_prev;   // character before the window
+    int c_first;  // first character of the window
+};
+
+template <int Q>
+__device__ __forceinline__ void tpc_roll_init(TpcRoll<Q> &r, const TpcHashParams &P, const uint64_t *s_h,
+                                              const uint64_t *sb, const uint32_t *sn, uint64_t g0, uint64_t wbase)
+{
+    tpc_vhash_init<Q>(r.v, P, s_h, sb, sn, g0, wbase);
+    r.ncnt = 0;
+    for (int t = 0; t < P.k; t++) r.ncnt += tpc_tile_char(sb, sn, g0 + t, wbase) == TPC_CODE_N;
+    r.c_prev = tpc_tile_char(sb, sn, g0 - 1, wbase);
+    r.c_first = tpc_tile_char(sb, sn, g0, wbase);
+}
+
+template <int Q, class Emit>
+__device__ __forceinline__ void tpc_emit_edge(Emit &emit, const uint64_t (&p)[Q], const uint64_t (&n)[Q])
+{
+    const bool neg = tpc_pick_neg<Q>(p, n);
+#pragma unroll
+    for (int i = 0; i < Q; i++) emit(neg ? n[i] : p[i]);
+}
+
+// One position: emits the Bloom addresses of the window at g (if N-free and inside the round's
+// range), then rolls to g+1.  Returns true when the window was an N-free vertex.
+template <int Q, bool GATED, class Emit>
+__device__ __forceinline__ bool tpc_insert_step(TpcRoll<Q> &r, const TpcHashParams &P, const uint64_t *s_h, const uint64_t *s_hk,
+                                                const uint64_t *sb, const uint32_t *sn, uint64_t g, uint64_t wbase,
+                                                uint64_t lo, uint64_t hi, Emit &emit)
+{
+    TpcVHash<Q> &v = r.v;
+    const int c_next = tpc_tile_char(sb, sn, g + P.k, wbase);
+    const int c_first_nx = tpc_tile_char(sb, sn, g + 1, wbase);
+    const int c_first = r.c_first;
+    uint64_t r1p[Q], ep[Q], en[Q], npos[Q], nneg[Q];
+    // hash_extend / hash_prepend of the outgoing edge (cyclichash.h:112-121) are the
+    // intermediates of update / reverse_update (cyclichash.h:86-102).
+#pragma unroll
+    for (int i = 0; i < Q; i++) {
+        r1p[i] = tpc_rotl1(v.pos[i], P.L, P.lmask);
+        ep[i] = r1p[i] ^ s_h[i * 5 + c_next];
+        en[i] = v.neg[i] ^ s_hk[i * 5 + tpc_rc(c_next)];
+        npos[i] = ep[i] ^ s_hk[i * 5 + c_first];
+        nneg[i] = tpc_rotr1(en[i] ^ s_h[i * 5 + tpc_rc(c_first)], P.L);
+    }
+    const bool vertex = r.ncnt == 0;
+    if (vertex) {
+        bool go = true;
+        if (GATED) {  // VE.h:1063-1073
+            const uint64_t first = tpc_min(v.pos[0], v.neg[0]);
+            const uint64_t second = tpc_min(npos[0], nneg[0]);
+            go = (first >= lo && first <= hi) || (second >= lo && second <= hi);
+        }
+        if (go) {
+            if (c_next != TPC_CODE_N) {
+                tpc_emit_edge<Q>(emit, ep, en);
+            } else {  // dummy out-edges v+'A', v+'T' (VE.h:1048-1052)
+                uint64_t p[Q], n[Q];
+#pragma unroll
+                for (int i = 0; i < Q; i++) { p[i] = r1p[i] ^ s_h[i * 5 + 0]; n[i] = v.neg[i] ^ s_hk[i * 5 + 3]; }
+                tpc_emit_edge<Q>(emit, p, n);
+#pragma unroll
+                for (int i = 0; i < Q; i++) { p[i] = r1p[i] ^ s_h[i * 5 + 3]; n[i] = v.neg[i] ^ s_hk[i * 5 + 0]; }
+                tpc_emit_edge<Q>(emit, p, n);
+            }
+            if (r.c_prev == TPC_CODE_N) {  // dummy in-edges 'A'+v, 'T'+v (VE.h:1054-1058)
+                uint64_t p[Q], n[Q];
+#pragma unroll
+                for (int i = 0; i < Q; i++) {
+                    p[i] = s_hk[i * 5 + 0] ^ v.pos[i];
+                    n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3];
+                }
+                tpc_emit_edge<Q>(emit, p, n);
+#pragma unroll
+                for (int i = 0; i < Q; i++) {
+                    p[i] = s_hk[i * 5 + 3] ^ v.pos[i];
+                    n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask) ^ s_h[i * 5 + 0];
+                }
+                tpc_emit_edge<Q>(emit, p, n);
+            }
+        }
+    }
+    r.ncnt += (c_next == TPC_CODE_N) - (c_first == TPC_CODE_N);
+#pragma unroll
+    for (int i = 0; i < Q; i++) { v.pos[i] = npos[i]; v.neg[i] = nneg[i]; }
+    r.c_prev = c_first;
+    r.c_first = c_first_nx;
+    return vertex;
+}

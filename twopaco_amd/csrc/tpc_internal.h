@@ -23,6 +23,25 @@ int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t 
 int tpc_launch_split(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, uint64_t bin_size);
 int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *out);
 
+// partitioned insert (tpc_partition.hip)
+struct TpcPartPlan {
+    int slice_bits, b1, b2, pos_per_round;
+    uint64_t n_tiles;     // 512-word tiles of the text
+    uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
+    uint64_t cap1, cap2;  // entries per private region (multiples of 32)
+    uint64_t ovf_cap;
+    uint32_t *buf1, *cnt1, *buf2, *cnt2;
+    uint64_t *ovf;
+    unsigned long long *ovf_cur;  // [0] count, [1] overflow-of-overflow flag
+};
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_text, TpcPartPlan &pl);
+size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
+size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl);
+size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
+size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
+int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
+                                  unsigned long long *n_kmers);
+
 // pass 2 / output (tpc_pass2.hip)
 // Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of
 // n_words/256+2 uint64; *n_out (device) receives the list length; list must hold it (two-phase:

@@ -14,6 +14,7 @@
 //   InitialFilterFillerWorker  VE.h:503-583     -> k_split
 //   VertexRollingHash          graphconstructor/vertexrollinghash.h:54-252
 #include "tpc_device.h"
+#include "tpc_insert_step.h"
 #include "tpc_internal.h"
 
 namespace {
@@ -40,18 +41,22 @@ __device__ __forceinline__ bool get_bit(const uint32_t *filter, uint64_t a)
     return (filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u;
 }
 
-template <int Q, bool TEST>
-__device__ __forceinline__ void insert_edge(uint32_t *filter, const uint64_t (&p)[Q], const uint64_t (&n)[Q])
-{
-    const bool neg = tpc_pick_neg<Q>(p, n);
-#pragma unroll
-    for (int i = 0; i < Q; i++) insert_bit<TEST>(filter, neg ? n[i] : p[i]);
-}
+template <bool TEST>
+struct DirectEmit {
+    uint32_t *filter;
+    __device__ __forceinline__ void operator()(uint64_t a) { insert_bit<TEST>(filter, a); }
+};
 
-__device__ __forceinline__ void wave_add(unsigned long long *dst, unsigned v)
+// one atomic per workgroup (same-address device atomics serialise at ~12 ns each)
+__device__ __forceinline__ void block_add(unsigned long long *dst, unsigned v, uint32_t *s_w)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (t) atomicAdd(dst, (unsigned long long)t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -75,72 +80,14 @@ k_insert(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__re
     const uint64_t g0 = (wfirst + tid) * TPC_RUN;
     unsigned hashed = 0;
     if (g0 < n_text) {
-        TpcVHash<Q> v;
-        tpc_vhash_init<Q>(v, P, s_h, s_b, s_n, g0, wbase);
-        int ncnt = 0;  // N characters inside the current window (k - definiteCount, VE.h:1033)
-        for (int t = 0; t < P.k; t++) ncnt += tpc_tile_char(s_b, s_n, g0 + t, wbase) == TPC_CODE_N;
-        int c_prev = tpc_tile_char(s_b, s_n, g0 - 1, wbase);
-        int c_first = tpc_tile_char(s_b, s_n, g0, wbase);
-        for (int s = 0; s < TPC_RUN; s++) {
-            const uint64_t g = g0 + s;
-            const int c_next = tpc_tile_char(s_b, s_n, g + P.k, wbase);
-            const int c_first_nx = tpc_tile_char(s_b, s_n, g + 1, wbase);
-            uint64_t r1p[Q], ep[Q], en[Q], npos[Q], nneg[Q];
-            // hash_extend / hash_prepend of the outgoing edge (cyclichash.h:112-121) are the
-            // intermediates of update / reverse_update (cyclichash.h:86-102).
-#pragma unroll
-            for (int i = 0; i < Q; i++) {
-                r1p[i] = tpc_rotl1(v.pos[i], P.L, P.lmask);
-                ep[i] = r1p[i] ^ s_h[i * 5 + c_next];
-                en[i] = v.neg[i] ^ s_hk[i * 5 + tpc_rc(c_next)];
-                npos[i] = ep[i] ^ s_hk[i * 5 + c_first];
-                nneg[i] = tpc_rotr1(en[i] ^ s_h[i * 5 + tpc_rc(c_first)], P.L);
-            }
-            if (ncnt == 0) {
-                hashed++;
-                bool go = true;
-                if (GATED) {  // VE.h:1063-1073
-                    const uint64_t first = tpc_min(v.pos[0], v.neg[0]);
-                    const uint64_t second = tpc_min(npos[0], nneg[0]);
-                    go = within(first, lo, hi) || within(second, lo, hi);
-                }
-                if (go) {
-                    if (c_next != TPC_CODE_N) {
-                        insert_edge<Q, TEST>(filter, ep, en);
-                    } else {  // dummy out-edges v+'A', v+'T' (VE.h:1048-1052)
-                        uint64_t p[Q], n[Q];
-#pragma unroll
-                        for (int i = 0; i < Q; i++) { p[i] = r1p[i] ^ s_h[i * 5 + 0]; n[i] = v.neg[i] ^ s_hk[i * 5 + 3]; }
-                        insert_edge<Q, TEST>(filter, p, n);
-#pragma unroll
-                        for (int i = 0; i < Q; i++) { p[i] = r1p[i] ^ s_h[i * 5 + 3]; n[i] = v.neg[i] ^ s_hk[i * 5 + 0]; }
-                        insert_edge<Q, TEST>(filter, p, n);
-                    }
-                    if (c_prev == TPC_CODE_N) {  // dummy in-edges 'A'+v, 'T'+v (VE.h:1054-1058)
-                        uint64_t p[Q], n[Q];
-#pragma unroll
-                        for (int i = 0; i < Q; i++) {
-                            p[i] = s_hk[i * 5 + 0] ^ v.pos[i];
-                            n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3];
-                        }
-                        insert_edge<Q, TEST>(filter, p, n);
-#pragma unroll
-                        for (int i = 0; i < Q; i++) {
-                            p[i] = s_hk[i * 5 + 3] ^ v.pos[i];
-                            n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask) ^ s_h[i * 5 + 0];
-                        }
-                        insert_edge<Q, TEST>(filter, p, n);
-                    }
-                }
-            }
-            ncnt += (c_next == TPC_CODE_N) - (c_first == TPC_CODE_N);
-#pragma unroll
-            for (int i = 0; i < Q; i++) { v.pos[i] = npos[i]; v.neg[i] = nneg[i]; }
-            c_prev = c_first;
-            c_first = c_first_nx;
-        }
+        TpcRoll<Q> r;
+        tpc_roll_init<Q>(r, P, s_h, s_b, s_n, g0, wbase);
+        DirectEmit<TEST> emit{filter};
+        for (int s = 0; s < TPC_RUN; s++)
+            hashed += tpc_insert_step<Q, GATED>(r, P, s_h, s_hk, s_b, s_n, g0 + s, wbase, lo, hi, emit);
     }
-    if (n_kmers) wave_add(n_kmers, hashed);
+    __shared__ uint32_t s_w[4];
+    if (n_kmers) block_add(n_kmers, hashed, s_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -268,7 +215,8 @@ k_query(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
         }
     }
     rmask[wfirst + tid] = word;
-    wave_add(n_marks, (unsigned)__popc(word));
+    __shared__ uint32_t s_w[4];
+    block_add(n_marks, (unsigned)__popc(word), s_w);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #include "tpc_device.h"
 #include "tpc_internal.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 
 namespace {
 
@@ -52,6 +53,20 @@ __device__ __forceinline__ void wave_add64(unsigned long long *dst, unsigned v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// One atomic per workgroup: same-address device atomics serialise at ~12 ns each, so per-wave
+// counters from a large grid cost milliseconds (measured: 2 M of them = 19 ms in k_scan2).
+__device__ __forceinline__ void block_add64(unsigned long long *dst, unsigned v, uint32_t *s_w)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (t) atomicAdd(dst, (unsigned long long)t);
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------- mask -> ordered position list
@@ -254,36 +269,36 @@ k_scan2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
     __shared__ uint64_t s_h0[4];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_w[4];
     unsigned used = 0, tp = 0;
-    if (s < cap) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) {
         const Slot sl = table[s];
-        if (sl.key != EMPTY) {
-            used = 1;
-            const uint64_t cnt = sl.meta >> META_COUNT_SHIFT;
-            const unsigned pm = (unsigned)sl.meta & 31u, nm = (unsigned)(sl.meta >> META_NEXT_SHIFT) & 31u;
-            const bool bif = cnt >= 2 && (__popc(pm) > 1 || __popc(nm) > 1 || (pm & 16u) || (nm & 16u));
-            if (bif && cnt <= abundance) {
-                tp = 1;
-                if (keys_out) {
-                    const unsigned long long o = atomicAdd(cursor, 1ull);
-                    if (C == 1) {
-                        keys_out[o] = sl.key;
-                    } else {
-                        uint64_t fw[C], rc[C];
-                        load_kmer<C>(bases, marks[sl.key], P.k, fw);
-                        revcomp_kmer<C>(fw, P.k, rc);
-                        const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+        if (sl.key == EMPTY) continue;
+        used++;
+        const uint64_t cnt = sl.meta >> META_COUNT_SHIFT;
+        const unsigned pm = (unsigned)sl.meta & 31u, nm = (unsigned)(sl.meta >> META_NEXT_SHIFT) & 31u;
+        const bool bif = cnt >= 2 && (__popc(pm) > 1 || __popc(nm) > 1 || (pm & 16u) || (nm & 16u));
+        if (bif && cnt <= abundance) {
+            tp++;
+            if (keys_out) {
+                const unsigned long long o = atomicAdd(cursor, 1ull);
+                if (C == 1) {
+                    keys_out[o] = sl.key;
+                } else {
+                    uint64_t fw[C], rc[C];
+                    load_kmer<C>(bases, marks[sl.key], P.k, fw);
+                    revcomp_kmer<C>(fw, P.k, rc);
+                    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
 #pragma unroll
-                        for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
-                    }
+                    for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
                 }
             }
         }
     }
     if (!keys_out) {
-        wave_add64(&counters[0], tp);
-        wave_add64(&counters[1], used);
+        block_add64(&counters[0], tp, s_w);
+        block_add64(&counters[1], used, s_w);
     }
 }
 
@@ -312,9 +327,10 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
     __shared__ uint64_t s_h0[4];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_w[4];
     unsigned valid = 0;
-    if (idx < n_marks) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_marks; idx += stride) {
         int64_t id = INT64_MAX;
         if (J > 0) {
             const uint64_t g = marks[idx];
@@ -334,7 +350,7 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
                 for (int w = 0; w < C; w++) sk[w] = keys[(uint64_t)(r - 1) * C + w];
                 if (keys_equal<C>(sk, ck)) {
                     id = keys_equal<C>(ck, fw) ? (int64_t)r : -(int64_t)r;
-                    valid = 1;
+                    valid++;
                     break;
                 }
                 slot = (slot + 1) & mask;
@@ -342,7 +358,7 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
         }
         ids[idx] = id;
     }
-    wave_add64(n_valid, valid);
+    block_add64(n_valid, valid, s_w);
 }
 
 // gather / permutation helpers for the multi-word key sort
@@ -417,7 +433,7 @@ int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_
 int tpc_launch_scan2(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance,
                      unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor)
 {
-#define CALL(C_) hipLaunchKernelGGL((k_scan2<C_>), dim3(nblk(cap, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, abundance, counters, keys_out, cursor)
+#define CALL(C_) hipLaunchKernelGGL((k_scan2<C_>), dim3(std::min<unsigned>(nblk(cap, 256), 8192u)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, abundance, counters, keys_out, cursor)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
@@ -486,7 +502,7 @@ int tpc_launch_emit(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n
                     const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid)
 {
     if (n_marks == 0) return 0;
-#define CALL(C_) hipLaunchKernelGGL((k_emit<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, keys, J, idtab, cap, ids, n_valid)
+#define CALL(C_) hipLaunchKernelGGL((k_emit<C_>), dim3(std::min<unsigned>(nblk(n_marks, 256), 16384u)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, keys, J, idtab, cap, ids, n_valid)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
