@@ -109,6 +109,13 @@ int tpc_key_words(const tpc_ctx *ctx);
 /* Sorted junction keys, n_junctions x key_words uint64 (what bifurcations.bin holds, sorted). */
 int tpc_junction_keys(tpc_ctx *ctx, uint64_t *keys_host);
 
+/* Junction keys appended so far by tpc_pass2_filter, unsorted (the content of the reference's
+ * bifurcations.bin scratch file, VE.h:219,1228-1256): *n receives their number; keys_host (may be
+ * NULL to query n only) receives n x key_words words.  tpc_junction_keys_set replaces the set --
+ * the multi-GPU driver uses the pair to union the per-rank sets before tpc_junctions_finalize. */
+int tpc_junction_keys_raw(tpc_ctx *ctx, uint64_t *keys_host, uint64_t *n);
+int tpc_junction_keys_set(tpc_ctx *ctx, const uint64_t *keys_host, uint64_t n);
+
 /* BifurcationStorage::GetId (bifurcationstorage.h:100-127) for one k-mer given as k ASCII
  * characters: +(rank+1), -(rank+1) or TPC_INVALID_VERTEX.  Host-side binary search over the
  * downloaded keys (VertexEnumerator::GetId is a cold query API, VE.h:99-102). */

@@ -57,6 +57,11 @@ def lib():
         L.orc_hash_dump.argtypes = [p, u64, p, ctypes.c_int, p]
         L.orc_fill_only.argtypes = [p, u64, u64]
         L.orc_split_bins.argtypes = [p, p]
+        L.orc_dist_begin.argtypes = [p]
+        L.orc_dist_round.argtypes = [p, u64, u64, u64, p]
+        L.orc_set_keys.argtypes = [p, p, u64]
+        L.orc_lookup_marks.restype = u64
+        L.orc_lookup_marks.argtypes = [p, p, p, u64]
         L.orc_check_only.restype = u64
         L.orc_check_only.argtypes = [p, u64, u64]
         _lib = L
@@ -112,6 +117,26 @@ class Oracle:
 
     def fill_only(self, low=0, high=None):
         lib().orc_fill_only(self._h, low, (1 << self.L) if high is None else high)
+
+    # --- per-round primitives (multi-process tests) ------------------------------------
+    def dist_begin(self):
+        lib().orc_dist_begin(self._h)
+
+    def dist_round(self, low, high, abundance=(1 << 64) - 1):
+        st = np.zeros(4, dtype=np.uint64)
+        lib().orc_dist_round(self._h, low, high, abundance, st.ctypes.data)
+        return {"true": int(st[0]), "false": int(st[1]), "table": int(st[2]), "marks": int(st[3])}
+
+    def set_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        lib().orc_set_keys(self._h, keys.ctypes.data, keys.shape[0])
+
+    def lookup_marks(self):
+        n = lib().orc_lookup_marks(self._h, None, None, 0)
+        g = np.zeros(n, dtype=np.uint64)
+        ids = np.zeros(n, dtype=np.int64)
+        lib().orc_lookup_marks(self._h, g.ctypes.data, ids.ctypes.data, n)
+        return g, ids
 
     def split_bins(self):
         bins = np.zeros(1 << 24, dtype=np.uint32)

@@ -771,6 +771,57 @@ void orc_hash_dump(const orc_run *R, uint64_t g, uint64_t *posneg, int c, uint64
     if (c >= 0 && c <= 4) edge_out(R, &v, c, addr);
 }
 
+/* ---- per-round primitives (used by the multi-process tests: one vertex-hash range per rank) ---- */
+int orc_dist_begin(orc_run *R)
+{
+    uint64_t mw = (R->ntxt >> 5) + 1;
+    free(R->mask); free(R->rmask); free(R->filter); free(R->keys);
+    R->mask = (uint32_t *)calloc(mw, sizeof(uint32_t));
+    R->rmask = (uint32_t *)calloc(mw, sizeof(uint32_t));
+    R->filter = (uint32_t *)malloc(filter_words(R) * sizeof(uint32_t));
+    R->keys = NULL; R->nkeys = 0; R->nout = 0;
+    return 0;
+}
+
+/* one round of VE.h:228-392 for the range [low,high]; stats = true,false,table,marks */
+int orc_dist_round(orc_run *R, uint64_t low, uint64_t high, uint64_t abundance, uint64_t *stats)
+{
+    uint32_t *run = build_run_lengths(R);
+    uint64_t mw = (R->ntxt >> 5) + 1;
+    memset(R->filter, 0, filter_words(R) * sizeof(uint32_t));
+    memset(R->rmask, 0, mw * sizeof(uint32_t));
+    fill_pass(R, run, low, high);
+    uint64_t marks = check_pass(R, run, low, high);
+    filter_pass(R, marks, abundance, 0);
+    for (uint64_t i = 0; i < mw; i++) R->mask[i] |= R->rmask[i];
+    stats[0] = R->r_true[0]; stats[1] = R->r_false[0]; stats[2] = R->r_table[0]; stats[3] = marks;
+    free(run);
+    return 0;
+}
+
+int orc_set_keys(orc_run *R, const uint64_t *keys, uint64_t n)
+{
+    free(R->keys);
+    R->keys = (uint64_t *)malloc((n + 1) * R->C * sizeof(uint64_t));
+    memcpy(R->keys, keys, n * R->C * sizeof(uint64_t));
+    R->nkeys = n;
+    key_cmp_C = R->C;
+    qsort(R->keys, R->nkeys, R->C * sizeof(uint64_t), key_cmp);
+    return 0;
+}
+
+/* ids of the marked positions of the run-wide mask, increasing g; returns their number */
+uint64_t orc_lookup_marks(orc_run *R, uint64_t *g_out, int64_t *id_out, uint64_t cap)
+{
+    uint64_t n = 0;
+    for (uint64_t g = 1; g + R->k < R->ntxt; g++) {
+        if (!bit_get(R->mask, g)) continue;
+        if (n < cap) { g_out[n] = g; id_out[n] = get_id(R, R->txt + g); }
+        n++;
+    }
+    return n;
+}
+
 /* Split-pass bins only (2^24 counters, caller-provided). */
 int orc_split_bins(orc_run *R, uint32_t *bins)
 {

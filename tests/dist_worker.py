@@ -1,0 +1,71 @@
+"""Worker of the world_size-2 tests (spawned by test_dist_cpu.py / test_gpu_dist.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleBackend:
+    """CPU stand-in for the HIP backend -- TEST ONLY: lets the rank orchestration (ranges, key
+    union, id lookup, record merge) run under gloo without a GPU."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def run_begin(self):
+        self.o.dist_begin()
+
+    def round(self, lo, hi, abundance):
+        return self.o.dist_round(lo, hi, abundance)
+
+    def local_keys(self):
+        return self.o.keys
+
+    def set_keys(self, keys):
+        self.o.set_keys(keys)
+
+    def finalize(self):
+        return len(self.o.keys)
+
+    def emit(self):
+        self._g, self._ids = self.o.lookup_marks()
+        return len(self._g), int((self._ids != (1 << 63) - 1).sum())
+
+    def emit_fetch(self):
+        return self._g, self._ids
+
+
+def worker(rank, world, port, case, files, use_gpu, result_path):
+    import pickle
+
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from twopaco_amd import dist as tdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    abundance = case["abundance"] if case["abundance"] is not None else (1 << 64) - 1
+    if use_gpu:
+        from twopaco_amd import capi
+        text = capi.PackedText.from_fasta(files)
+        ctx = capi.Context(0)
+        ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+        ctx.seq_upload(text)
+        be = tdist.HipBackend(ctx)
+    else:
+        o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+        for f in files:
+            o.add_fasta(f)
+        be = OracleBackend(o)
+    st = tdist.sharded_step(be, dist, case["L"], abundance, fetch=True)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (st["g"], st["ids"], st["junctions"], st["marks"], st["range"]))
+    if rank == 0:
+        with open(result_path, "wb") as f:
+            pickle.dump(gathered, f)
+    dist.barrier()
+    dist.destroy_process_group()

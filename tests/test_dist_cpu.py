@@ -1,0 +1,79 @@
+"""CPU, world_size 2 (gloo): the multi-GPU orchestration of twopaco_amd/dist.py -- vertex-hash
+ranges, union of the per-rank junction keys, id lookup, record merge -- with the oracle standing in
+for the HIP kernels.  The merged records must equal the single-process oracle's."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from helpers import case_files, golden_cases
+from oracle import oracle as O
+from twopaco_amd import dist as tdist
+
+CASES = {c["name"]: c for c in golden_cases()}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(case, files, world, tmp_path, use_gpu=False):
+    from dist_worker import worker
+    res = str(tmp_path / "res.pkl")
+    mp.spawn(worker, args=(world, free_port(), case, files, use_gpu, res), nprocs=world, join=True)
+    with open(res, "rb") as f:
+        return pickle.load(f)
+
+
+def check_against_single(case, files, gathered):
+    abundance = case["abundance"] if case["abundance"] is not None else (1 << 64) - 1
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in files:
+        o.add_fasta(f)
+    o.enumerate(rounds=1, abundance=abundance)
+    J = gathered[0][2]
+    assert all(g[2] == J for g in gathered) and J == len(o.keys) == case["distinct"]
+    recs = tdist.merge_records([(g[0], g[1]) for g in gathered], o.rec_start, o.rec_len, case["k"], J)
+    seq, pos, ids = o.records
+    assert recs == list(zip(seq.tolist(), pos.tolist(), ids.tolist()))
+    assert len(recs) == case["true_marks"]
+    # ranges are disjoint and cover [0, 2^L]
+    rng = sorted(g[4] for g in gathered)
+    assert rng[0][0] == 0 and rng[-1][1] == 1 << case["L"]
+    for a, b in zip(rng, rng[1:]):
+        assert a[1] + 1 == b[0]
+
+
+def test_ranges_cover_and_balance():
+    for L in (12, 20, 36):
+        for world in (1, 2, 3, 8):
+            r = tdist.vertex_hash_ranges(L, world)
+            assert r[0][0] == 0 and r[-1][1] == 1 << L
+            assert all(a[1] + 1 == b[0] for a, b in zip(r, r[1:]))
+    # density of min(u, v) of two uniforms is 2(1-x): each range holds 1/world of the mass
+    rng = np.random.default_rng(1)
+    x = np.minimum(rng.random(200000), rng.random(200000)) * (1 << 30)
+    for lo, hi in tdist.vertex_hash_ranges(30, 4):
+        frac = np.mean((x >= lo) & (x <= hi))
+        assert abs(frac - 0.25) < 0.01
+
+
+@pytest.mark.parametrize("name", ["rand6_k9_fp", "edge_k5", "c2_k51_r2", "rand6_k9_a3"])
+def test_two_ranks_equal_single_process(name, tmp_path):
+    case = CASES[name]
+    files = case_files(case, tmp_path)
+    gathered = run_world(case, files, 2, tmp_path)
+    check_against_single(case, files, gathered)
+
+
+def test_three_ranks(tmp_path):
+    case = CASES["rand6_k25_q3"]
+    files = case_files(case, tmp_path)
+    check_against_single(case, files, run_world(case, files, 3, tmp_path))

@@ -14,7 +14,7 @@ KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
                "tpc_run_begin", "tpc_filter_reset", "tpc_pass1_insert", "tpc_pass1_split_hist", "tpc_pass1_query", "tpc_pass2_filter",
-               "tpc_junctions_finalize", "tpc_key_words", "tpc_junction_keys", "tpc_get_id", "tpc_emit",
+               "tpc_junctions_finalize", "tpc_key_words", "tpc_junction_keys", "tpc_junction_keys_raw", "tpc_junction_keys_set", "tpc_get_id", "tpc_emit",
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option"]
 
@@ -49,6 +49,8 @@ def hip():
         L.tpc_junctions_finalize.argtypes = [p, p]
         L.tpc_key_words.argtypes = [p]
         L.tpc_junction_keys.argtypes = [p, p]
+        L.tpc_junction_keys_raw.argtypes = [p, p, p]
+        L.tpc_junction_keys_set.argtypes = [p, p, u64]
         L.tpc_get_id.restype = i64
         L.tpc_get_id.argtypes = [p, ctypes.c_char_p]
         L.tpc_emit.argtypes = [p, p, p]
@@ -238,6 +240,18 @@ class Context:
         keys = np.zeros((self.n_junctions, C), dtype=np.uint64)
         self._ck(hip().tpc_junction_keys(self._h, keys.ctypes.data))
         return keys
+
+    def junction_keys_raw(self):
+        """Keys appended so far (unsorted, before junctions_finalize)."""
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_junction_keys_raw(self._h, None, ctypes.byref(n)))
+        keys = np.zeros((n.value, hip().tpc_key_words(self._h)), dtype=np.uint64)
+        self._ck(hip().tpc_junction_keys_raw(self._h, keys.ctypes.data, ctypes.byref(n)))
+        return keys
+
+    def junction_keys_set(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._ck(hip().tpc_junction_keys_set(self._h, keys.ctypes.data, keys.shape[0]))
 
     def get_id(self, kmer):
         return hip().tpc_get_id(self._h, kmer.encode())

@@ -35,6 +35,7 @@ struct tpc_ctx {
     uint64_t marks_cap = 0, n_marks = 0;
     bool marks_valid = false;  // marks[] is the compaction of rmask
     uint64_t *block_sums = nullptr;
+    uint64_t *scan_blocks = nullptr;  // scan2 per-chunk counts / offsets
     // exact filter table
     void *table = nullptr;
     uint64_t table_cap = 0, table_alloc = 0;
@@ -182,7 +183,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5] };
+                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -420,17 +421,19 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
     }
     c->table_cap = cap;
     TpcLaunch a = make_launch(c);
+    const bool counted = abundance < c->n_marks;  // otherwise no key can exceed the abundance cut
+    if (!c->scan_blocks) HIPCHK(c, hipMalloc((void **)&c->scan_blocks, 2 * TPC_SCAN2_BLOCKS * sizeof(uint64_t)));
     {
         Timed t(c, TPC_K_FILTER2);
         // key = EMPTY (all ones), meta = 0
         tpc_launch_table_init(c->stream, c->table, cap);
-        if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap)) return fail(c, -1, "filter2 launch failed");
+        if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap, counted)) return fail(c, -1, "filter2 launch failed");
     }
     uint64_t tp = 0, used = 0;
     {
         Timed t(c, TPC_K_SCAN2);
-        HIPCHK(c, hipMemsetAsync(c->counters + 4, 0, 3 * sizeof(unsigned long long), c->stream));
-        if (tpc_launch_scan2(a, c->C, c->marks, c->table, cap, abundance, c->counters + 4, nullptr, nullptr)) return fail(c, -1, "scan2 launch failed");
+        if (tpc_launch_scan2_count(a, c->table, cap, abundance, counted, c->scan_blocks, c->scan_blocks + TPC_SCAN2_BLOCKS, c->counters + 4))
+            return fail(c, -1, "scan2 launch failed");
         if ((rc = read_counter(c, 4, &tp))) return rc;
         if ((rc = read_counter(c, 5, &used))) return rc;
         if (tp) {
@@ -445,7 +448,7 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
                 c->keys = nk;
                 c->keys_cap = ncap;
             }
-            if (tpc_launch_scan2(a, c->C, c->marks, c->table, cap, abundance, c->counters + 4, c->keys + c->n_keys * c->C, c->counters + 6))
+            if (tpc_launch_scan2_write(a, c->C, c->marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
                 return fail(c, -1, "scan2 launch failed");
             c->n_keys += tp;
         }
@@ -502,6 +505,35 @@ int tpc_junction_keys(tpc_ctx *c, uint64_t *keys_host)
     if (!c || !c->finalized) return fail(c, -1, "junctions_finalize first");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n_keys) HIPCHK(c, hipMemcpy(keys_host, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tpc_junction_keys_raw(tpc_ctx *c, uint64_t *keys_host, uint64_t *n)
+{
+    if (!c || !n) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    *n = c->n_keys;
+    if (keys_host && c->n_keys) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(keys_host, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int tpc_junction_keys_set(tpc_ctx *c, const uint64_t *keys_host, uint64_t n)
+{
+    if (!c || (!keys_host && n)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->keys_cap) {
+        if (c->keys) (void)hipFree(c->keys);
+        c->keys = nullptr; c->keys_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->keys, (n + 1024) * c->C * sizeof(uint64_t)));
+        c->keys_cap = n + 1024;
+    }
+    if (n) HIPCHK(c, hipMemcpy(c->keys, keys_host, n * c->C * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->n_keys = n;
+    c->finalized = false;
+    c->keys_host.clear();
     return 0;
 }
 

@@ -54,10 +54,16 @@ int tpc_launch_mask_or(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64
 // meta word; see tpc_pass2.hip.
 size_t tpc_table_slot_bytes(int C);
 int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
-int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap);
-// counters[0]=true junctions, [1]=table size; keys_out may be nullptr (count only)
-int tpc_launch_scan2(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance,
-                     unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor);
+// counted: keep exact occurrence counts (needed only when the abundance cut can apply)
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted);
+// TrueBifurcations in two atomic-free passes over TPC_SCAN2_BLOCKS chunks of the table.
+// count: block_tp / block_used (TPC_SCAN2_BLOCKS uint64 each) become exclusive offsets; totals[0] =
+// true junctions, totals[1] = table size.  write: junction keys at block_tp offsets.
+#define TPC_SCAN2_BLOCKS 4096
+int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, uint64_t abundance, bool counted, uint64_t *block_tp,
+                           uint64_t *block_used, unsigned long long *totals);
+int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                           const uint64_t *block_off, uint64_t *keys_out);
 
 // Sort junction keys (J x C) in CompressedString::Less order; tmp buffers managed by caller via
 // query: returns required scratch bytes when scratch == nullptr.

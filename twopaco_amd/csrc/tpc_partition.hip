@@ -45,16 +45,40 @@ struct Overflow {
     }
 };
 
+// exclusive scan over the PT_THREADS-thread workgroup
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < PT_THREADS / 64; i++) { const uint32_t x = s_w[i]; if (i < wv) base += x; tot += x; }
+    total = tot;
+    return base + inc - v;
+}
+
 // LDS bins with carry: only whole groups of 32 entries leave the workgroup, so every global
-// write is a full aligned 128-byte line; the <32 leftovers stay for the next round.
+// write is a full aligned 128-byte line; the <32 leftovers stay for the next round.  A flush is
+// three short data-parallel phases (bookkeeping + scan of the group counts, one half-wave per
+// 128-byte group, one half-wave per bin for the carry), not a serial walk over the bins.
 template <int LOG_NB>
 struct Bins {
     static constexpr int NB = 1 << LOG_NB;
     static constexpr int CAP = PT_BIN_ENTRIES >> LOG_NB;
-    uint32_t *cnt;   // [NB] entries currently in the bin (may exceed CAP: the excess overflowed)
-    uint32_t *cur;   // [NB] entries already written to the private region of the bin
-    uint32_t *nfl;   // [NB] scratch for a flush
-    uint32_t *data;  // [NB * CAP]
+    static constexpr int MAX_ITEMS = PT_BIN_ENTRIES / 32;
+    static_assert(NB <= PT_THREADS, "one bookkeeping thread per bin");
+    uint32_t *cnt;    // [NB] entries currently in the bin (may exceed CAP: the excess overflowed)
+    uint32_t *cur;    // [NB] entries already written to the private region of the bin
+    uint32_t *meta;   // [NB] n | f << 16 of the flush in progress
+    uint32_t *data;   // [NB * CAP]
+    uint32_t *items;  // [MAX_ITEMS] bin | group << 16
+    uint32_t *scan;   // [8]
 
     __device__ __forceinline__ void init()
     {
@@ -69,34 +93,42 @@ struct Bins {
     }
 
     // region: this workgroup's private output, NB consecutive areas of `cap` entries.
-    // addr_hi(b): the address bits implied by bin b, for entries diverted to the overflow list.
+    // addr_of(b, val): full filter address of an entry, for the ones diverted to the overflow list.
     template <class AddrOf>
     __device__ __forceinline__ void flush(bool final, uint32_t *region, uint64_t cap, const Overflow &ovf, AddrOf addr_of)
     {
         __syncthreads();
-        for (int b = threadIdx.x; b < NB; b += PT_THREADS) {
-            const uint32_t n = min(cnt[b], (uint32_t)CAP);
-            const uint32_t f = final ? ((n + 31u) & ~31u) : (n & ~31u);
-            nfl[b] = f | (n << 16);
+        const uint32_t tid = threadIdx.x;
+        uint32_t n = 0, f = 0;
+        if (tid < (uint32_t)NB) {
+            n = min(cnt[tid], (uint32_t)CAP);
+            f = final ? ((n + 31u) & ~31u) : (n & ~31u);
+            meta[tid] = n | (f << 16);
+        }
+        uint32_t total;
+        const uint32_t off = block_excl_scan(f >> 5, scan, total);
+        for (uint32_t g = 0; g < (f >> 5); g++) items[off + g] = tid | (g << 16);
+        __syncthreads();
+        const uint32_t l = tid & 31u;
+        for (uint32_t w = tid >> 5; w < total; w += PT_THREADS / 32) {
+            const uint32_t it = items[w];
+            const uint32_t b = it & 0xFFFFu, idx = (it >> 16) * 32u + l;
+            const uint32_t nb = meta[b] & 0xFFFFu;
+            const uint32_t val = idx < nb ? data[b * CAP + idx] : PT_SENT;
+            const uint64_t pos = (uint64_t)cur[b] + idx;
+            if (pos < cap) region[(uint64_t)b * cap + pos] = val;
+            else if (val != PT_SENT) ovf.push(addr_of(b, val));
         }
         __syncthreads();
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int b = wave; b < NB; b += PT_THREADS / 64) {
-            const uint32_t pk = nfl[b];
-            const uint32_t f = pk & 0xFFFFu, n = pk >> 16;
-            if (f == 0) continue;
-            const uint32_t c = cur[b];
-            uint32_t *dst = region + (uint64_t)b * cap + c;
-            for (uint32_t i = lane; i < f; i += 64) {
-                const uint32_t val = i < n ? data[b * CAP + i] : PT_SENT;
-                if ((uint64_t)c + i < cap) dst[i] = val;
-                else if (val != PT_SENT) ovf.push(addr_of((uint32_t)b, val));
-            }
-            const uint32_t carry = n > f ? n - f : 0;  // < 32
+        for (uint32_t b = tid >> 5; b < (uint32_t)NB; b += PT_THREADS / 32) {
+            const uint32_t m = meta[b];
+            const uint32_t nb = m & 0xFFFFu, fb = m >> 16;
+            if (fb == 0) continue;  // nothing left the bin
+            const uint32_t carry = nb - min(nb, fb);  // < 32
             uint32_t tmp = 0;
-            if ((uint32_t)lane < carry) tmp = data[b * CAP + f + lane];
-            if ((uint32_t)lane < carry) data[b * CAP + lane] = tmp;
-            if (lane == 0) { cur[b] = c + f; cnt[b] = carry; }
+            if (l < carry) tmp = data[b * CAP + fb + l];
+            if (l < carry) data[b * CAP + l] = tmp;
+            if (l == 0) { cur[b] += fb; cnt[b] = carry; }
         }
         __syncthreads();
     }
@@ -136,10 +168,11 @@ k_part_hash(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
     uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + Q * 5);
     uint32_t *s_cnt = s_n + TW;
     uint32_t *s_cur = s_cnt + NB;
-    uint32_t *s_nfl = s_cur + NB;
-    uint32_t *s_w = s_nfl + NB;  // 8 words
+    uint32_t *s_meta = s_cur + NB;
+    uint32_t *s_items = s_meta + NB;
+    uint32_t *s_w = s_items + Bins<LOG_NB>::MAX_ITEMS;  // 8 words
 
-    Bins<LOG_NB> bins{s_cnt, s_cur, s_nfl, s_data};
+    Bins<LOG_NB> bins{s_cnt, s_cur, s_meta, s_data, s_items, s_w};
     bins.init();
     const int tid = threadIdx.x;
     if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
@@ -196,8 +229,10 @@ k_part_split(int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t 
     uint32_t *s_data = reinterpret_cast<uint32_t *>(smem);
     uint32_t *s_cnt = s_data + PT_BIN_ENTRIES;
     uint32_t *s_cur = s_cnt + NB2;
-    uint32_t *s_nfl = s_cur + NB2;
-    Bins<LOG_NB2> bins{s_cnt, s_cur, s_nfl, s_data};
+    uint32_t *s_meta = s_cur + NB2;
+    uint32_t *s_items = s_meta + NB2;
+    uint32_t *s_w = s_items + Bins<LOG_NB2>::MAX_ITEMS;
+    Bins<LOG_NB2> bins{s_cnt, s_cur, s_meta, s_data, s_items, s_w};
     bins.init();
     const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
@@ -205,25 +240,40 @@ k_part_split(int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t 
     uint32_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
     __syncthreads();
-    for (uint32_t w = j; w < nwg1; w += wpb) {
-        const uint32_t *src = buf1 + ((uint64_t)w * NB1 + b1) * cap1;
-        const uint32_t n = cnt1[(uint64_t)w * NB1 + b1];
-        for (uint32_t base = 0; base < n; base += LOADS * PT_THREADS) {
-            uint32_t v[LOADS];
+    // rounds of LOADS x PT_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
+    // round's loads are issued before the current round is binned and flushed
+    uint32_t w = j, base = 0;
+    uint32_t n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0;
+    while (w < nwg1 && n == 0) { w += wpb; n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0; }
+    uint32_t v[LOADS], vn[LOADS];
+    auto load = [&](uint32_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
+        const uint32_t *src = buf1 + ((uint64_t)ww * NB1 + b1) * cap1;
 #pragma unroll
-            for (int i = 0; i < LOADS; i++) {
-                const uint32_t idx = base + i * PT_THREADS + threadIdx.x;
-                v[i] = idx < n ? src[idx] : PT_SENT;
-            }
-#pragma unroll
-            for (int i = 0; i < LOADS; i++) {
-                if (v[i] != PT_SENT) {
-                    const uint32_t b2 = v[i] >> slice_bits, val = v[i] & slice_mask;
-                    if (!bins.push(b2, val)) ovf.push(addr_of(b2, val));
-                }
-            }
-            bins.flush(false, region, cap2, ovf, addr_of);
+        for (int i = 0; i < LOADS; i++) {
+            const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
+            dst[i] = idx < nn ? src[idx] : PT_SENT;
         }
+    };
+    if (w < nwg1) load(v, w, base, n);
+    while (w < nwg1) {
+        // advance to the next round and prefetch it
+        uint32_t w2 = w, base2 = base + LOADS * PT_THREADS, n2 = n;
+        if (base2 >= n2) {
+            base2 = 0;
+            do { w2 += wpb; n2 = w2 < nwg1 ? cnt1[(uint64_t)w2 * NB1 + b1] : 0; } while (w2 < nwg1 && n2 == 0);
+        }
+        if (w2 < nwg1) load(vn, w2, base2, n2);
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            if (v[i] != PT_SENT) {
+                const uint32_t b2 = v[i] >> slice_bits, val = v[i] & slice_mask;
+                if (!bins.push(b2, val)) ovf.push(addr_of(b2, val));
+            }
+        }
+        bins.flush(false, region, cap2, ovf, addr_of);
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) v[i] = vn[i];
+        w = w2; base = base2; n = n2;
     }
     bins.flush(true, region, cap2, ovf, addr_of);
     bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, cap2);
@@ -241,20 +291,34 @@ k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restri
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     uint32_t *out = filter + (uint64_t)blockIdx.x * words;
-    if (fresh) { for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0; }
-    else { for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i]; }
+    const bool wide = (words & 3u) == 0;  // 16-byte accesses whenever the slice allows
+    if (fresh) {
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
+    } else {
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
+    }
     __syncthreads();
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
         const uint32_t *src = buf2 + r * cap2;
         const uint32_t n = cnt2[r];
-        for (uint32_t i = threadIdx.x; i < n; i += PT_APPLY_THREADS) {
-            const uint32_t v = src[i];
-            if (v != PT_SENT) atomicOr(&slice[v >> 5], 1u << (v & 31u));
+        for (uint32_t i0 = 0; i0 < n; i0 += 8 * PT_APPLY_THREADS) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
+                v[u] = i < n ? src[i] : PT_SENT;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (v[u] != PT_SENT) atomicOr(&slice[v[u] >> 5], 1u << (v[u] & 31u));
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
+    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
 }
 
 // ------------------------------------------------------------------------------------------ level 4
@@ -287,7 +351,7 @@ template <int Q>
 int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_t lo, uint64_t hi, unsigned long long *n_kmers)
 {
     const int nb = 1 << pl.b1;
-    const size_t lds = (size_t)PT_BIN_ENTRIES * 4 + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + (size_t)nb * 12 + 64;
+    const size_t lds = (size_t)PT_BIN_ENTRIES * 4 + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + (size_t)nb * 12 + (size_t)PT_BIN_ENTRIES / 32 * 4 + 64;
     switch (pl.b1) {
     case 1: launch_hash<Q, 1>(a, pl, gated, lo, hi, n_kmers, lds); break;
     case 2: launch_hash<Q, 2>(a, pl, gated, lo, hi, n_kmers, lds); break;
@@ -308,7 +372,7 @@ int launch_split_1(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const int nb2 = 1 << pl.b2;
-    const size_t lds = (size_t)PT_BIN_ENTRIES * 4 + (size_t)nb2 * 12 + 64;
+    const size_t lds = (size_t)PT_BIN_ENTRIES * 4 + (size_t)nb2 * 12 + (size_t)PT_BIN_ENTRIES / 32 * 4 + 64;
     const dim3 grid((unsigned)((1u << pl.b1) * pl.wpb));
 #define TPC_SPLIT(B2)                                                                                                              \
     case B2:                                                                                                                       \

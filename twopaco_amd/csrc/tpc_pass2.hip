@@ -21,6 +21,7 @@ namespace {
 constexpr uint64_t EMPTY = ~0ull;
 constexpr int META_NEXT_SHIFT = 5;
 constexpr int META_COUNT_SHIFT = 16;
+constexpr uint64_t META_MULTI = 1ull << 10;  // a second occurrence was seen (stands in for count >= 2 when no abundance cut applies)
 
 struct Slot { uint64_t key; uint64_t meta; };  // C == 1: key = canonical packed k-mer; C > 1: key = representative mark index
 
@@ -207,7 +208,11 @@ __global__ void k_table_init(Slot *table, uint64_t cap)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) { table[i].key = EMPTY; table[i].meta = 0; }
 }
 
-template <int C>
+// COUNTED = false: no abundance cut can apply (abundance >= number of marks), so the occurrence
+// count collapses to "seen at least twice" = META_MULTI and a thread whose bits are already in the
+// slot issues no atomic at all.  Slots are read before they are CAS-ed / OR-ed: a stale read can only
+// miss bits (they are set monotonically), in which case the atomic runs as before.
+template <int C, bool COUNTED>
 __global__ void __launch_bounds__(256)
 k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
           const uint32_t *__restrict__ nmask, const uint64_t *__restrict__ marks, uint64_t n_marks, Slot *table, uint64_t cap)
@@ -234,71 +239,110 @@ k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
     for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
     const uint64_t mask = cap - 1;
     uint64_t slot = key_hash<C>(ck) & mask;
-    if (C == 1) {
-        for (;;) {
-            const uint64_t cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)ck[0]);
-            if (cur == EMPTY || cur == ck[0]) break;
-            slot = (slot + 1) & mask;
+    bool claimed = false;    // this thread put the key into the slot
+    uint64_t seen_meta = 0;  // meta bits known to be set already
+    for (;;) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&table[slot]);
+        uint64_t cur = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+        seen_meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
+        if (cur == EMPTY) {
+            cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)(C == 1 ? ck[0] : idx));
+            seen_meta = 0;
+            if (cur == EMPTY) { claimed = true; break; }
         }
-    } else {
-        // slot key = index of the first mark that claimed it; equality is decided on the immutable
-        // text: same k-mer up to reverse complement <=> same canonical key
-        for (;;) {
-            const uint64_t cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)idx);
-            if (cur == EMPTY) break;
+        if (C == 1) {
+            if (cur == ck[0]) break;
+        } else {
+            // slot key = index of the first mark that claimed it; equality is decided on the immutable
+            // text: same k-mer up to reverse complement <=> same canonical key
             uint64_t ofw[C], orc[C];
             load_kmer<C>(bases, marks[cur], P.k, ofw);
             if (keys_equal<C>(ofw, ck)) break;
             revcomp_kmer<C>(ofw, P.k, orc);
             if (keys_equal<C>(orc, ck)) break;
-            slot = (slot + 1) & mask;
         }
+        slot = (slot + 1) & mask;
     }
     unsigned long long *meta = (unsigned long long *)&table[slot].meta;
-    atomicOr(meta, (1ull << prev) | (1ull << (META_NEXT_SHIFT + next)));
-    atomicAdd(meta, 1ull << META_COUNT_SHIFT);  // CandidateOccurence::Inc, candidateoccurence.h:64-67
+    uint64_t want = (1ull << prev) | (1ull << (META_NEXT_SHIFT + next));
+    if (!COUNTED && !claimed) want |= META_MULTI;
+    if ((seen_meta & want) != want) atomicOr(meta, (unsigned long long)want);
+    if (COUNTED) atomicAdd(meta, 1ull << META_COUNT_SHIFT);  // CandidateOccurence::Inc, candidateoccurence.h:64-67
 }
 
-// TrueBifurcations (VE.h:1228-1256): count and (optionally) append the junction keys.
-template <int C>
-__global__ void __launch_bounds__(256)
-k_scan2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-        const uint64_t *__restrict__ marks, const Slot *__restrict__ table, uint64_t cap, uint64_t abundance,
-        unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor)
+// TrueBifurcations (VE.h:1228-1256) without global atomics: every workgroup owns a contiguous chunk
+// of the table; pass 1 counts (used slots, true junctions) per chunk, a scan turns the counts into
+// offsets, pass 2 walks the same chunk again and writes the junction keys at its offset.
+__device__ __forceinline__ bool slot_is_junction(const Slot &sl, uint64_t abundance, bool counted)
 {
-    __shared__ uint64_t s_h0[4];
-    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
-    __syncthreads();
+    const uint64_t cnt = sl.meta >> META_COUNT_SHIFT;
+    const unsigned pm = (unsigned)sl.meta & 31u, nm = (unsigned)(sl.meta >> META_NEXT_SHIFT) & 31u;
+    const bool twice = counted ? cnt >= 2 : (sl.meta & META_MULTI) != 0;
+    const bool bif = twice && (__popc(pm) > 1 || __popc(nm) > 1 || (pm & 16u) || (nm & 16u));
+    return bif && (!counted || cnt <= abundance);
+}
+
+__global__ void __launch_bounds__(256)
+k_scan2_count(const Slot *__restrict__ table, uint64_t cap, uint64_t chunk, uint64_t abundance, int counted,
+              uint64_t *block_tp, uint64_t *block_used)
+{
     __shared__ uint32_t s_w[4];
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(cap, lo + chunk);
     unsigned used = 0, tp = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) {
-        const Slot sl = table[s];
+    for (uint64_t s = lo + threadIdx.x; s < hi; s += 256) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&table[s]);
+        Slot sl;
+        sl.key = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+        sl.meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
         if (sl.key == EMPTY) continue;
         used++;
-        const uint64_t cnt = sl.meta >> META_COUNT_SHIFT;
-        const unsigned pm = (unsigned)sl.meta & 31u, nm = (unsigned)(sl.meta >> META_NEXT_SHIFT) & 31u;
-        const bool bif = cnt >= 2 && (__popc(pm) > 1 || __popc(nm) > 1 || (pm & 16u) || (nm & 16u));
-        if (bif && cnt <= abundance) {
-            tp++;
-            if (keys_out) {
-                const unsigned long long o = atomicAdd(cursor, 1ull);
-                if (C == 1) {
-                    keys_out[o] = sl.key;
-                } else {
-                    uint64_t fw[C], rc[C];
-                    load_kmer<C>(bases, marks[sl.key], P.k, fw);
-                    revcomp_kmer<C>(fw, P.k, rc);
-                    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+        tp += slot_is_junction(sl, abundance, counted != 0);
+    }
+    uint32_t total;
+    block_excl_scan256(tp, s_w, total);
+    if (threadIdx.x == 0) block_tp[blockIdx.x] = total;
+    block_excl_scan256(used, s_w, total);
+    if (threadIdx.x == 0) block_used[blockIdx.x] = total;
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+k_scan2_write(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+              const uint64_t *__restrict__ marks, const Slot *__restrict__ table, uint64_t cap, uint64_t chunk, uint64_t abundance,
+              int counted, const uint64_t *__restrict__ block_off, uint64_t *keys_out)
+{
+    __shared__ uint64_t s_h0[4];
+    __shared__ uint32_t s_w[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(cap, lo + chunk);
+    uint64_t base = block_off[blockIdx.x];
+    for (uint64_t s0 = lo; s0 < hi; s0 += 256) {
+        const uint64_t s = s0 + threadIdx.x;
+        Slot sl;
+        sl.key = EMPTY; sl.meta = 0;
+        if (s < hi) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(&table[s]);
+            sl.key = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+            sl.meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
+        }
+        const bool tp = sl.key != EMPTY && slot_is_junction(sl, abundance, counted != 0);
+        uint32_t total;
+        const uint32_t ex = block_excl_scan256(tp ? 1u : 0u, s_w, total);
+        if (tp) {
+            const uint64_t o = base + ex;
+            if (C == 1) {
+                keys_out[o] = sl.key;
+            } else {
+                uint64_t fw[C], rc[C];
+                load_kmer<C>(bases, marks[sl.key], P.k, fw);
+                revcomp_kmer<C>(fw, P.k, rc);
+                const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
 #pragma unroll
-                    for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
-                }
+                for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
             }
         }
-    }
-    if (!keys_out) {
-        block_add64(&counters[0], tp, s_w);
-        block_add64(&counters[1], used, s_w);
+        base += total;
     }
 }
 
@@ -421,19 +465,37 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap)
     return 0;
 }
 
-int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap)
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted)
 {
     if (n_marks == 0) return 0;
-#define CALL(C_) hipLaunchKernelGGL((k_filter2<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, n_marks, (Slot *)table, cap)
+#define CALL(C_)                                                                                                                         \
+    if (counted) hipLaunchKernelGGL((k_filter2<C_, true>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, \
+                                    marks, n_marks, (Slot *)table, cap);                                                                 \
+    else hipLaunchKernelGGL((k_filter2<C_, false>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, \
+                            n_marks, (Slot *)table, cap)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
 }
 
-int tpc_launch_scan2(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance,
-                     unsigned long long *counters, uint64_t *keys_out, unsigned long long *cursor)
+uint64_t tpc_scan2_chunk(uint64_t cap) { return ((cap + TPC_SCAN2_BLOCKS - 1) / TPC_SCAN2_BLOCKS + 255) / 256 * 256; }
+
+int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, uint64_t abundance, bool counted, uint64_t *block_tp,
+                           uint64_t *block_used, unsigned long long *totals)
 {
-#define CALL(C_) hipLaunchKernelGGL((k_scan2<C_>), dim3(std::min<unsigned>(nblk(cap, 256), 8192u)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, abundance, counters, keys_out, cursor)
+    const uint64_t chunk = tpc_scan2_chunk(cap);
+    hipLaunchKernelGGL(k_scan2_count, dim3(TPC_SCAN2_BLOCKS), dim3(256), 0, a.stream, (const Slot *)table, cap, chunk, abundance, counted ? 1 : 0,
+                       block_tp, block_used);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, a.stream, block_tp, (uint64_t)TPC_SCAN2_BLOCKS, totals);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, a.stream, block_used, (uint64_t)TPC_SCAN2_BLOCKS, totals + 1);
+    return 0;
+}
+
+int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                           const uint64_t *block_off, uint64_t *keys_out)
+{
+    const uint64_t chunk = tpc_scan2_chunk(cap);
+#define CALL(C_) hipLaunchKernelGGL((k_scan2_write<C_>), dim3(TPC_SCAN2_BLOCKS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, chunk, abundance, counted ? 1 : 0, block_off, keys_out)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
