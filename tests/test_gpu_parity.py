@@ -119,6 +119,37 @@ def test_enumerator_matches_reference_golden(capi, tmp_path, case):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["rand6_k9_fp_r4", "c2_k51_r2", "rand6_k9_a3", "edge_k5"])
+def test_all_passes_forced_partitioned(capi, tmp_path, name):
+    """Whole run with both first-pass kernels forced onto the partitioned paths == oracle records."""
+    case = [c for c in CASES if c["name"] == name][0]
+    abundance = case["abundance"] if case["abundance"] is not None else MAXU
+    o = _oracle_for(case, tmp_path)
+    o.enumerate(rounds=case["n_rounds"], abundance=abundance)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", 8)):
+        ctx.set_option(opt, val)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    ctx.run_begin()
+    for r in range(case["n_rounds"]):
+        st = o.round_stats(r)
+        ctx.filter_reset()
+        ctx.pass1_insert(st["low"], st["high"])
+        assert ctx.pass1_query(st["low"], st["high"]) == st["marks"]
+        assert ctx.pass2_filter(abundance) == {"true": st["true"], "false": st["false"], "table": st["table"]}
+    J = ctx.junctions_finalize()
+    assert (ctx.junction_keys() == o.keys).all()
+    ctx.emit()
+    g, ids = ctx.emit_fetch()
+    seq, pos, oid = o.records
+    real = np.abs(oid) <= J
+    valid = ids != capi.INVALID_VERTEX
+    assert (g[valid] == o.rec_start[seq[real]] + pos[real].astype(np.uint64)).all() and (ids[valid] == oid[real]).all()
+    ctx.close()
+
+
 def test_test_first_variant_same_filter(capi, tmp_path):
     case = [c for c in CASES if c["name"] == "rand6_k9_fp"][0]
     text = capi.PackedText.from_fasta(case_files(case, tmp_path))
@@ -162,6 +193,55 @@ def test_partitioned_insert_matches_oracle(capi, tmp_path, name, slice_bits):
         assert (ctx.filter_download() == o.filter).all()
     from twopaco_amd import synth
     ctx.close()
+
+
+@pytest.mark.parametrize("name,slice_bits", [("rand6_k9_fp", 8), ("rand6_k9_fp", 10), ("rand6_k9_q8", 9), ("rand6_k9_q1", 12),
+                                             ("rand6_k25_q3", 12), ("rand6_k9_L33", 20), ("c2_k51_r2", 16), ("edge_k5", 7),
+                                             ("rand6_k9_fp_r4", 9), ("edge_k7_fp_r2", 6), ("c2_k125", 14)])
+def test_partitioned_query_matches_oracle(capi, tmp_path, name, slice_bits):
+    """The partitioned query (tpc_qpartition.hip) produces the oracle's candidate mask and mark count,
+    whole range and gated round ranges, on top of either insert path."""
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    ctx.set_option("insert_mode", 2)
+    ctx.set_option("query_mode", 2)
+    ctx.set_option("slice_bits", slice_bits)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+    for lo, hi in ranges:
+        o.fill_only(lo, hi)
+        marks = o.check_only(lo, hi)
+        ctx.filter_reset()
+        ctx.pass1_insert(lo, hi)
+        assert ctx.pass1_query(lo, hi) == marks
+        assert (ctx.mask_download(False) == o.round_mask).all(), (name, lo, hi)
+    ctx.close()
+
+
+def test_partitioned_query_adversarial_skew(capi):
+    """Repeats + poly-A: bins, regions and the survivor lists overflow; result equals the direct kernel's."""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 700).astype(np.uint8)
+    recs = [np.tile(unit, 400), np.zeros(200000, dtype=np.uint8), np.concatenate([unit[:300], unit[350:]])]
+    text = capi.PackedText.from_codes(recs)
+    masks = []
+    for mode in (1, 2):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_option("query_mode", mode)
+        ctx.set_option("slice_bits", 12)
+        ctx.set_params(25, 24, 5, capi.seed_table(5, 24, seed=3))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        n = ctx.pass1_query()
+        masks.append((n, ctx.mask_download(False)))
+        ctx.close()
+    assert masks[0][0] == masks[1][0] > 0
+    assert (masks[0][1] == masks[1][1]).all()
 
 
 @pytest.mark.parametrize("n", [3000, 3000000])

@@ -1,0 +1,174 @@
+// tpc_bins.h -- LDS write-combining bins shared by the partitioned insert (uint32 entries) and the
+// partitioned query (uint64 entries).  See tpc_partition.hip for the scheme.
+#pragma once
+#include "tpc_device.h"
+
+constexpr int PT_THREADS = 512;          // levels 1 and 2
+constexpr int PT_BIN_BYTES = 131072;     // LDS bin storage
+constexpr int PT_LINE = 128;             // flush granule: one aligned 128-byte line
+constexpr int PT_APPLY_THREADS = 1024;
+
+// Slice-index permutation.  Canonical edge addresses of hash function 0 are min(H, H') of two hashes
+// (reference vertexrollinghash.h:170-184), so their density over [0, 2^L) is 2(1-x): binning by the
+// plain top bits would hand bucket 0 twice the average load.  The slice index s = a >> slice_bits is
+// therefore multiplied by an odd constant mod 2^F (a bijection) before it is split into the two
+// bucket levels; the workgroup that owns permuted slice s' touches filter slice s = s' * inv.
+struct PtPerm {
+    int slice_bits, F;
+    uint32_t mult, inv;
+    __host__ __device__ __forceinline__ uint64_t fwd(uint64_t a) const
+    {
+        const uint64_t smask = ((uint64_t)1 << slice_bits) - 1, fmask = ((uint64_t)1 << F) - 1;
+        return ((((a >> slice_bits) * mult) & fmask) << slice_bits) | (a & smask);
+    }
+    __host__ __device__ __forceinline__ uint64_t back(uint64_t a) const
+    {
+        const uint64_t smask = ((uint64_t)1 << slice_bits) - 1, fmask = ((uint64_t)1 << F) - 1;
+        return ((((a >> slice_bits) * inv) & fmask) << slice_bits) | (a & smask);
+    }
+    __host__ __device__ __forceinline__ uint32_t slice_of(uint32_t permuted) const { return (uint32_t)(((uint64_t)permuted * inv) & (((uint64_t)1 << F) - 1)); }
+};
+
+inline PtPerm pt_make_perm(int slice_bits, int F)
+{
+    PtPerm p;
+    p.slice_bits = slice_bits; p.F = F;
+    p.mult = 0x9E3779B1u;
+    uint32_t x = p.mult;  // Newton iteration for the inverse mod 2^32 (then truncated to F bits by the masks)
+    for (int i = 0; i < 5; i++) x *= 2u - p.mult * x;
+    p.inv = x;
+    return p;
+}
+
+// exclusive scan over the PT_THREADS-thread workgroup
+__device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < PT_THREADS / 64; i++) { const uint32_t x = s_w[i]; if (i < wv) base += x; tot += x; }
+    total = tot;
+    return base + inc - v;
+}
+
+// LDS bins: each bin is a ring of CAP entries.  Only whole groups of GROUP entries leave the
+// workgroup, so every global write is a full aligned 128-byte line; the < GROUP leftovers simply stay
+// in the ring.  A flush is two short data-parallel phases: one bookkeeping thread per bin builds the
+// list of 128-byte groups (scan of the group counts), then GROUP lanes copy each group.
+template <class T>
+struct Bins {
+    static constexpr int ENTRIES = PT_BIN_BYTES / (int)sizeof(T);
+    static constexpr int GROUP = PT_LINE / (int)sizeof(T);
+    static constexpr int LOG_GROUP = sizeof(T) == 4 ? 5 : 4;
+    static constexpr int MAX_ITEMS = ENTRIES / GROUP;
+    static constexpr T SENT = (T)~(T)0;
+    int NB, CAP, LOG_CAP;  // bins (<= PT_THREADS: one bookkeeping thread per bin), entries per bin
+    uint32_t *tail;   // [NB + 1] entries ever pushed into the bin; [NB] = dummy bin of invalid lanes
+    uint32_t *head;   // [NB + 1] entries already written to the bin's private region (multiple of GROUP)
+    T *data;          // [NB * CAP] rings
+    uint2 *items;     // [MAX_ITEMS] x = bin | ring index << 10 | valid << 24, y = position in the region
+    uint32_t *scan;   // [16]
+#ifdef TPC_PROFILE_PHASES
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};  // thread 0: ticks in push / bookkeeping / copy, rounds
+    unsigned long long t_mark = 0;
+    __device__ __forceinline__ void tick(int slot) { const unsigned long long t = wall_clock64(); if (t_mark) prof[slot] += t - t_mark; t_mark = t; }
+    __device__ __forceinline__ void dump(unsigned long long *out) { if (threadIdx.x == 0) for (int i = 0; i < 6; i++) atomicAdd(&out[i], prof[i]); }
+#else
+    __device__ __forceinline__ void tick(int) {}
+    __device__ __forceinline__ void dump(unsigned long long *) {}
+#endif
+
+    static size_t lds_bytes(int log_nb) { return (size_t)PT_BIN_BYTES + ((size_t)8 << log_nb) + 16 + (size_t)MAX_ITEMS * 8 + 64; }
+
+    // carve: data first (16-byte aligned), then the bookkeeping arrays; returns the first free byte
+    __device__ __forceinline__ unsigned char *carve(unsigned char *p, int log_nb)
+    {
+        NB = 1 << log_nb;
+        LOG_CAP = (sizeof(T) == 4 ? 15 : 14) - log_nb;
+        CAP = 1 << LOG_CAP;
+        data = reinterpret_cast<T *>(p);
+        items = reinterpret_cast<uint2 *>(p + PT_BIN_BYTES);
+        tail = reinterpret_cast<uint32_t *>(items + MAX_ITEMS);
+        head = tail + NB + 2;
+        scan = head + NB + 2;
+        return reinterpret_cast<unsigned char *>(scan + 16);
+    }
+
+    __device__ __forceinline__ void init()
+    {
+        for (int b = threadIdx.x; b <= NB; b += PT_THREADS) { tail[b] = 0; head[b] = 0; }
+    }
+
+    // N entries per lane at once: all ring slots are claimed (N independent LDS atomics in flight)
+    // before any entry is stored.  ok[i] == false lanes go to the dummy bin.  lost(b, val) receives
+    // the entries that found their ring full.
+    template <int N, class Lost>
+    __device__ __forceinline__ void push_batch(const uint32_t (&b)[N], const T (&val)[N], const bool (&ok)[N], Lost lost)
+    {
+        uint32_t slot[N], hd[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t bb = ok[i] ? b[i] : (uint32_t)NB;
+            slot[i] = atomicAdd(&tail[bb], 1u);
+            hd[i] = head[bb];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (ok[i]) {
+                if (slot[i] - hd[i] < (uint32_t)CAP) data[(b[i] << LOG_CAP) + (slot[i] & (uint32_t)(CAP - 1))] = val[i];
+                else lost(b[i], val[i]);
+            }
+        }
+    }
+
+    // region: this workgroup's private output, NB consecutive areas of `cap` entries.
+    // lost(b, val): called for an entry that does not fit its region (goes to an overflow list).
+    template <class Lost>
+    __device__ __forceinline__ void flush(bool final, T *region, uint64_t cap, Lost lost)
+    {
+        __syncthreads();
+        tick(0);  // everything since the previous flush: loads + hashing + pushes
+        const uint32_t tid = threadIdx.x;
+        uint32_t n = 0, f = 0, h = 0;
+        if (tid < (uint32_t)NB) {
+            h = head[tid];
+            n = min(tail[tid] - h, (uint32_t)CAP);  // entries beyond CAP were handed to lost() by push_batch
+            f = final ? ((n + GROUP - 1u) & ~(uint32_t)(GROUP - 1)) : (n & ~(uint32_t)(GROUP - 1));
+        }
+        uint32_t total;
+        const uint32_t off = pt_block_excl_scan(f >> LOG_GROUP, scan, total);
+        for (uint32_t g = 0; g < (f >> LOG_GROUP); g++) {
+            const uint32_t left = n - g * GROUP;
+            items[off + g] = make_uint2(tid | (((h + g * GROUP) & (uint32_t)(CAP - 1)) << 10) | (min(left, (uint32_t)GROUP) << 24), h + g * GROUP);
+        }
+        if (tid < (uint32_t)NB) { head[tid] = h + f; tail[tid] = h + (final ? f : n); }
+        __syncthreads();
+        tick(1);
+        const uint32_t l = tid & (GROUP - 1);
+        for (uint32_t w = tid >> LOG_GROUP; w < total; w += PT_THREADS / GROUP) {
+            const uint2 it = items[w];
+            const uint32_t b = it.x & 1023u, idx0 = (it.x >> 10) & 16383u, valid = it.x >> 24;
+            const T val = l < valid ? data[(b << LOG_CAP) + idx0 + l] : SENT;
+            const uint64_t pos = (uint64_t)it.y + l;
+            if (pos < cap) region[(uint64_t)b * cap + pos] = val;
+            else if (val != SENT) lost(b, val);
+        }
+        __syncthreads();
+        tick(2);
+#ifdef TPC_PROFILE_PHASES
+        prof[4]++;
+#endif
+    }
+
+    __device__ __forceinline__ void store_counts(uint32_t *out, uint64_t cap)
+    {
+        for (int b = threadIdx.x; b < NB; b += PT_THREADS) out[b] = (uint32_t)min((uint64_t)head[b], cap);
+    }
+};

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,8 +60,9 @@ struct tpc_ctx {
     int opt_slice_bits = 20;
     // partitioned insert
     bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
-    void *pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t pbytes[6] = {0, 0, 0, 0, 0, 0};
+    void *pbuf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // shared by insert and query
+    size_t pbytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
     int last_insert_mode = 0;
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
@@ -183,7 +185,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->scan_blocks };
+                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -199,6 +201,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "insert_test_first")) { c->opt_test_first = value != 0; return 0; }
     if (!strcmp(name, "insert_mode")) { c->opt_insert_mode = (int)value; return 0; }
     if (!strcmp(name, "slice_bits")) { c->opt_slice_bits = (int)value; return 0; }
+    if (!strcmp(name, "query_mode")) { c->opt_query_mode = (int)value; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -388,13 +391,57 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    c->marks_valid = false;
+    TpcQPlan pl;
+    bool part = c->opt_query_mode != 1 && tpc_qpart_plan(c->P.L, c->opt_slice_bits, c->n_text, pl);
+    if (c->opt_query_mode == 0 && c->P.L < 28) part = false;  // small filters are cache resident: direct loads win
+    if (part) {
+        for (int i = 0; i < 8; i++) {
+            const size_t need = tpc_qpart_bytes(pl, i);
+            if (need > c->pbytes[i]) {
+                if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
+                c->pbuf[i] = nullptr; c->pbytes[i] = 0;
+                if (hipMalloc(&c->pbuf[i], need) != hipSuccess) { part = false; break; }  // not enough HBM: direct path
+                c->pbytes[i] = need;
+            }
+        }
+    }
+    if (part) {
+        pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
+        pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        pl.surv = (uint64_t *)c->pbuf[6]; pl.surv_cur = (unsigned long long *)c->pbuf[7];
+        unsigned long long f1[2] = {0, 0}, f2 = 0;
+        {
+            Timed t(c, TPC_K_QUERY);
+            HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+            if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+            tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
+        uint64_t n = 0;
+        int rc = read_counter(c, 1, &n);
+        if (rc) return rc;
+        if (getenv("TPC_PROFILE_PHASES")) {
+            unsigned long long pr[32];
+            (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu carry %llu rounds %llu | hash: push %llu book %llu copy %llu carry %llu rounds %llu (wall_clock ticks summed over WGs) sites: hashpush %llu hashregion %llu splitpush %llu splitregion %llu\n",
+                    pr[0], pr[8], pr[9], pr[10], pr[11], pr[12], pr[16], pr[17], pr[18], pr[19], pr[20], pr[24], pr[25], pr[26], pr[27]);
+        }
+        if (f1[1] == 0 && f2 == 0) {
+            if (n_marks) *n_marks = n;
+            return 0;
+        }
+        // an overflow list overflowed (pathological skew): the direct kernel below rewrites the whole mask
+    }
     HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
     {
         Timed t(c, TPC_K_QUERY);
         if (tpc_launch_query(make_launch(c), c->rmask, lo, hi, gated, c->counters + 1)) return fail(c, -1, "query launch failed");
     }
     HIPCHK(c, hipGetLastError());
-    c->marks_valid = false;
     uint64_t n = 0;
     int rc = read_counter(c, 1, &n);
     if (rc) return rc;

@@ -29,8 +29,10 @@ template <int Q, class Emit>
 __device__ __forceinline__ void tpc_emit_edge(Emit &emit, const uint64_t (&p)[Q], const uint64_t (&n)[Q])
 {
     const bool neg = tpc_pick_neg<Q>(p, n);
+    uint64_t a[Q];
 #pragma unroll
-    for (int i = 0; i < Q; i++) emit(neg ? n[i] : p[i]);
+    for (int i = 0; i < Q; i++) a[i] = neg ? n[i] : p[i];
+    emit.template edge<Q>(a);  // the q Bloom addresses of one edge
 }
 
 // One position: emits the Bloom addresses of the window at g (if N-free and inside the round's

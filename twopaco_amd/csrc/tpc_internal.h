@@ -26,6 +26,7 @@ int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *
 // partitioned insert (tpc_partition.hip)
 struct TpcPartPlan {
     int slice_bits, b1, b2, pos_per_round;
+    uint32_t perm_mult, perm_inv;  // slice-index permutation (tpc_bins.h:PtPerm)
     uint64_t n_tiles;     // 512-word tiles of the text
     uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
     uint64_t cap1, cap2;  // entries per private region (multiples of 32)
@@ -41,6 +42,26 @@ size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
                                   unsigned long long *n_kmers);
+
+// partitioned query (tpc_qpartition.hip)
+struct TpcQPlan {
+    int slice_bits, b1, b2, pos_per_round;
+    uint32_t perm_mult, perm_inv;
+    uint64_t n_tiles;
+    uint32_t nwg1, wpb;
+    uint64_t cap1, cap2;   // entries (uint64) per private region, multiples of 16
+    uint64_t ovf_cap;      // {address, survivor id} pairs
+    uint64_t surv_cap;     // per survivor sub-list (64 of them)
+    uint64_t *buf1, *buf2;
+    uint32_t *cnt1, *cnt2;
+    uint64_t *ovf;
+    unsigned long long *ovf_cur;   // [0] count, [1] overflow flag
+    uint64_t *surv;
+    unsigned long long *surv_cur;  // [0..63] counts, [64] overflow flag
+};
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_text, TpcQPlan &pl);
+size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur
+int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 
 // pass 2 / output (tpc_pass2.hip)
 // Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of

@@ -44,7 +44,12 @@ __device__ __forceinline__ bool get_bit(const uint32_t *filter, uint64_t a)
 template <bool TEST>
 struct DirectEmit {
     uint32_t *filter;
-    __device__ __forceinline__ void operator()(uint64_t a) { insert_bit<TEST>(filter, a); }
+    template <int Q>
+    __device__ __forceinline__ void edge(const uint64_t (&a)[Q])
+    {
+#pragma unroll
+        for (int i = 0; i < Q; i++) insert_bit<TEST>(filter, a[i]);
+    }
 };
 
 // one atomic per workgroup (same-address device atomics serialise at ~12 ns each)

@@ -1,0 +1,497 @@
+// tpc_qpartition.hip -- first-pass query (CandidateCheckingWorker, reference
+// src/graphconstructor/vertexenumerator.h:586-704) through the same LDS write-combining bins as
+// the partitioned insert.
+//
+// Why.  The direct kernel (tpc_pass1.hip:k_query) issues ~6 scattered 4-byte loads per k-mer into a
+// multi-GiB filter; scattered loads top out at ~50 G/s on MI355X (profiles/r01_microbench.txt), a
+// 38 ms floor on the 62-genome workload.  Here the *first* Bloom probe of every unknown edge
+// travels to the workgroup that holds its filter slice in LDS:
+//
+//   A  k_q_hash    rolling hash; for every N-free vertex in the round's range: prev or next is N ->
+//                  mark directly (VE.h:640-641); otherwise each unknown edge (c != prev / c != next)
+//                  gets its canonical strand and first address a0 -> entry {a0 remainder, edge,
+//                  position} binned by the top B1 bits of a0 (uint64 entries, 16 per 128-B line)
+//   B  k_q_split   second-level binning by the next B2 bits
+//   C  k_q_lookup  one workgroup per slice: slice of the filter loaded into LDS once, every entry
+//                  tests its bit there; survivors (first probe hit: Bloom false positives ~ fill
+//                  rate, plus true second edges) are appended to 64 survivor sub-lists
+//   D  k_q_verify  one thread per survivor: recomputes the vertex hashes from the text, probes
+//                  functions 1..q-1 directly, and ORs the mark bit.
+//
+// mark(g) <=> some unknown edge is present: with prev and next definite the known in- and out-edge
+// count 1 each, so "inCount > 1 || outCount > 1" (VE.h:656) holds exactly when one more edge passes
+// all q probes.  The mask is bit-identical to k_query's (tests/test_gpu_parity.py).
+#include "tpc_bins.h"
+#include "tpc_internal.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int QE_E_SHIFT = 31;   // entry: [0,31) address remainder, [31,34) edge, [34,64) position
+constexpr uint64_t QE_REM_MASK = (1ull << QE_E_SHIFT) - 1ull;
+constexpr int QS_LISTS = 64;     // survivor sub-lists (independent cursors: same-address atomics serialise)
+
+struct QOverflow {  // entries that did not fit a region: {full address, survivor id} pairs
+    uint64_t *list;
+    unsigned long long *cursor;  // [0] pairs appended, [1] overflow flag (-> host falls back to k_query)
+    uint64_t cap;
+    __device__ __forceinline__ void push(uint64_t addr, uint64_t sid, int site = 0) const
+    {
+#ifdef TPC_PROFILE_PHASES
+        atomicAdd(cursor + 24 + site, 1ull);
+#endif
+        const unsigned long long o = atomicAdd(cursor, 1ull);
+        if (o < cap) { list[2 * o] = addr; list[2 * o + 1] = sid; } else cursor[1] = 1ull;
+    }
+};
+
+__device__ __forceinline__ bool within(uint64_t v, uint64_t lo, uint64_t hi) { return v >= lo && v <= hi; }
+
+// ------------------------------------------------------------------------------------------ A
+template <int Q, bool GATED>
+__global__ void __launch_bounds__(PT_THREADS)
+k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+         const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
+         uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
+    Bins<uint64_t> bins;
+    uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
+    uint64_t *s_h = s_b + TW;
+    uint64_t *s_hk = s_h + Q * 5;
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + Q * 5);
+    bins.init();
+    const int tid = threadIdx.x;
+    if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
+    const int shift = P.L - LOG_NB;
+    uint64_t *region = buf1 + (uint64_t)blockIdx.x * NB * cap1;
+    auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
+    const int xw = (P.k + 1) / 32 + 2;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        const uint64_t wfirst = tile * PT_THREADS;
+        const uint64_t wbase = wfirst - 1;
+        for (int i = tid; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
+            const int64_t w = (int64_t)wfirst - 1 + i;
+            s_b[i] = w >= 0 ? bases[w] : 0ull;
+            s_n[i] = w >= 0 ? nmask[w] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        const uint64_t g0 = (wfirst + tid) * TPC_RUN;
+        const bool active = g0 < n_text;
+        TpcVHash<Q> v;
+        int ncnt = 0, c_prev = TPC_CODE_N, c_first = TPC_CODE_N;
+        uint32_t word = 0;
+        if (active) {
+            tpc_vhash_init<Q>(v, P, s_h, s_b, s_n, g0, wbase);
+            for (int t = 0; t < P.k; t++) ncnt += tpc_tile_char(s_b, s_n, g0 + t, wbase) == TPC_CODE_N;
+            c_prev = tpc_tile_char(s_b, s_n, g0 - 1, wbase);
+            c_first = tpc_tile_char(s_b, s_n, g0, wbase);
+        }
+        for (int s0 = 0; s0 < TPC_RUN; s0 += pos_per_round) {
+            if (active) {
+                for (int s = s0; s < s0 + pos_per_round; s++) {
+                    const uint64_t g = g0 + s;
+                    const int c_next = tpc_tile_char(s_b, s_n, g + P.k, wbase);
+                    const int c_first_nx = tpc_tile_char(s_b, s_n, g + 1, wbase);
+                    uint64_t r1p[Q], r1n[Q];
+#pragma unroll
+                    for (int i = 0; i < Q; i++) {
+                        r1p[i] = tpc_rotl1(v.pos[i], P.L, P.lmask);
+                        r1n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask);
+                    }
+                    bool check = ncnt == 0;
+                    if (GATED) check = check && within(tpc_min(v.pos[0], v.neg[0]), lo, hi);  // VE.h:638
+                    if (check) {
+                        if (c_prev == TPC_CODE_N || c_next == TPC_CODE_N) {
+                            word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
+                        } else {
+                            const uint64_t sid_g = g << 3;
+                            uint32_t eb[8];
+                            uint64_t ev[8];
+                            bool eok[8];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                {   // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200)
+                                    bool neg = false, decided = false;
+                                    uint64_t p0 = 0, n0 = 0;
+#pragma unroll
+                                    for (int i = 0; i < Q; i++) {
+                                        const uint64_t p = s_hk[i * 5 + c] ^ v.pos[i];
+                                        const uint64_t n = r1n[i] ^ s_h[i * 5 + 3 - c];
+                                        if (i == 0) { p0 = p; n0 = n; }
+                                        if (!decided && p != n) { neg = n < p; decided = true; }
+                                    }
+                                    const uint64_t a0 = perm.fwd(neg ? n0 : p0);  // permuted address from here on
+                                    eb[c] = (uint32_t)(a0 >> shift);
+                                    ev[c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)c) << QE_E_SHIFT);
+                                    eok[c] = c != c_prev;
+                                }
+                                {   // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184)
+                                    bool neg = false, decided = false;
+                                    uint64_t p0 = 0, n0 = 0;
+#pragma unroll
+                                    for (int i = 0; i < Q; i++) {
+                                        const uint64_t p = r1p[i] ^ s_h[i * 5 + c];
+                                        const uint64_t n = v.neg[i] ^ s_hk[i * 5 + 3 - c];
+                                        if (i == 0) { p0 = p; n0 = n; }
+                                        if (!decided && p != n) { neg = n < p; decided = true; }
+                                    }
+                                    const uint64_t a0 = perm.fwd(neg ? n0 : p0);
+                                    eb[4 + c] = (uint32_t)(a0 >> shift);
+                                    ev[4 + c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)(4 + c)) << QE_E_SHIFT);
+                                    eok[4 + c] = c != c_next;
+                                }
+                            }
+                            bins.template push_batch<8>(eb, ev, eok, lost);
+                        }
+                    }
+                    // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113)
+#pragma unroll
+                    for (int i = 0; i < Q; i++) {
+                        v.pos[i] = r1p[i] ^ s_h[i * 5 + c_next] ^ s_hk[i * 5 + c_first];
+                        v.neg[i] = tpc_rotr1(v.neg[i] ^ s_hk[i * 5 + tpc_rc(c_next)] ^ s_h[i * 5 + tpc_rc(c_first)], P.L);
+                    }
+                    ncnt += (c_next == TPC_CODE_N) - (c_first == TPC_CODE_N);
+                    c_prev = c_first;
+                    c_first = c_first_nx;
+                }
+            }
+            bins.flush(false, region, cap1, lost);
+        }
+        rmask[wfirst + tid] = word;  // N-neighbour marks; k_q_verify ORs the rest
+    }
+    bins.flush(true, region, cap1, lost);
+    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, cap1);
+#ifdef TPC_PROFILE_PHASES
+    bins.dump(ovf.cursor + 16);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ B
+__global__ void __launch_bounds__(PT_THREADS)
+k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
+          const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, uint64_t cap2, QOverflow ovf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
+    constexpr int LOADS = 8;
+    constexpr uint64_t SENT = ~0ull;
+    Bins<uint64_t> bins;
+    bins.carve(smem, LOG_NB2);
+    bins.init();
+    const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
+    const int shift1 = L - LOG_NB1;
+    const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
+    uint64_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
+    auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
+    __syncthreads();
+    uint32_t w = j, base = 0;
+    uint32_t n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0;
+    while (w < nwg1 && n == 0) { w += wpb; n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0; }
+    uint64_t v[LOADS], vn[LOADS];
+    auto load = [&](uint64_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
+        const uint64_t *src = buf1 + ((uint64_t)ww * NB1 + b1) * cap1;
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
+            dst[i] = idx < nn ? src[idx] : SENT;
+        }
+    };
+    if (w < nwg1) load(v, w, base, n);
+    while (w < nwg1) {
+        uint32_t w2 = w, base2 = base + LOADS * PT_THREADS, n2 = n;
+        if (base2 >= n2) {
+            base2 = 0;
+            do { w2 += wpb; n2 = w2 < nwg1 ? cnt1[(uint64_t)w2 * NB1 + b1] : 0; } while (w2 < nwg1 && n2 == 0);
+        }
+        if (w2 < nwg1) load(vn, w2, base2, n2);
+        {
+            uint32_t bb[LOADS];
+            bool ok[LOADS];
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) { ok[i] = v[i] != SENT; bb[i] = (uint32_t)((v[i] & rem_mask) >> slice_bits); }
+            bins.template push_batch<LOADS>(bb, v, ok, lost);
+        }
+        bins.flush(false, region, cap2, lost);
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) v[i] = vn[i];
+        w = w2; base = base2; n = n2;
+    }
+    bins.flush(true, region, cap2, lost);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, cap2);
+#ifdef TPC_PROFILE_PHASES
+    bins.dump(ovf.cursor + 8);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ C
+// One workgroup per slice.  Survivors (entry >> 31 = edge | position << 3) are staged in LDS and
+// appended to sub-list (blockIdx % QS_LISTS) with one global atomic per flush.
+constexpr int QL_STAGE = 3072;
+__global__ void __launch_bounds__(PT_APPLY_THREADS)
+k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
+           uint64_t cap2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t words = 1u << (slice_bits - 5);
+    uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(slice + ((words + 3u) & ~3u));
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(stage + QL_STAGE);  // [0] staged count, [2..3] flush base
+    const uint32_t nb2 = 1u << log_nb2;
+    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
+    const uint32_t *src_slice = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;  // blockIdx = permuted slice index
+    if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
+    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
+    if (threadIdx.x == 0) s_ctl[0] = 0;
+    __syncthreads();
+    const uint32_t slice_mask = (1u << slice_bits) - 1u;
+    const int list = blockIdx.x % QS_LISTS;
+    uint64_t *my_list = surv + (uint64_t)list * surv_cap;
+    auto flush = [&]() {  // all threads
+        __syncthreads();
+        const uint32_t m = s_ctl[0];
+        if (m) {
+            if (threadIdx.x == 0) {
+                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
+                s_ctl[2] = (uint32_t)base; s_ctl[3] = (uint32_t)(base >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = (uint64_t)s_ctl[2] | ((uint64_t)s_ctl[3] << 32);
+            for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
+                if (base + i < surv_cap) my_list[base + i] = stage[i];
+                else surv_cur[QS_LISTS] = 1ull;  // sub-list overflow -> host falls back
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_ctl[0] = 0;
+        }
+        __syncthreads();
+    };
+    for (uint32_t j = 0; j < wpb; j++) {
+        const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
+        const uint64_t *src = buf2 + r * cap2;
+        const uint32_t n = cnt2[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 2 * PT_APPLY_THREADS) {
+            uint64_t v[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
+                v[u] = i < n ? src[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (v[u] != ~0ull) {
+                    const uint32_t a = (uint32_t)v[u] & slice_mask;
+                    if ((slice[a >> 5] >> (a & 31u)) & 1u) {
+                        const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
+                        stage[slot] = v[u] >> QE_E_SHIFT;  // slot < QL_STAGE: at most 2048 added per batch to <= 1024 left
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t staged = s_ctl[0];
+            __syncthreads();  // everyone has read the count before anyone stages more
+            if (staged > QL_STAGE - 2 * PT_APPLY_THREADS) flush();
+        }
+    }
+    flush();
+}
+
+// Region-overflow entries: first probe straight from the filter; hits join sub-list 0.
+__global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long long *cursor, uint64_t cap, const uint32_t *__restrict__ filter,
+                        uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+{
+    const uint64_t n = min((uint64_t)cursor[0], cap);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t a = perm.back(list[2 * i]);
+        if ((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u) {
+            const unsigned long long o = atomicAdd(&surv_cur[0], 1ull);
+            if (o < surv_cap) surv[o] = list[2 * i + 1]; else surv_cur[QS_LISTS] = 1ull;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ D
+template <int Q>
+__global__ void __launch_bounds__(256)
+k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ filter,
+           const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint32_t *rmask)
+{
+    __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
+    if (threadIdx.x < Q * 5) { s_h[threadIdx.x] = tab[threadIdx.x]; s_hk[threadIdx.x] = tab[TPC_TAB_HK + threadIdx.x]; }
+    __syncthreads();
+    const int list = blockIdx.y;
+    const uint64_t n = min((uint64_t)surv_cur[list], surv_cap);
+    const uint64_t *my = surv + (uint64_t)list * surv_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const uint64_t sid = my[idx];
+        const int e = (int)(sid & 7);
+        const uint64_t g = sid >> 3;
+        if ((rmask[g >> 5] >> ((uint32_t)g & 31u)) & 1u) continue;  // already marked by another edge
+        // vertex hashes of the N-free window at g, from the text (VertexRollingHash ctor, vertexrollinghash.h:79-102)
+        uint64_t pos[Q], neg[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
+        for (int t0 = 0; t0 < P.k; t0 += 32) {
+            uint64_t w = tpc_text_word(bases, g + t0);
+            const int m = min(32, P.k - t0);
+            for (int t = 0; t < m; t++) {
+                const int c = (int)(w & 3);
+                w >>= 2;
+#pragma unroll
+                for (int i = 0; i < Q; i++) pos[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+            }
+        }
+        for (int t1 = P.k; t1 > 0; t1 -= 32) {  // reverse complement: last base first
+            const int m = min(32, t1);
+            uint64_t w = tpc_text_word(bases, g + t1 - m);
+            for (int t = m - 1; t >= 0; t--) {
+                const int c = 3 - (int)((w >> (2 * t)) & 3);
+#pragma unroll
+                for (int i = 0; i < Q; i++) neg[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+            }
+        }
+        const int c = e & 3;
+        uint64_t p[Q], nn[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            if (e < 4) {  // in-edge c + v
+                p[i] = s_hk[i * 5 + c] ^ pos[i];
+                nn[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c];
+            } else {      // out-edge v + c
+                p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+                nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c];
+            }
+        }
+        const bool ng = tpc_pick_neg<Q>(p, nn);
+        bool present = true;  // function 0 passed in k_q_lookup
+#pragma unroll
+        for (int i = 1; i < Q; i++) {
+            if (present) {
+                const uint64_t a = ng ? nn[i] : p[i];
+                present = (filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u;
+            }
+        }
+        if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
+    }
+}
+
+template <int Q>
+void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
+{
+    QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const size_t lds = Bins<uint64_t>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
+    if (gated) {
+        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
+                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+    } else {
+        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
+                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+    }
+}
+
+template <int Q>
+void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
+{
+    hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, rmask);
+}
+
+}  // namespace
+
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_text, TpcQPlan &pl)
+{
+    const int F = L - slice_bits;
+    if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
+    if (n_text >= (1ull << 30)) return false;  // entry holds a 30-bit position (larger texts: direct kernel)
+    pl.slice_bits = slice_bits;
+    pl.b1 = (F + 1) / 2;
+    pl.b2 = F / 2;
+    if (pl.b1 > 9 || L - pl.b1 > 31) return false;
+    pl.n_tiles = (n_text / TPC_RUN + PT_THREADS) / PT_THREADS;
+    pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
+    pl.wpb = 4;
+    const int cap = (PT_BIN_BYTES / 8) >> pl.b1;
+    const int budget = std::max(1, (1 << pl.b1) * (cap - 16) * 5 / 8);  // entries per round
+    const int ppr = budget / (PT_THREADS * 6);
+    pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
+    const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
+    const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
+    pl.cap1 = ((uint64_t)(avg1 * 1.5 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
+    const double avg2 = a_max / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
+    // a level-2 region is one filter slice, and every query address is a function-0 address whose
+    // density over the slices falls linearly from 2x to 0 (tpc_bins.h): size for the densest slice
+    pl.cap2 = ((uint64_t)(avg2 * 2.1 + 8 * std::sqrt(avg2) + 128) + 15) & ~15ull;
+    pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
+    pl.surv_cap = (uint64_t)((double)n_text * 1.5 / QS_LISTS) + 65536;  // per sub-list
+    const PtPerm pm = pt_make_perm(slice_bits, F);
+    pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
+    return true;
+}
+
+size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
+{
+    switch (which) {
+    case 0: return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 8;
+    case 1: return (size_t)pl.nwg1 * (1u << pl.b1) * 4;
+    case 2: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 8;
+    case 3: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * 4;
+    case 4: return pl.ovf_cap * 16;
+    case 5: return 32 * sizeof(unsigned long long);
+    case 6: return (size_t)QS_LISTS * pl.surv_cap * 8;
+    case 7: return (QS_LISTS + 1) * sizeof(unsigned long long);
+    }
+    return 0;
+}
+
+// Launches A-D on the stream.  The caller zeroes ovf_cur / surv_cur first and reads both flags back
+// afterwards: surv_cur[QS_LISTS] != 0 or ovf_cur[1] != 0 means a list overflowed and the mask is
+// incomplete (re-run the direct kernel).
+int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
+{
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    switch (a.P.q) {
+    case 1: launch_qhash<1>(a, pl, gated, lo, hi, rmask); break;
+    case 2: launch_qhash<2>(a, pl, gated, lo, hi, rmask); break;
+    case 3: launch_qhash<3>(a, pl, gated, lo, hi, rmask); break;
+    case 4: launch_qhash<4>(a, pl, gated, lo, hi, rmask); break;
+    case 5: launch_qhash<5>(a, pl, gated, lo, hi, rmask); break;
+    case 6: launch_qhash<6>(a, pl, gated, lo, hi, rmask); break;
+    case 7: launch_qhash<7>(a, pl, gated, lo, hi, rmask); break;
+    case 8: launch_qhash<8>(a, pl, gated, lo, hi, rmask); break;
+    default: return -1;
+    }
+    {
+        QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
+        const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2);
+        (void)hipFuncSetAttribute((const void *)k_q_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1,
+                           pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf);
+    }
+    {
+        const size_t words = (size_t)1 << (pl.slice_bits - 5);
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
+        (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_q_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, pl.buf2,
+                           pl.cnt2, pl.cap2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+    }
+    hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+    switch (a.P.q) {
+    case 1: launch_qverify<1>(a, pl, rmask); break;
+    case 2: launch_qverify<2>(a, pl, rmask); break;
+    case 3: launch_qverify<3>(a, pl, rmask); break;
+    case 4: launch_qverify<4>(a, pl, rmask); break;
+    case 5: launch_qverify<5>(a, pl, rmask); break;
+    case 6: launch_qverify<6>(a, pl, rmask); break;
+    case 7: launch_qverify<7>(a, pl, rmask); break;
+    case 8: launch_qverify<8>(a, pl, rmask); break;
+    }
+    return 0;
+}
