@@ -49,6 +49,27 @@ struct QOverflow {  // entries that did not fit a region: {full address, survivo
 __device__ __forceinline__ bool within(uint64_t v, uint64_t lo, uint64_t hi) { return v >= lo && v <= hi; }
 
 // ------------------------------------------------------------------------------------------ A
+// Only hash function 0 is rolled here: the first probe of an edge is its function-0 address, and the
+// canonical strand is decided by function 0 unless its two strand values tie (probability 2^-L), in
+// which case the other functions are evaluated from the tile.  k_q_verify recomputes all q functions
+// for the few survivors.
+template <int Q>
+__device__ bool q_tie_break(const TpcHashParams &P, const uint64_t *s_h, const uint64_t *s_hk, const uint64_t *sb, const uint32_t *sn,
+                            uint64_t g, uint64_t wbase, int c, bool out_edge)
+{   // DetermineStrandExtend / Prepend (vertexrollinghash.h:170-200) for functions 1..Q-1; true = negative strand
+    for (int i = 1; i < Q; i++) {
+        uint64_t pos = 0, neg = 0;
+        for (int t = 0; t < P.k; t++) {
+            pos = tpc_rotl1(pos, P.L, P.lmask) ^ s_h[i * 5 + tpc_tile_char(sb, sn, g + t, wbase)];
+            neg = tpc_rotl1(neg, P.L, P.lmask) ^ s_h[i * 5 + tpc_rc(tpc_tile_char(sb, sn, g + P.k - 1 - t, wbase))];
+        }
+        const uint64_t p = out_edge ? (tpc_rotl1(pos, P.L, P.lmask) ^ s_h[i * 5 + c]) : (s_hk[i * 5 + c] ^ pos);
+        const uint64_t n = out_edge ? (neg ^ s_hk[i * 5 + 3 - c]) : (tpc_rotl1(neg, P.L, P.lmask) ^ s_h[i * 5 + 3 - c]);
+        if (p != n) return n < p;
+    }
+    return false;
+}
+
 template <int Q, bool GATED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
@@ -82,11 +103,11 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
         __syncthreads();
         const uint64_t g0 = (wfirst + tid) * TPC_RUN;
         const bool active = g0 < n_text;
-        TpcVHash<Q> v;
+        TpcVHash<1> v;  // function 0 only
         int ncnt = 0, c_prev = TPC_CODE_N, c_first = TPC_CODE_N;
         uint32_t word = 0;
         if (active) {
-            tpc_vhash_init<Q>(v, P, s_h, s_b, s_n, g0, wbase);
+            tpc_vhash_init<1>(v, P, s_h, s_b, s_n, g0, wbase);
             for (int t = 0; t < P.k; t++) ncnt += tpc_tile_char(s_b, s_n, g0 + t, wbase) == TPC_CODE_N;
             c_prev = tpc_tile_char(s_b, s_n, g0 - 1, wbase);
             c_first = tpc_tile_char(s_b, s_n, g0, wbase);
@@ -97,12 +118,8 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                     const uint64_t g = g0 + s;
                     const int c_next = tpc_tile_char(s_b, s_n, g + P.k, wbase);
                     const int c_first_nx = tpc_tile_char(s_b, s_n, g + 1, wbase);
-                    uint64_t r1p[Q], r1n[Q];
-#pragma unroll
-                    for (int i = 0; i < Q; i++) {
-                        r1p[i] = tpc_rotl1(v.pos[i], P.L, P.lmask);
-                        r1n[i] = tpc_rotl1(v.neg[i], P.L, P.lmask);
-                    }
+                    const uint64_t r1p = tpc_rotl1(v.pos[0], P.L, P.lmask);
+                    const uint64_t r1n = tpc_rotl1(v.neg[0], P.L, P.lmask);
                     bool check = ncnt == 0;
                     if (GATED) check = check && within(tpc_min(v.pos[0], v.neg[0]), lo, hi);  // VE.h:638
                     if (check) {
@@ -116,30 +133,20 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 {   // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200)
-                                    bool neg = false, decided = false;
-                                    uint64_t p0 = 0, n0 = 0;
-#pragma unroll
-                                    for (int i = 0; i < Q; i++) {
-                                        const uint64_t p = s_hk[i * 5 + c] ^ v.pos[i];
-                                        const uint64_t n = r1n[i] ^ s_h[i * 5 + 3 - c];
-                                        if (i == 0) { p0 = p; n0 = n; }
-                                        if (!decided && p != n) { neg = n < p; decided = true; }
-                                    }
+                                    const uint64_t p0 = s_hk[c] ^ v.pos[0];
+                                    const uint64_t n0 = r1n ^ s_h[3 - c];
+                                    bool neg = n0 < p0;
+                                    if (p0 == n0 && c != c_prev) neg = q_tie_break<Q>(P, s_h, s_hk, s_b, s_n, g, wbase, c, false);
                                     const uint64_t a0 = perm.fwd(neg ? n0 : p0);  // permuted address from here on
                                     eb[c] = (uint32_t)(a0 >> shift);
                                     ev[c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)c) << QE_E_SHIFT);
                                     eok[c] = c != c_prev;
                                 }
                                 {   // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184)
-                                    bool neg = false, decided = false;
-                                    uint64_t p0 = 0, n0 = 0;
-#pragma unroll
-                                    for (int i = 0; i < Q; i++) {
-                                        const uint64_t p = r1p[i] ^ s_h[i * 5 + c];
-                                        const uint64_t n = v.neg[i] ^ s_hk[i * 5 + 3 - c];
-                                        if (i == 0) { p0 = p; n0 = n; }
-                                        if (!decided && p != n) { neg = n < p; decided = true; }
-                                    }
+                                    const uint64_t p0 = r1p ^ s_h[c];
+                                    const uint64_t n0 = v.neg[0] ^ s_hk[3 - c];
+                                    bool neg = n0 < p0;
+                                    if (p0 == n0 && c != c_next) neg = q_tie_break<Q>(P, s_h, s_hk, s_b, s_n, g, wbase, c, true);
                                     const uint64_t a0 = perm.fwd(neg ? n0 : p0);
                                     eb[4 + c] = (uint32_t)(a0 >> shift);
                                     ev[4 + c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)(4 + c)) << QE_E_SHIFT);
@@ -149,12 +156,9 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                             bins.template push_batch<8>(eb, ev, eok, lost);
                         }
                     }
-                    // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113)
-#pragma unroll
-                    for (int i = 0; i < Q; i++) {
-                        v.pos[i] = r1p[i] ^ s_h[i * 5 + c_next] ^ s_hk[i * 5 + c_first];
-                        v.neg[i] = tpc_rotr1(v.neg[i] ^ s_hk[i * 5 + tpc_rc(c_next)] ^ s_h[i * 5 + tpc_rc(c_first)], P.L);
-                    }
+                    // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113), function 0
+                    v.pos[0] = r1p ^ s_h[c_next] ^ s_hk[c_first];
+                    v.neg[0] = tpc_rotr1(v.neg[0] ^ s_hk[tpc_rc(c_next)] ^ s_h[tpc_rc(c_first)], P.L);
                     ncnt += (c_next == TPC_CODE_N) - (c_first == TPC_CODE_N);
                     c_prev = c_first;
                     c_first = c_first_nx;
@@ -253,7 +257,7 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     uint64_t *my_list = surv + (uint64_t)list * surv_cap;
     auto flush = [&]() {  // all threads
         __syncthreads();
-        const uint32_t m = s_ctl[0];
+        const uint32_t m = min(s_ctl[0], (uint32_t)QL_STAGE);
         if (m) {
             if (threadIdx.x == 0) {
                 const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
@@ -274,28 +278,32 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
         const uint64_t *src = buf2 + r * cap2;
         const uint32_t n = cnt2[r];
-        for (uint32_t i0 = 0; i0 < n; i0 += 2 * PT_APPLY_THREADS) {
-            uint64_t v[2];
+        for (uint32_t i0 = 0; i0 < n; i0 += 4 * PT_APPLY_THREADS) {
+            uint64_t v[4];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
                 v[u] = i < n ? src[i] : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 if (v[u] != ~0ull) {
                     const uint32_t a = (uint32_t)v[u] & slice_mask;
                     if ((slice[a >> 5] >> (a & 31u)) & 1u) {
                         const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
-                        stage[slot] = v[u] >> QE_E_SHIFT;  // slot < QL_STAGE: at most 2048 added per batch to <= 1024 left
+                        if (slot < (uint32_t)QL_STAGE) stage[slot] = v[u] >> QE_E_SHIFT;
+                        else {  // staging full (dense hits): straight to the sub-list
+                            const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
+                            if (o < surv_cap) my_list[o] = v[u] >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
+                        }
                     }
                 }
             }
-            __syncthreads();
-            const uint32_t staged = s_ctl[0];
-            __syncthreads();  // everyone has read the count before anyone stages more
-            if (staged > QL_STAGE - 2 * PT_APPLY_THREADS) flush();
         }
+        __syncthreads();
+        const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
+        __syncthreads();  // everyone has read the count before anyone stages more
+        if (staged > QL_STAGE / 2) flush();
     }
     flush();
 }
