@@ -221,6 +221,31 @@ def test_partitioned_query_matches_oracle(capi, tmp_path, name, slice_bits):
     ctx.close()
 
 
+def test_partitioned_paths_in_batches(capi, tmp_path):
+    """Tiny buffer budget: insert and query run as several tile batches (later insert batches OR into
+    the filter, query batches carry batch-relative positions); same bitmap and mask."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.01)   # 8 x 50 kbp = 25 tiles of 16384 positions
+    text = capi.PackedText.from_codes(recs)
+    o = O.Oracle(25, 26, 5, O.seed_table(11, 5, 26))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    o.fill_only()
+    marks = o.check_only()
+    ctx = capi.Context(0)
+    for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", 14), ("part_min_tiles", 1), ("part_budget_bytes", 3 << 20)):
+        ctx.set_option(opt, val)
+    ctx.set_params(25, 26, 5, capi.seed_table(5, 26, seed=11))
+    ctx.seq_upload(text)
+    ctx.filter_reset()
+    ctx.pass1_insert()
+    assert (ctx.filter_download() == o.filter).all()
+    assert ctx.pass1_query() == marks
+    assert (ctx.mask_download(False) == o.round_mask).all()
+    ctx.close()
+
+
 def test_partitioned_query_adversarial_skew(capi):
     """Repeats + poly-A: bins, regions and the survivor lists overflow; result equals the direct kernel's."""
     rng = np.random.default_rng(5)

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""End-to-end CLI timing on a synthetic workload: writes the FASTA files, runs bin/twopaco, prints
+wall time and junction occurrences per second.  python tools/e2e_cli.py [m1|m2] [threads]"""
+import os, re, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from twopaco_amd import synth
+wl = sys.argv[1] if len(sys.argv) > 1 else "m2"
+threads = sys.argv[2] if len(sys.argv) > 2 else str(min(64, os.cpu_count()))
+recs, p = synth.workload(wl)
+tmp = tempfile.mkdtemp(dir="/tmp")
+files = []
+for i, r in enumerate(recs):
+    f = os.path.join(tmp, "g%d.fa" % i)
+    synth.write_fasta(f, [r], first_id=i)
+    files.append(f)
+exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
+out = os.path.join(tmp, "out.bin")
+for rep in range(2):
+    t0 = time.time()
+    res = subprocess.run([exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", "12345", "-o", out] + files,
+                         env=dict(os.environ, TWOPACO_TIMING="1"), capture_output=True, text=True)
+    wall = time.time() - t0
+    occ = int(re.search(r"True marks count: (\d+)", res.stdout).group(1))
+    print(res.stderr.strip())
+    print("run %d: wall %.3f s, %d junction occurrences, %.2f M occ/s end to end, out.bin %d bytes" % (rep, wall, occ, occ / wall / 1e6, os.path.getsize(out)))

@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w
     return base + inc - v;
 }
 
+template <class T>
+struct PtRegion { T *base; uint64_t cap; };
+
 // LDS bins: each bin is a ring of CAP entries.  Only whole groups of GROUP entries leave the
 // workgroup, so every global write is a full aligned 128-byte line; the < GROUP leftovers simply stay
 // in the ring.  A flush is two short data-parallel phases: one bookkeeping thread per bin builds the
@@ -128,10 +131,10 @@ struct Bins {
         }
     }
 
-    // region: this workgroup's private output, NB consecutive areas of `cap` entries.
+    // reg(b): this workgroup's private output area of bin b as PtRegion{base, cap}.
     // lost(b, val): called for an entry that does not fit its region (goes to an overflow list).
-    template <class Lost>
-    __device__ __forceinline__ void flush(bool final, T *region, uint64_t cap, Lost lost)
+    template <class Reg, class Lost>
+    __device__ __forceinline__ void flush(bool final, Reg reg, Lost lost)
     {
         __syncthreads();
         tick(0);  // everything since the previous flush: loads + hashing + pushes
@@ -157,7 +160,8 @@ struct Bins {
             const uint32_t b = it.x & 1023u, idx0 = (it.x >> 10) & 16383u, valid = it.x >> 24;
             const T val = l < valid ? data[(b << LOG_CAP) + idx0 + l] : SENT;
             const uint64_t pos = (uint64_t)it.y + l;
-            if (pos < cap) region[(uint64_t)b * cap + pos] = val;
+            const PtRegion<T> rg = reg(b);
+            if (pos < rg.cap) rg.base[pos] = val;
             else if (val != SENT) lost(b, val);
         }
         __syncthreads();
@@ -167,8 +171,9 @@ struct Bins {
 #endif
     }
 
-    __device__ __forceinline__ void store_counts(uint32_t *out, uint64_t cap)
+    template <class Reg>
+    __device__ __forceinline__ void store_counts(uint32_t *out, Reg reg)
     {
-        for (int b = threadIdx.x; b < NB; b += PT_THREADS) out[b] = (uint32_t)min((uint64_t)head[b], cap);
+        for (int b = threadIdx.x; b < NB; b += PT_THREADS) out[b] = (uint32_t)min((uint64_t)head[b], reg((uint32_t)b).cap);
     }
 };

@@ -60,8 +60,11 @@ struct tpc_ctx {
     int opt_slice_bits = 20;
     // partitioned insert
     bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
-    void *pbuf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // shared by insert and query
-    size_t pbytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *pbuf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // shared by insert and query
+    size_t pbytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint64_t> off2_uploaded;   // level-2 region offsets currently in pbuf[8]
+    int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
+    int64_t opt_part_budget = (int64_t)40 << 30;  // bytes of partition buffers per batch (first ~48 GiB of hipMalloc are cheap)
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
     int last_insert_mode = 0;
     // timing
@@ -141,6 +144,19 @@ int materialize_reset(tpc_ctx *c)
     return 0;
 }
 
+bool ensure_pbuf(tpc_ctx *c, int i, size_t need)
+{
+    if (need <= c->pbytes[i]) return true;
+    if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
+    c->pbuf[i] = nullptr; c->pbytes[i] = 0;
+    if (i == 8) c->off2_uploaded.clear();
+    if (hipMalloc(&c->pbuf[i], need) != hipSuccess) { (void)hipGetLastError(); return false; }
+    c->pbytes[i] = need;
+    return true;
+}
+
+uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
+
 int compact_mask(tpc_ctx *c, const uint32_t *m)
 {   // ordered list of the set bits of m -> c->marks / c->n_marks
     Timed t(c, TPC_K_COMPACT);
@@ -185,7 +201,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->scan_blocks };
+                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->pbuf[8], c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -202,6 +218,8 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "insert_mode")) { c->opt_insert_mode = (int)value; return 0; }
     if (!strcmp(name, "slice_bits")) { c->opt_slice_bits = (int)value; return 0; }
     if (!strcmp(name, "query_mode")) { c->opt_query_mode = (int)value; return 0; }
+    if (!strcmp(name, "part_budget_bytes")) { c->opt_part_budget = value; return 0; }
+    if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -295,38 +313,49 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
     TpcPartPlan pl;
-    bool part = c->opt_insert_mode != 1 && tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, c->n_text, pl);
-    if (c->opt_insert_mode == 0 && c->P.L < 28) part = false;  // small filters: the direct kernel is as fast
+    const uint64_t tiles = text_tiles512(c);
+    uint64_t batches = 1;
+    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
+    if (part) {
+        // as few batches of tiles as the buffer budget allows
+        for (;; batches *= 2) {
+            const uint64_t per = (tiles + batches - 1) / batches;
+            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, pl)) { part = false; break; }
+            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+        }
+    }
     if (part) {
         const size_t need[6] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
-                                 pl.ovf_cap * sizeof(uint64_t), 2 * sizeof(unsigned long long) };
-        for (int i = 0; i < 6; i++) {
-            if (need[i] > c->pbytes[i]) {
-                if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
-                c->pbuf[i] = nullptr; c->pbytes[i] = 0;
-                if (hipMalloc(&c->pbuf[i], need[i]) != hipSuccess) { part = false; break; }  // not enough HBM: direct path
-                c->pbytes[i] = need[i];
-            }
-        }
+                                 pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
+        for (int i = 0; i < 6 && part; i++) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
     }
     if (part) {
         pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
-        const bool fresh = c->filter_zero_pending;
+        bool fresh = c->filter_zero_pending;
         unsigned long long ov[2] = {0, 0};
+        bool overflowed = false;
         {
             Timed t(c, TPC_K_INSERT);
-            HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 2 * sizeof(unsigned long long), c->stream));
             if (fresh) HIPCHK(c, hipMemsetAsync(c->filter + (c->filter_words - 1), 0, sizeof(uint32_t), c->stream));
-            if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
-                return fail(c, -1, "partitioned insert launch failed");
+            const uint64_t per = pl.n_tiles;
+            for (uint64_t t0 = 0; t0 < tiles; t0 += per) {
+                pl.tile0 = t0;
+                pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
+                HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 2 * sizeof(unsigned long long), c->stream));
+                if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
+                    return fail(c, -1, "partitioned insert launch failed");
+                fresh = false;  // later batches OR into the slices
+                HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+                if (t0 + per < tiles) { HIPCHK(c, hipStreamSynchronize(c->stream)); overflowed = overflowed || ov[1] != 0; }
+            }
         }
         c->filter_zero_pending = false;
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        overflowed = overflowed || ov[1] != 0;
         c->last_insert_mode = 2;
-        if (ov[1] == 0) {
+        if (!overflowed) {
             if (n_kmers) return read_counter(c, 0, n_kmers);
             return 0;
         }
@@ -393,44 +422,58 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     c->marks_valid = false;
     TpcQPlan pl;
-    bool part = c->opt_query_mode != 1 && tpc_qpart_plan(c->P.L, c->opt_slice_bits, c->n_text, pl);
-    if (c->opt_query_mode == 0 && c->P.L < 28) part = false;  // small filters are cache resident: direct loads win
+    const uint64_t tiles = text_tiles512(c);
+    uint64_t batches = 1;
+    bool part = c->opt_query_mode != 1 && !(c->opt_query_mode == 0 && c->P.L < 28);  // small filters are cache resident: direct loads win
     if (part) {
-        for (int i = 0; i < 8; i++) {
-            const size_t need = tpc_qpart_bytes(pl, i);
-            if (need > c->pbytes[i]) {
-                if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
-                c->pbuf[i] = nullptr; c->pbytes[i] = 0;
-                if (hipMalloc(&c->pbuf[i], need) != hipSuccess) { part = false; break; }  // not enough HBM: direct path
-                c->pbytes[i] = need;
-            }
+        for (;; batches *= 2) {
+            const uint64_t per = (tiles + batches - 1) / batches;
+            const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, pl);
+            if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) { part = false; break; }  // geometry unsupported (not a size problem)
+            if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
+            if (per <= 1) { part = false; break; }
         }
     }
+    if (part)
+        for (int i = 0; i < 9 && part; i++) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
     if (part) {
         pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
         pl.surv = (uint64_t *)c->pbuf[6]; pl.surv_cur = (unsigned long long *)c->pbuf[7];
+        pl.off2 = (const uint64_t *)c->pbuf[8];
+        if (c->off2_uploaded != pl.off2_host) {
+            HIPCHK(c, hipMemcpy(c->pbuf[8], pl.off2_host.data(), pl.off2_host.size() * 8, hipMemcpyHostToDevice));
+            c->off2_uploaded = pl.off2_host;
+        }
         unsigned long long f1[2] = {0, 0}, f2 = 0;
+        bool overflowed = false;
         {
             Timed t(c, TPC_K_QUERY);
-            HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
-            HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
-            if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+            const uint64_t per = pl.n_tiles;
+            for (uint64_t t0 = 0; t0 < tiles && !overflowed; t0 += per) {
+                pl.tile0 = t0;
+                pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
+                HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
+                HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+                if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+                HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
+                if (t0 + per < tiles) { HIPCHK(c, hipStreamSynchronize(c->stream)); overflowed = f1[1] != 0 || f2 != 0; }
+            }
             tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
         uint64_t n = 0;
         int rc = read_counter(c, 1, &n);
         if (rc) return rc;
+        overflowed = overflowed || f1[1] != 0 || f2 != 0;
         if (getenv("TPC_PROFILE_PHASES")) {
             unsigned long long pr[32];
             (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu carry %llu rounds %llu | hash: push %llu book %llu copy %llu carry %llu rounds %llu (wall_clock ticks summed over WGs) sites: hashpush %llu hashregion %llu splitpush %llu splitregion %llu\n",
-                    pr[0], pr[8], pr[9], pr[10], pr[11], pr[12], pr[16], pr[17], pr[18], pr[19], pr[20], pr[24], pr[25], pr[26], pr[27]);
+            fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu rounds %llu | hash: push %llu book %llu copy %llu rounds %llu (10 ns ticks summed over WGs)\n",
+                    pr[0], pr[8], pr[9], pr[10], pr[12], pr[16], pr[17], pr[18], pr[20]);
         }
-        if (f1[1] == 0 && f2 == 0) {
+        if (!overflowed) {
             if (n_marks) *n_marks = n;
             return 0;
         }

@@ -1,6 +1,7 @@
 // tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi.hip) and the kernels.
 #pragma once
 #include "tpc_device.h"
+#include <vector>
 
 #define TPC_TAB_MAXQ 8
 #define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[8][5] then hk[8][5]
@@ -27,7 +28,7 @@ int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *
 struct TpcPartPlan {
     int slice_bits, b1, b2, pos_per_round;
     uint32_t perm_mult, perm_inv;  // slice-index permutation (tpc_bins.h:PtPerm)
-    uint64_t n_tiles;     // 512-word tiles of the text
+    uint64_t tile0, n_tiles;  // 512-word tiles of the text handled by this batch
     uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
     uint64_t cap1, cap2;  // entries per private region (multiples of 32)
     uint64_t ovf_cap;
@@ -35,7 +36,7 @@ struct TpcPartPlan {
     uint64_t *ovf;
     unsigned long long *ovf_cur;  // [0] count, [1] overflow-of-overflow flag
 };
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_text, TpcPartPlan &pl);
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, TpcPartPlan &pl);  // n_tiles: 512-word tiles per batch
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
@@ -47,9 +48,12 @@ int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uin
 struct TpcQPlan {
     int slice_bits, b1, b2, pos_per_round;
     uint32_t perm_mult, perm_inv;
-    uint64_t n_tiles;
+    uint64_t tile0, n_tiles;
     uint32_t nwg1, wpb;
-    uint64_t cap1, cap2;   // entries (uint64) per private region, multiples of 16
+    uint64_t cap1;         // entries (uint64) per level-1 region, multiple of 16
+    std::vector<uint64_t> off2_host;  // level-2 region offsets (entries), one per (b1, j, b2) + end
+    uint64_t buf2_entries;
+    const uint64_t *off2;  // device copy
     uint64_t ovf_cap;      // {address, survivor id} pairs
     uint64_t surv_cap;     // per survivor sub-list (64 of them)
     uint64_t *buf1, *buf2;
@@ -59,8 +63,8 @@ struct TpcQPlan {
     uint64_t *surv;
     unsigned long long *surv_cur;  // [0..63] counts, [64] overflow flag
 };
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_text, TpcQPlan &pl);
-size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl);  // n_tiles: 512-word tiles per batch
+size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 
 // pass 2 / output (tpc_pass2.hip)

@@ -70,7 +70,7 @@ struct HashEmit {
 template <int Q, bool GATED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-            const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
+            const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
             uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, unsigned long long *n_kmers)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,10 +88,11 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     const int shift = P.L - LOG_NB;
     HashEmit emit{&bins, &ovf, shift, (uint32_t)((1ull << shift) - 1ull), perm};
     uint32_t *region = buf1 + (uint64_t)blockIdx.x * NB * cap1;
+    auto reg = [region, cap1](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
     const int xw = (P.k + 1) / 32 + 2;
     unsigned hashed = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
         __syncthreads();  // previous tile's staging is no longer read
         const uint64_t wfirst = tile * PT_THREADS;
         const uint64_t wbase = wfirst - 1;
@@ -109,11 +110,11 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
             if (active)
                 for (int s = s0; s < s0 + pos_per_round; s++)
                     hashed += tpc_insert_step<Q, GATED>(r, P, s_h, s_hk, s_b, s_n, g0 + s, wbase, lo, hi, emit);
-            bins.flush(false, region, cap1, lost);
+            bins.flush(false, reg, lost);
         }
     }
-    bins.flush(true, region, cap1, lost);
-    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, cap1);
+    bins.flush(true, reg, lost);
+    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, reg);
     if (n_kmers) {
         for (int off = 32; off > 0; off >>= 1) hashed += __shfl_down(hashed, off, 64);
         if ((tid & 63) == 0) s_w[tid >> 6] = hashed;
@@ -143,6 +144,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     uint32_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
     auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
+    auto reg = [region, cap2](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap2, cap2}; };
     __syncthreads();
     // rounds of LOADS x PT_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
     // round's loads are issued before the current round is binned and flushed
@@ -174,13 +176,13 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
             for (int i = 0; i < LOADS; i++) { ok[i] = v[i] != PT_SENT; bb[i] = v[i] >> slice_bits; val[i] = v[i] & slice_mask; }
             bins.template push_batch<LOADS>(bb, val, ok, lost);
         }
-        bins.flush(false, region, cap2, lost);
+        bins.flush(false, reg, lost);
 #pragma unroll
         for (int i = 0; i < LOADS; i++) v[i] = vn[i];
         w = w2; base = base2; n = n2;
     }
-    bins.flush(true, region, cap2, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, cap2);
+    bins.flush(true, reg, lost);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg);
 }
 
 // ------------------------------------------------------------------------------------------ level 3
@@ -245,11 +247,11 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     if (gated) {
         (void)hipFuncSetAttribute((const void *)k_part_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_part_hash<Q, true>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
     } else {
         (void)hipFuncSetAttribute((const void *)k_part_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_part_hash<Q, false>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
     }
     return 0;
 }
@@ -269,15 +271,17 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 
 // Partition geometry for a filter of 2^L bits: slices of 2^slice_bits bits, fan-out split over two
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_text, TpcPartPlan &pl)
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, TpcPartPlan &pl)
 {
+    const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
     pl.slice_bits = slice_bits;
     pl.b1 = (F + 1) / 2;
     pl.b2 = F / 2;
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;  // entries are remainders below the 0xFFFFFFFF sentinel
-    pl.n_tiles = (n_text / TPC_RUN + PT_THREADS) / PT_THREADS;
+    pl.n_tiles = n_tiles;
+    pl.tile0 = 0;
     pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
     pl.wpb = 4;
     // positions per thread per round: keep a round's entries near a third of the bin storage
@@ -287,7 +291,7 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_text, TpcPartPlan &p
     pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
-    pl.cap1 = ((uint64_t)(avg1 * 1.5 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
+    pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
     const double avg2 = a_max / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;

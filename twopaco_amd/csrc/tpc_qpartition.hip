@@ -73,7 +73,7 @@ __device__ bool q_tie_break(const TpcHashParams &P, const uint64_t *s_h, const u
 template <int Q, bool GATED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-         const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
+         const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
          uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,9 +89,10 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
     const int shift = P.L - LOG_NB;
     uint64_t *region = buf1 + (uint64_t)blockIdx.x * NB * cap1;
+    auto reg = [region, cap1](uint32_t b) { return PtRegion<uint64_t>{region + (uint64_t)b * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
     const int xw = (P.k + 1) / 32 + 2;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
         __syncthreads();
         const uint64_t wfirst = tile * PT_THREADS;
         const uint64_t wbase = wfirst - 1;
@@ -126,7 +127,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                         if (c_prev == TPC_CODE_N || c_next == TPC_CODE_N) {
                             word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
                         } else {
-                            const uint64_t sid_g = g << 3;
+                            const uint64_t sid_g = (g - tile0 * (uint64_t)(PT_THREADS * TPC_RUN)) << 3;  // position relative to the batch
                             uint32_t eb[8];
                             uint64_t ev[8];
                             bool eok[8];
@@ -164,12 +165,12 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                     c_first = c_first_nx;
                 }
             }
-            bins.flush(false, region, cap1, lost);
+            bins.flush(false, reg, lost);
         }
         rmask[wfirst + tid] = word;  // N-neighbour marks; k_q_verify ORs the rest
     }
-    bins.flush(true, region, cap1, lost);
-    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, cap1);
+    bins.flush(true, reg, lost);
+    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, reg);
 #ifdef TPC_PROFILE_PHASES
     bins.dump(ovf.cursor + 16);
 #endif
@@ -178,7 +179,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 // ------------------------------------------------------------------------------------------ B
 __global__ void __launch_bounds__(PT_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
-          const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, uint64_t cap2, QOverflow ovf)
+          const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -190,7 +191,9 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32
     const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
     const int shift1 = L - LOG_NB1;
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
-    uint64_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
+    // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
+    const uint64_t *my_off = off2 + (uint64_t)blockIdx.x * NB2;
+    auto reg = [buf2, my_off](uint32_t b) { const uint64_t o = my_off[b]; return PtRegion<uint64_t>{buf2 + o, my_off[b + 1] - o}; };
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
     __syncthreads();
     uint32_t w = j, base = 0;
@@ -220,13 +223,13 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32
             for (int i = 0; i < LOADS; i++) { ok[i] = v[i] != SENT; bb[i] = (uint32_t)((v[i] & rem_mask) >> slice_bits); }
             bins.template push_batch<LOADS>(bb, v, ok, lost);
         }
-        bins.flush(false, region, cap2, lost);
+        bins.flush(false, reg, lost);
 #pragma unroll
         for (int i = 0; i < LOADS; i++) v[i] = vn[i];
         w = w2; base = base2; n = n2;
     }
-    bins.flush(true, region, cap2, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, cap2);
+    bins.flush(true, reg, lost);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg);
 #ifdef TPC_PROFILE_PHASES
     bins.dump(ovf.cursor + 8);
 #endif
@@ -238,7 +241,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32
 constexpr int QL_STAGE = 3072;
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-           uint64_t cap2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
@@ -276,7 +279,7 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     };
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        const uint64_t *src = buf2 + r * cap2;
+        const uint64_t *src = buf2 + off2[r];
         const uint32_t n = cnt2[r];
         for (uint32_t i0 = 0; i0 < n; i0 += 4 * PT_APPLY_THREADS) {
             uint64_t v[4];
@@ -327,7 +330,7 @@ __global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long l
 template <int Q>
 __global__ void __launch_bounds__(256)
 k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ filter,
-           const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint32_t *rmask)
+           const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t gbase, uint32_t *rmask)
 {
     __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
     if (threadIdx.x < Q * 5) { s_h[threadIdx.x] = tab[threadIdx.x]; s_hk[threadIdx.x] = tab[TPC_TAB_HK + threadIdx.x]; }
@@ -339,7 +342,7 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
         const uint64_t sid = my[idx];
         const int e = (int)(sid & 7);
-        const uint64_t g = sid >> 3;
+        const uint64_t g = gbase + (sid >> 3);
         if ((rmask[g >> 5] >> ((uint32_t)g & 31u)) & 1u) continue;  // already marked by another edge
         // vertex hashes of the N-free window at g, from the text (VertexRollingHash ctor, vertexrollinghash.h:79-102)
         uint64_t pos[Q], neg[Q];
@@ -398,32 +401,35 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     if (gated) {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     } else {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     }
 }
 
 template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
-    hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, rmask);
+    hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
+                       pl.tile0 * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
 }
 
 }  // namespace
 
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_text, TpcQPlan &pl)
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl)
 {
+    const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
-    if (n_text >= (1ull << 30)) return false;  // entry holds a 30-bit position (larger texts: direct kernel)
+    if (n_text > (1ull << 30)) return false;  // an entry holds a 30-bit position relative to the batch
     pl.slice_bits = slice_bits;
     pl.b1 = (F + 1) / 2;
     pl.b2 = F / 2;
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;
-    pl.n_tiles = (n_text / TPC_RUN + PT_THREADS) / PT_THREADS;
+    pl.n_tiles = n_tiles;
+    pl.tile0 = 0;
     pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
     pl.wpb = 4;
     const int cap = (PT_BIN_BYTES / 8) >> pl.b1;
@@ -432,15 +438,27 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_text, TpcQPlan &pl)
     pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
-    pl.cap1 = ((uint64_t)(avg1 * 1.5 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
-    const double avg2 = a_max / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
-    // a level-2 region is one filter slice, and every query address is a function-0 address whose
-    // density over the slices falls linearly from 2x to 0 (tpc_bins.h): size for the densest slice
-    pl.cap2 = ((uint64_t)(avg2 * 2.1 + 8 * std::sqrt(avg2) + 128) + 15) & ~15ull;
+    pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
-    pl.surv_cap = (uint64_t)((double)n_text * 1.5 / QS_LISTS) + 65536;  // per sub-list
+    pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
+    // level-2 region sizes: a region is one filter slice, and every query address is a function-0 address
+    // whose density over the slices falls linearly from 2x to 0 (tpc_bins.h)
+    const uint64_t nreg = (uint64_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2);
+    const double avg2 = a_max / (double)nreg;
+    const double S = (double)(1ull << F);
+    pl.off2_host.resize(nreg + 1);
+    uint64_t o = 0;
+    for (uint64_t r = 0; r < nreg; r++) {
+        const uint32_t b1 = (uint32_t)(r / ((uint64_t)pl.wpb << pl.b2)), b2 = (uint32_t)(r & ((1u << pl.b2) - 1));
+        const uint32_t s = pm.slice_of((b1 << pl.b2) | b2);
+        const double d = avg2 * 2.0 * (1.0 - ((double)s + 0.5) / S) + avg2 * 0.02;
+        pl.off2_host[r] = o;
+        o += ((uint64_t)(d * 1.25 + 8 * std::sqrt(d) + 96) + 15) & ~15ull;
+    }
+    pl.off2_host[nreg] = o;
+    pl.buf2_entries = o;
     return true;
 }
 
@@ -449,12 +467,13 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     switch (which) {
     case 0: return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 8;
     case 1: return (size_t)pl.nwg1 * (1u << pl.b1) * 4;
-    case 2: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 8;
+    case 2: return (size_t)pl.buf2_entries * 8;
     case 3: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * 4;
     case 4: return pl.ovf_cap * 16;
     case 5: return 32 * sizeof(unsigned long long);
     case 6: return (size_t)QS_LISTS * pl.surv_cap * 8;
     case 7: return (QS_LISTS + 1) * sizeof(unsigned long long);
+    case 8: return pl.off2_host.size() * 8;
     }
     return 0;
 }
@@ -481,14 +500,14 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
         const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2);
         (void)hipFuncSetAttribute((const void *)k_q_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1,
-                           pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf);
+                           pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_q_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, pl.buf2,
-                           pl.cnt2, pl.cap2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+                           pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
     switch (a.P.q) {

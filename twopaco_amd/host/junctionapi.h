@@ -113,6 +113,13 @@ namespace TwoPaCo
 			{
 				throw std::runtime_error("Can't create the output file");
 			}
+
+			buffer_.reserve(BUFFER_BYTES + RECORD_BYTES);
+		}
+
+		~JunctionPositionWriter()
+		{
+			Flush();
 		}
 
 		void WriteJunction(JunctionPosition pos)
@@ -130,15 +137,37 @@ namespace TwoPaCo
 			}
 		}
 
+		// Records are staged in a 1 MiB buffer (the reference issues two ofstream writes per record).
+		void Flush()
+		{
+			if (!buffer_.empty())
+			{
+				out_.write(buffer_.data(), std::streamsize(buffer_.size()));
+				buffer_.clear();
+			}
+
+			out_.flush();
+		}
+
 	private:
+		static const size_t RECORD_BYTES = sizeof(uint32_t) + sizeof(int64_t);
+		static const size_t BUFFER_BYTES = 1 << 20;
 		void Put(uint32_t p, int64_t id)
 		{
-			out_.write(reinterpret_cast<const char*>(&p), sizeof(p));
-			out_.write(reinterpret_cast<const char*>(&id), sizeof(id));
+			const char * a = reinterpret_cast<const char*>(&p);
+			const char * b = reinterpret_cast<const char*>(&id);
+			buffer_.insert(buffer_.end(), a, a + sizeof(p));
+			buffer_.insert(buffer_.end(), b, b + sizeof(id));
+			if (buffer_.size() >= BUFFER_BYTES)
+			{
+				out_.write(buffer_.data(), std::streamsize(buffer_.size()));
+				buffer_.clear();
+			}
 		}
 
 		uint32_t nowChr_;
 		std::ofstream out_;
+		std::vector<char> buffer_;
 	};
 }
 

@@ -1,7 +1,9 @@
 #include "vertexenumerator.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <iostream>
 #include <cstdlib>
 #include <ctime>
 #include <numeric>
@@ -18,6 +20,20 @@ namespace TwoPaCo
 	namespace
 	{
 		const uint64_t BINS_COUNT = uint64_t(1) << 24;  // reference vertexenumerator.h:471
+
+		// TWOPACO_TIMING=1: millisecond phase timings on stderr (the log keeps the reference's whole seconds)
+		struct PhaseTimer
+		{
+			bool on;
+			std::chrono::steady_clock::time_point t;
+			PhaseTimer() : on(std::getenv("TWOPACO_TIMING") != 0), t(std::chrono::steady_clock::now()) {}
+			void Lap(const char * what)
+			{
+				std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+				if (on) std::cerr << "[timing] " << what << ": " << std::chrono::duration<double, std::milli>(now - t).count() << " ms" << std::endl;
+				t = now;
+			}
+		};
 
 		class HipVertexEnumerator : public VertexEnumerator
 		{
@@ -86,11 +102,13 @@ namespace TwoPaCo
 					logStream << fn << std::endl;
 				}
 
+				PhaseTimer timer;
 				std::vector<uint64_t> table = MakeSeedTable(hashFunctions, filterSize, options.pinnedSeed, options.seed);
 				seed_ = VertexRollingHashSeed(hashFunctions, vertexLength, filterSize, table);
 
 				PackedText text;
 				PackFastaFiles(fileName, threads, text);
+				timer.Lap("parse + pack FASTA");
 
 				int rc = tpc_ctx_create(options.device, &ctx_);
 				if (rc != 0)
@@ -99,8 +117,12 @@ namespace TwoPaCo
 				}
 
 				Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
+				// a one-shot run never amortises device allocations, and on MI355X hipMalloc gets slow
+				// (~25 ms per GiB) beyond the first ~48 GiB: keep the partition buffers small and batch
+				Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(20) << 30), "set_option");
 				Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
+				timer.Lap("context + upload");
 
 				Check(tpc_run_begin(ctx_), "run_begin");
 
@@ -185,6 +207,7 @@ namespace TwoPaCo
 					low = high + 1;
 				}
 
+				timer.Lap("rounds (insert, query, exact filter)");
 				mark = time(0);
 				uint64_t junctions = 0;
 				Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
@@ -197,6 +220,7 @@ namespace TwoPaCo
 				std::vector<uint64_t> g(marked);
 				std::vector<int64_t> id(marked);
 				Check(tpc_emit_fetch(ctx_, g.data(), id.data()), "emit_fetch");
+				timer.Lap("sort + id lookup + fetch");
 
 				// EdgeConstructionWorker, reference vertexenumerator.h:927-958, in (sequence, position)
 				// order -- the order the reference's -t 1 run assigns stub ids in.
@@ -251,6 +275,8 @@ namespace TwoPaCo
 					cur = end;
 				}
 
+				posWriter.Flush();
+				timer.Lap("merge + write junction stream");
 				logStream << "True marks count: " << occurence << std::endl;
 				logStream << "Edges construction time: " << time(0) - mark << std::endl;
 				logStream << std::string(80, '-') << std::endl;
