@@ -102,7 +102,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("TPC_FORCE_DIST"):  # TPC_FORCE_DIST: exercise the distributed path with one rank
         from twopaco_amd import dist as tdist
         return tdist.bench_main(args, rank, world, local_rank)
 

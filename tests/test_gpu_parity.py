@@ -336,3 +336,28 @@ def test_naive_positions_seed_free(capi, tmp_path):
         for v in list(junction)[:200]:
             assert e.get_id(v) != capi.INVALID_VERTEX
         e.close()
+
+
+def test_cli_binary_writes_reference_bytes(tmp_path):
+    """bin/twopaco (the flag-compatible CLI) end to end on a golden case."""
+    import subprocess
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp_r4"][0]
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    out = str(tmp_path / "cli.bin")
+    r = subprocess.run([exe, "-k", str(case["k"]), "-f", str(case["L"]), "-q", str(case["q"]), "-r", str(case["n_rounds"]), "-t", "2",
+                        "--seed", str(case["seed"]), "--tmpdir", str(tmp_path), "-o", out, os.path.join(GOLDEN, case["fasta"])],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()
+    assert "Distinct junctions = %d" % case["distinct"] in r.stdout
+    assert "Splitting the input kmers set..." in r.stdout and r.stdout.count("Round ") == case["n_rounds"]
+
+
+def test_cli_selftest(tmp_path):
+    """twopaco --test: the reference's randomized differential self-test (test.cpp), shortened via env."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    r = subprocess.run([exe, "--test", "-f", "20", "--tmpdir", str(tmp_path), "dummy.fa"], capture_output=True, text=True,
+                       env=dict(os.environ, TWOPACO_SELFTEST_TRIALS="1"))
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("PASSED") == 1 and "FAILED" not in r.stderr

@@ -111,7 +111,9 @@ int main(int argc, char * argv[])
 
 		if (runTests)
 		{
-			return TwoPaCo::RunTests(10, 20, 9000, 6, TwoPaCo::Range(3, 11), TwoPaCo::Range(1, 2), TwoPaCo::Range(1, 5), TwoPaCo::Range(4, 5), 0.05, 0.1, tmpDirName) ? 0 : 1;
+			size_t trials = 10;
+			if (const char * t = std::getenv("TWOPACO_SELFTEST_TRIALS")) trials = size_t(std::atoi(t));
+			return TwoPaCo::RunTests(trials, 20, 9000, 6, TwoPaCo::Range(3, 11), TwoPaCo::Range(1, 2), TwoPaCo::Range(1, 5), TwoPaCo::Range(4, 5), 0.05, 0.1, tmpDirName) ? 0 : 1;
 		}
 
 		int64_t filterBits = filterSizeSet ? int64_t(filterSize) : int64_t(std::log2(filterMemory * 8e+9));
