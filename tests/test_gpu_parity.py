@@ -361,3 +361,40 @@ def test_cli_selftest(tmp_path):
                        env=dict(os.environ, TWOPACO_SELFTEST_TRIALS="1"))
     assert r.returncode == 0, r.stderr
     assert r.stderr.count("PASSED") == 1 and "FAILED" not in r.stderr
+
+
+def test_m2_full_size_partitioned_equals_direct(capi):
+    """BASELINE.json configs[2] at full size (62 x 5 Mbp, k=25, f=36, 8 GiB filter): the partitioned
+    insert/query and the direct atomic/load kernels give the same candidate mask, counters, junction keys
+    and (position, id) lists; junction ids are consistent (equal k-mer up to strand <=> equal |id|)."""
+    import hashlib
+    from twopaco_amd import synth
+    recs, p = synth.workload("m2")
+    text = capi.PackedText.from_codes(recs)
+    results = []
+    for mode in (2, 1):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_option("query_mode", mode)
+        ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=4242))
+        ctx.seq_upload(text)
+        ctx.run_begin()
+        ctx.filter_reset()
+        n_kmers = ctx.pass1_insert()
+        marks = ctx.pass1_query()
+        mask_sha = hashlib.sha256(ctx.mask_download(False).tobytes()).hexdigest()
+        st = ctx.pass2_filter()
+        J = ctx.junctions_finalize()
+        keys = ctx.junction_keys()
+        ctx.emit()
+        g, ids = ctx.emit_fetch()
+        results.append((n_kmers, marks, mask_sha, st, J, hashlib.sha256(keys.tobytes()).hexdigest(),
+                        hashlib.sha256(g.tobytes()).hexdigest(), hashlib.sha256(ids.tobytes()).hexdigest()))
+        if mode == 2:
+            assert n_kmers == synth.n_kmers(recs, p["k"])
+            assert (np.diff(keys[:, 0].astype(np.int64)) > 0).all()  # sorted, distinct (C = 1)
+            valid = ids != capi.INVALID_VERTEX
+            assert int(valid.sum()) >= marks - st["false"] * 64 and (np.abs(ids[valid]) <= J).all() and (ids[valid] != 0).all()
+            assert (np.diff(g.astype(np.int64)) > 0).all()
+        ctx.close()
+    assert results[0] == results[1]
