@@ -110,7 +110,7 @@ struct Bins {
     }
 
     // N entries per lane at once: all ring slots are claimed (N independent LDS atomics in flight)
-    // before any entry is stored.  ok[i] == false lanes go to the dummy bin.  lost(b, val) receives
+    // before any entry is stored.  ok[i] == false lanes are masked off.  lost(b, val) receives
     // the entries that found their ring full.
     template <int N, class Lost>
     __device__ __forceinline__ void push_batch(const uint32_t (&b)[N], const T (&val)[N], const bool (&ok)[N], Lost lost)
@@ -118,9 +118,11 @@ struct Bins {
         uint32_t slot[N], hd[N];
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            const uint32_t bb = ok[i] ? b[i] : (uint32_t)NB;
-            slot[i] = atomicAdd(&tail[bb], 1u);
-            hd[i] = head[bb];
+            slot[i] = 0; hd[i] = 0;
+            if (ok[i]) {  // predicated, not a dummy bin: a shared dummy counter is a 64-way same-address LDS atomic
+                slot[i] = atomicAdd(&tail[b[i]], 1u);
+                hd[i] = head[b[i]];
+            }
         }
 #pragma unroll
         for (int i = 0; i < N; i++) {
