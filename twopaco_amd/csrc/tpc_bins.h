@@ -40,7 +40,8 @@ inline PtPerm pt_make_perm(int slice_bits, int F)
     return p;
 }
 
-// exclusive scan over the PT_THREADS-thread workgroup
+// exclusive scan over a THREADS-thread workgroup
+template <int THREADS>
 __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -53,7 +54,7 @@ __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < PT_THREADS / 64; i++) { const uint32_t x = s_w[i]; if (i < wv) base += x; tot += x; }
+    for (int i = 0; i < THREADS / 64; i++) { const uint32_t x = s_w[i]; if (i < wv) base += x; tot += x; }
     total = tot;
     return base + inc - v;
 }
@@ -65,7 +66,7 @@ struct PtRegion { T *base; uint64_t cap; };
 // workgroup, so every global write is a full aligned 128-byte line; the < GROUP leftovers simply stay
 // in the ring.  A flush is two short data-parallel phases: one bookkeeping thread per bin builds the
 // list of 128-byte groups (scan of the group counts), then GROUP lanes copy each group.
-template <class T>
+template <class T, int THREADS = PT_THREADS>
 struct Bins {
     static constexpr int ENTRIES = PT_BIN_BYTES / (int)sizeof(T);
     static constexpr int GROUP = PT_LINE / (int)sizeof(T);
@@ -77,7 +78,7 @@ struct Bins {
     uint32_t *head;   // [NB + 1] entries already written to the bin's private region (multiple of GROUP)
     T *data;          // [NB * CAP] rings
     uint2 *items;     // [MAX_ITEMS] x = bin | ring index << 10 | valid << 24, y = position in the region
-    uint32_t *scan;   // [16]
+    uint32_t *scan;   // [32]
 #ifdef TPC_PROFILE_PHASES
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};  // thread 0: ticks in push / bookkeeping / copy, rounds
     unsigned long long t_mark = 0;
@@ -88,7 +89,7 @@ struct Bins {
     __device__ __forceinline__ void dump(unsigned long long *) {}
 #endif
 
-    static size_t lds_bytes(int log_nb) { return (size_t)PT_BIN_BYTES + ((size_t)8 << log_nb) + 16 + (size_t)MAX_ITEMS * 8 + 64; }
+    static size_t lds_bytes(int log_nb) { return (size_t)PT_BIN_BYTES + ((size_t)8 << log_nb) + 16 + (size_t)MAX_ITEMS * 8 + 128 + 64; }
 
     // carve: data first (16-byte aligned), then the bookkeeping arrays; returns the first free byte
     __device__ __forceinline__ unsigned char *carve(unsigned char *p, int log_nb)
@@ -101,12 +102,12 @@ struct Bins {
         tail = reinterpret_cast<uint32_t *>(items + MAX_ITEMS);
         head = tail + NB + 2;
         scan = head + NB + 2;
-        return reinterpret_cast<unsigned char *>(scan + 16);
+        return reinterpret_cast<unsigned char *>(scan + 32);
     }
 
     __device__ __forceinline__ void init()
     {
-        for (int b = threadIdx.x; b <= NB; b += PT_THREADS) { tail[b] = 0; head[b] = 0; }
+        for (int b = threadIdx.x; b <= NB; b += THREADS) { tail[b] = 0; head[b] = 0; }
     }
 
     // N entries per lane at once: all ring slots are claimed (N independent LDS atomics in flight)
@@ -148,7 +149,7 @@ struct Bins {
             f = final ? ((n + GROUP - 1u) & ~(uint32_t)(GROUP - 1)) : (n & ~(uint32_t)(GROUP - 1));
         }
         uint32_t total;
-        const uint32_t off = pt_block_excl_scan(f >> LOG_GROUP, scan, total);
+        const uint32_t off = pt_block_excl_scan<THREADS>(f >> LOG_GROUP, scan, total);
         for (uint32_t g = 0; g < (f >> LOG_GROUP); g++) {
             const uint32_t left = n - g * GROUP;
             items[off + g] = make_uint2(tid | (((h + g * GROUP) & (uint32_t)(CAP - 1)) << 10) | (min(left, (uint32_t)GROUP) << 24), h + g * GROUP);
@@ -157,7 +158,7 @@ struct Bins {
         __syncthreads();
         tick(1);
         const uint32_t l = tid & (GROUP - 1);
-        for (uint32_t w = tid >> LOG_GROUP; w < total; w += PT_THREADS / GROUP) {
+        for (uint32_t w = tid >> LOG_GROUP; w < total; w += THREADS / GROUP) {
             const uint2 it = items[w];
             const uint32_t b = it.x & 1023u, idx0 = (it.x >> 10) & 16383u, valid = it.x >> 24;
             const T val = l < valid ? data[(b << LOG_CAP) + idx0 + l] : SENT;
@@ -176,6 +177,6 @@ struct Bins {
     template <class Reg>
     __device__ __forceinline__ void store_counts(uint32_t *out, Reg reg)
     {
-        for (int b = threadIdx.x; b < NB; b += PT_THREADS) out[b] = (uint32_t)min((uint64_t)head[b], reg((uint32_t)b).cap);
+        for (int b = threadIdx.x; b < NB; b += THREADS) out[b] = (uint32_t)min((uint64_t)head[b], reg((uint32_t)b).cap);
     }
 };

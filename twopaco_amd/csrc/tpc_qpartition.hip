@@ -70,16 +70,19 @@ __device__ bool q_tie_break(const TpcHashParams &P, const uint64_t *s_h, const u
     return false;
 }
 
+constexpr int QH_THREADS = 1024;  // two threads per packed word: 16 positions each
+constexpr int QH_RUN = 16;
+
 template <int Q, bool GATED>
-__global__ void __launch_bounds__(PT_THREADS)
+__global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
          uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
-    constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
-    Bins<uint64_t> bins;
+    constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;  // a tile is still 512 packed words
+    Bins<uint64_t, QH_THREADS> bins;
     uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
     uint64_t *s_h = s_b + TW;
     uint64_t *s_hk = s_h + Q * 5;
@@ -92,17 +95,18 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     auto reg = [region, cap1](uint32_t b) { return PtRegion<uint64_t>{region + (uint64_t)b * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
     const int xw = (P.k + 1) / 32 + 2;
+    uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
     for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
         __syncthreads();
         const uint64_t wfirst = tile * PT_THREADS;
         const uint64_t wbase = wfirst - 1;
-        for (int i = tid; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
+        for (int i = tid; i < PT_THREADS + 1 + xw; i += QH_THREADS) {
             const int64_t w = (int64_t)wfirst - 1 + i;
             s_b[i] = w >= 0 ? bases[w] : 0ull;
             s_n[i] = w >= 0 ? nmask[w] : 0xFFFFFFFFu;
         }
         __syncthreads();
-        const uint64_t g0 = (wfirst + tid) * TPC_RUN;
+        const uint64_t g0 = wfirst * TPC_RUN + (uint64_t)tid * QH_RUN;
         const bool active = g0 < n_text;
         TpcVHash<1> v;  // function 0 only
         int ncnt = 0, c_prev = TPC_CODE_N, c_first = TPC_CODE_N;
@@ -113,7 +117,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
             c_prev = tpc_tile_char(s_b, s_n, g0 - 1, wbase);
             c_first = tpc_tile_char(s_b, s_n, g0, wbase);
         }
-        for (int s0 = 0; s0 < TPC_RUN; s0 += pos_per_round) {
+        for (int s0 = 0; s0 < QH_RUN; s0 += pos_per_round) {
             if (active) {
                 for (int s = s0; s < s0 + pos_per_round; s++) {
                     const uint64_t g = g0 + s;
@@ -167,7 +171,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
             }
             bins.flush(false, reg, lost);
         }
-        rmask[wfirst + tid] = word;  // N-neighbour marks; k_q_verify ORs the rest
+        rmask16[(wfirst * 2) + tid] = (uint16_t)word;  // N-neighbour marks (16 positions per thread); k_q_verify ORs the rest
     }
     bins.flush(true, reg, lost);
     bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, reg);
@@ -380,14 +384,12 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
             }
         }
         const bool ng = tpc_pick_neg<Q>(p, nn);
-        bool present = true;  // function 0 passed in k_q_lookup
+        bool present = true;  // function 0 passed in k_q_lookup; the other probes are independent loads
+        uint32_t wv[Q];
 #pragma unroll
-        for (int i = 1; i < Q; i++) {
-            if (present) {
-                const uint64_t a = ng ? nn[i] : p[i];
-                present = (filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u;
-            }
-        }
+        for (int i = 1; i < Q; i++) { const uint64_t a = ng ? nn[i] : p[i]; wv[i] = filter[a >> 5]; }
+#pragma unroll
+        for (int i = 1; i < Q; i++) { const uint64_t a = ng ? nn[i] : p[i]; present = present && ((wv[i] >> ((uint32_t)a & 31u)) & 1u); }
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
@@ -397,14 +399,14 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 {
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
-    const size_t lds = Bins<uint64_t>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
+    const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
     if (gated) {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
+        hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     } else {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
+        hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     }
 }
@@ -434,7 +436,7 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl)
     pl.wpb = 4;
     const int cap = (PT_BIN_BYTES / 8) >> pl.b1;
     const int budget = std::max(1, (1 << pl.b1) * (cap - 16) * 5 / 8);  // entries per round
-    const int ppr = budget / (PT_THREADS * 6);
+    const int ppr = budget / (1024 * 6);  // k_q_hash runs 1024 threads x 16 positions
     pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
