@@ -190,14 +190,14 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32
     constexpr int LOADS = 8;
     constexpr uint64_t SENT = ~0ull;
     Bins<uint64_t> bins;
-    bins.carve(smem, LOG_NB2);
+    uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
     bins.init();
+    for (uint32_t i = threadIdx.x; i <= NB2; i += PT_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
     const int shift1 = L - LOG_NB1;
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
     // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
-    const uint64_t *my_off = off2 + (uint64_t)blockIdx.x * NB2;
-    auto reg = [buf2, my_off](uint32_t b) { const uint64_t o = my_off[b]; return PtRegion<uint64_t>{buf2 + o, my_off[b + 1] - o}; };
+    auto reg = [buf2, s_off](uint32_t b) { const uint64_t o = s_off[b]; return PtRegion<uint64_t>{buf2 + o, s_off[b + 1] - o}; };
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
     __syncthreads();
     uint32_t w = j, base = 0;
@@ -499,7 +499,7 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
     }
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-        const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2);
+        const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
         (void)hipFuncSetAttribute((const void *)k_q_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1,
                            pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf);
