@@ -48,10 +48,8 @@ struct tpc_ctx {
     uint32_t *idtab = nullptr;
     uint64_t idtab_cap = 0;
     // emit
-    uint64_t *emit_g = nullptr;
     int64_t *emit_id = nullptr;
     uint64_t emit_cap = 0, n_emit = 0;
-    bool emit_uses_marks = false;
     // scalars
     unsigned long long *counters = nullptr;  // device, 8 words
     // options
@@ -66,7 +64,6 @@ struct tpc_ctx {
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = (int64_t)40 << 30;  // bytes of partition buffers per batch (first ~48 GiB of hipMalloc are cheap)
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
-    int last_insert_mode = 0;
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
@@ -203,7 +200,6 @@ void tpc_ctx_destroy(tpc_ctx *c)
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
                      c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->pbuf[8], c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (c->emit_g && !c->emit_uses_marks) (void)hipFree(c->emit_g);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -354,7 +350,6 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         overflowed = overflowed || ov[1] != 0;
-        c->last_insert_mode = 2;
         if (!overflowed) {
             if (n_kmers) return read_counter(c, 0, n_kmers);
             return 0;
@@ -370,7 +365,6 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         if (tpc_launch_insert(make_launch(c), lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
             return fail(c, -1, "insert launch failed");
     }
-    c->last_insert_mode = 1;
     HIPCHK(c, hipGetLastError());
     if (n_kmers) return read_counter(c, 0, n_kmers);
     return 0;
@@ -566,7 +560,7 @@ int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
     HIPCHK(c, hipSetDevice(c->device));
     {
         Timed t(c, TPC_K_SORT);
-        int rc = tpc_launch_sort_keys(c->stream, c->C, c->P.k, c->keys, c->n_keys, nullptr, 0);
+        int rc = tpc_launch_sort_keys(c->stream, c->C, c->P.k, c->keys, c->n_keys);
         if (rc) return fail(c, rc, "key sort failed (%d)", rc);
         uint64_t cap = 1024;
         while (cap < 2 * c->n_keys + 2) cap <<= 1;

@@ -90,10 +90,9 @@ int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, 
 int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
                            const uint64_t *block_off, uint64_t *keys_out);
 
-// Sort junction keys (J x C) in CompressedString::Less order; tmp buffers managed by caller via
-// query: returns required scratch bytes when scratch == nullptr.
-size_t tpc_sort_scratch_bytes(int C, uint64_t J, int k);
-int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void *scratch, size_t scratch_bytes);
+// Sort junction keys (J x C, in place) in CompressedString::Less order (rocPRIM radix sort; scratch is
+// allocated inside: J is small).
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J);
 
 // id index over sorted keys + output-pass lookup
 int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap);

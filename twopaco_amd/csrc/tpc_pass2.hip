@@ -501,7 +501,7 @@ int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, con
     return 0;
 }
 
-int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void *, size_t)
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J)
 {
     if (J < 2) return 0;
     hipError_t e;
@@ -549,7 +549,6 @@ int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J
     return rc;
 }
 
-size_t tpc_sort_scratch_bytes(int, uint64_t, int) { return 0; }
 
 int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap)
 {

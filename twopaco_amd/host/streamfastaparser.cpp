@@ -141,4 +141,51 @@ namespace TwoPaCo
 
 		pos_ = p;
 	}
+
+	uint64_t StreamFastaParser::ReadSequencePacked(std::vector<uint64_t> & bases, std::vector<uint32_t> & nmask)
+	{
+		const size_t n = data_.size();
+		const unsigned char * d = reinterpret_cast<const unsigned char*>(data_.data());
+		size_t p = pos_;
+		uint64_t count = 0, word = 0;
+		uint32_t mask = 0;
+		unsigned fill = 0;
+		bases.clear();
+		nmask.clear();
+		for (; p < n; ++p)
+		{
+			const uint8_t cls = CLASS.t[d[p]];
+			if (cls <= 4)
+			{
+				word |= static_cast<uint64_t>(cls & 3) << (2 * fill);
+				mask |= static_cast<uint32_t>(cls >> 2) << fill;
+				if (++fill == 32)
+				{
+					bases.push_back(word);
+					nmask.push_back(mask);
+					word = 0; mask = 0; fill = 0;
+				}
+
+				++count;
+			}
+			else if (cls == 6)
+			{
+				break;
+			}
+			else if (cls == 7)
+			{
+				pos_ = p;
+				throw Exception("Found an invalid character '" + std::string(1, static_cast<char>(d[p])) + "' in sequence " + currentHeader_);
+			}
+		}
+
+		if (fill)
+		{
+			bases.push_back(word);
+			nmask.push_back(mask);
+		}
+
+		pos_ = p;
+		return count;
+	}
 }

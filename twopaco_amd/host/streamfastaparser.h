@@ -34,6 +34,10 @@ namespace TwoPaCo
 		// other valid character ('N' after VertexEnumerator's mapping, reference vertexenumerator.h:1174).
 		void ReadSequenceCodes(std::vector<uint8_t> & out);
 
+		// Same scan, packed on the fly in the device layout: base i at bits 2*(i%32) of bases[i/32] (an
+		// N keeps code 0), bit i%32 of nmask[i/32] set for N.  Returns the number of characters.
+		uint64_t ReadSequencePacked(std::vector<uint64_t> & bases, std::vector<uint32_t> & nmask);
+
 	private:
 		std::string data_;
 		size_t pos_;

@@ -62,6 +62,41 @@ namespace TwoPaCo
 		length = end;
 	}
 
+	void PackedText::AppendPacked(const uint64_t * b, const uint32_t * m, uint64_t n)
+	{
+		if (n == 0) return;
+		const uint64_t end = length + n;
+		const uint64_t words = (end + 31) / 32;
+		if (bases.size() < words)
+		{
+			bases.resize(words, 0);
+			nmask.resize(words, 0);
+		}
+
+		const uint64_t w0 = length >> 5;
+		const unsigned o = static_cast<unsigned>(length & 31);
+		const uint64_t nw = (n + 31) / 32;
+		if (o == 0)
+		{
+			for (uint64_t i = 0; i < nw; i++) { bases[w0 + i] |= b[i]; nmask[w0 + i] |= m[i]; }
+		}
+		else
+		{
+			for (uint64_t i = 0; i < nw; i++)
+			{
+				bases[w0 + i] |= b[i] << (2 * o);
+				nmask[w0 + i] |= m[i] << o;
+				if (w0 + i + 1 < words)
+				{
+					bases[w0 + i + 1] |= b[i] >> (64 - 2 * o);
+					nmask[w0 + i + 1] |= m[i] >> (32 - o);
+				}
+			}
+		}
+
+		length = end;
+	}
+
 	void PackedText::EndRecord(uint64_t recordBases)
 	{
 		recStart.push_back(length - recordBases);
@@ -73,7 +108,8 @@ namespace TwoPaCo
 	void PackFastaFiles(const std::vector<std::string> & fileName, size_t threads, PackedText & out)
 	{
 		// per file: the records' code strings
-		struct Parsed { std::vector<std::vector<uint8_t> > records; std::unique_ptr<StreamFastaParser::Exception> error; };
+		struct Record { std::vector<uint64_t> bases; std::vector<uint32_t> nmask; uint64_t n; };
+		struct Parsed { std::vector<Record> records; std::unique_ptr<StreamFastaParser::Exception> error; };
 		std::vector<Parsed> parsed(fileName.size());
 		std::atomic<size_t> next(0);
 		auto work = [&]()
@@ -86,7 +122,8 @@ namespace TwoPaCo
 					while (parser.ReadRecord())
 					{
 						parsed[f].records.emplace_back();
-						parser.ReadSequenceCodes(parsed[f].records.back());
+						Record & rec = parsed[f].records.back();
+						rec.n = parser.ReadSequencePacked(rec.bases, rec.nmask);
 					}
 				}
 				catch (const StreamFastaParser::Exception & e)
@@ -116,11 +153,12 @@ namespace TwoPaCo
 				throw *parsed[f].error;
 			}
 
-			for (std::vector<uint8_t> & rec : parsed[f].records)
+			for (Record & rec : parsed[f].records)
 			{
-				out.AppendCodes(rec.data(), rec.size());
-				out.EndRecord(rec.size());
-				std::vector<uint8_t>().swap(rec);
+				out.AppendPacked(rec.bases.data(), rec.nmask.data(), rec.n);
+				out.EndRecord(rec.n);
+				std::vector<uint64_t>().swap(rec.bases);
+				std::vector<uint32_t>().swap(rec.nmask);
 			}
 		}
 	}

@@ -25,6 +25,7 @@ namespace TwoPaCo
 
 		PackedText() : length(0) {}
 		void AppendCodes(const uint8_t * codes, uint64_t n);  // 0..3 bases, 4 = N
+		void AppendPacked(const uint64_t * b, const uint32_t * m, uint64_t n);  // n characters already packed from bit 0
 		void BeginText();                                      // leading separator
 		void EndRecord(uint64_t recordBases);                  // bookkeeping + trailing separator
 	};
