@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstring>
+#include <thread>
 #include <iostream>
 #include <cstdlib>
 #include <ctime>
@@ -223,10 +226,59 @@ namespace TwoPaCo
 				timer.Lap("sort + id lookup + fetch");
 
 				// EdgeConstructionWorker, reference vertexenumerator.h:927-958, in (sequence, position)
-				// order -- the order the reference's -t 1 run assigns stub ids in.
+				// order -- the order the reference's -t 1 run assigns stub ids in.  The byte stream is what
+				// JunctionPositionWriter::WriteJunction would produce (junctionapi.h): 12-byte records, one
+				// separator per sequence-id step.  Plan: a sequential walk over the records fixes every
+				// output offset (records, stubs, separators); the records are then formatted by `threads`
+				// workers and written with one call.
 				uint64_t occurence = 0;
 				uint64_t currentStubVertexId = verticesCount + 42;  // vertexenumerator.h:419
-				JunctionPositionWriter posWriter(outFileName);
+				struct Piece { size_t begin, end; uint64_t first; uint64_t offset; };  // marks [begin,end) of one record -> byte offset
+				std::vector<Piece> pieces;
+				std::vector<char> out;
+				const size_t RECORD = sizeof(uint32_t) + sizeof(int64_t);
+				auto put = [&out](uint64_t offset, uint32_t p, int64_t v)
+				{
+					std::memcpy(&out[offset], &p, sizeof(p));
+					std::memcpy(&out[offset + sizeof(p)], &v, sizeof(v));
+				};
+
+				// pass 1 (parallel): number of valid ids in each block of marks
+				const size_t BLOCK = size_t(1) << 16;
+				const size_t blocks = (marked + BLOCK - 1) / BLOCK;
+				std::vector<uint64_t> validBefore(blocks + 1, 0);
+				const size_t workers = std::max<size_t>(1, std::min<size_t>(threads, 64));
+				{
+					std::vector<std::thread> pool;
+					for (size_t t = 0; t < workers; t++)
+					{
+						pool.emplace_back([&, t]()
+						{
+							for (size_t bl = t; bl < blocks; bl += workers)
+							{
+								uint64_t n = 0;
+								const size_t e = std::min(marked, (bl + 1) * BLOCK);
+								for (size_t i = bl * BLOCK; i < e; i++) n += id[i] != INVALID_VERTEX;
+								validBefore[bl + 1] = n;
+							}
+						});
+					}
+					for (std::thread & th : pool) th.join();
+				}
+				for (size_t bl = 0; bl < blocks; bl++) validBefore[bl + 1] += validBefore[bl];
+				auto validUpTo = [&](size_t i)  // valid ids among marks [0, i)
+				{
+					const size_t bl = i / BLOCK;
+					uint64_t n = validBefore[bl];
+					for (size_t j = bl * BLOCK; j < i; j++) n += id[j] != INVALID_VERTEX;
+					return n;
+				};
+
+				// pass 2 (sequential over the records): offsets, stubs, separators
+				struct Fixed { uint64_t offset; uint32_t pos; int64_t id; };
+				std::vector<Fixed> fixed;
+				uint64_t offset = 0;
+				uint32_t nowChr = 0;
 				size_t cur = 0;
 				for (size_t r = 0; r < text.recStart.size(); r++)
 				{
@@ -238,44 +290,92 @@ namespace TwoPaCo
 
 					const uint64_t first = text.recStart[r];
 					const uint64_t last = first + len - vertexLength;
-					while (cur < marked && g[cur] < first) ++cur;
-					size_t end = cur;
-					bool firstValid = false, lastValid = false;
-					for (; end < marked && g[end] <= last; ++end)
+					cur = size_t(std::lower_bound(g.begin() + cur, g.end(), first) - g.begin());
+					const size_t end = size_t(std::upper_bound(g.begin() + cur, g.end(), last) - g.begin());
+					const bool firstValid = cur < end && g[cur] == first && id[cur] != INVALID_VERTEX;
+					const bool lastValid = cur < end && g[end - 1] == last && id[end - 1] != INVALID_VERTEX;
+					for (; nowChr < r; ++nowChr)  // JunctionPositionWriter: one separator per sequence-id step
 					{
-						if (id[end] != INVALID_VERTEX)
-						{
-							firstValid = firstValid || g[end] == first;
-							lastValid = lastValid || g[end] == last;
-						}
+						fixed.push_back(Fixed{offset, UINT32_MAX, INT64_MAX});
+						offset += RECORD;
 					}
 
 					// first / last k-mer of the sequence without a junction id get a stub id (vertexenumerator.h:942-948)
 					if (!firstValid)
 					{
+						fixed.push_back(Fixed{offset, 0, int64_t(currentStubVertexId++)});
+						offset += RECORD;
 						++occurence;
-						posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(0), int64_t(currentStubVertexId++)));
 					}
 
-					for (size_t i = cur; i < end; i++)
-					{
-						if (id[i] != INVALID_VERTEX)
-						{
-							++occurence;
-							posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(g[i] - first), id[i]));
-						}
-					}
-
+					const uint64_t nValid = validUpTo(end) - validUpTo(cur);
+					pieces.push_back(Piece{cur, end, first, offset});
+					offset += nValid * RECORD;
+					occurence += nValid;
 					if (last != first && !lastValid)
 					{
+						fixed.push_back(Fixed{offset, uint32_t(last - first), int64_t(currentStubVertexId++)});
+						offset += RECORD;
 						++occurence;
-						posWriter.WriteJunction(JunctionPosition(uint32_t(r), uint32_t(last - first), int64_t(currentStubVertexId++)));
 					}
 
 					cur = end;
 				}
 
-				posWriter.Flush();
+				out.resize(offset);
+				for (const Fixed & f : fixed) put(f.offset, f.pos, f.id);
+
+				// pass 3 (parallel): format the junction records of every piece, in blocks of marks
+				struct Task { size_t begin, end; uint64_t first; uint64_t offset; };
+				std::vector<Task> tasks;
+				for (const Piece & p : pieces)
+				{
+					uint64_t off = p.offset;
+					for (size_t b0 = p.begin; b0 < p.end;)
+					{
+						const size_t e0 = std::min(p.end, (b0 / BLOCK + 1) * BLOCK);
+						tasks.push_back(Task{b0, e0, p.first, off});
+						off += (validUpTo(e0) - validUpTo(b0)) * RECORD;
+						b0 = e0;
+					}
+				}
+				{
+					std::vector<std::thread> pool;
+					for (size_t t = 0; t < workers; t++)
+					{
+						pool.emplace_back([&, t]()
+						{
+							for (size_t k = t; k < tasks.size(); k += workers)
+							{
+								uint64_t off = tasks[k].offset;
+								for (size_t i = tasks[k].begin; i < tasks[k].end; i++)
+								{
+									if (id[i] != INVALID_VERTEX)
+									{
+										put(off, uint32_t(g[i] - tasks[k].first), id[i]);
+										off += RECORD;
+									}
+								}
+							}
+						});
+					}
+					for (std::thread & th : pool) th.join();
+				}
+
+				{
+					std::FILE * f = std::fopen(outFileName.c_str(), "wb");
+					if (!f)
+					{
+						throw std::runtime_error("Can't create the output file");
+					}
+
+					const bool ok = out.empty() || std::fwrite(out.data(), 1, out.size(), f) == out.size();
+					if (std::fclose(f) != 0 || !ok)
+					{
+						throw std::runtime_error("Can't write to the output file");
+					}
+				}
+
 				timer.Lap("merge + write junction stream");
 				logStream << "True marks count: " << occurence << std::endl;
 				logStream << "Edges construction time: " << time(0) - mark << std::endl;
