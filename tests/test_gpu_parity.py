@@ -398,3 +398,30 @@ def test_m2_full_size_partitioned_equals_direct(capi):
             assert (np.diff(g.astype(np.int64)) > 0).all()
         ctx.close()
     assert results[0] == results[1]
+
+
+@pytest.mark.parametrize("L", [37, 38])
+def test_partitioned_paths_large_filters(capi, L):
+    """f=37/38 (16/32 GiB filter, 512 bins per level, rings of 32 uint64 entries): partitioned insert and
+    query against the direct kernels on the same text -- same candidate mask, marks and junction keys."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.02)
+    text = capi.PackedText.from_codes(recs)
+    res = []
+    for mode in (2, 1):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_option("query_mode", mode)
+        ctx.set_params(25, L, 5, capi.seed_table(5, L, seed=77))
+        ctx.seq_upload(text)
+        ctx.run_begin()
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        marks = ctx.pass1_query()
+        mask = ctx.mask_download(False)
+        st = ctx.pass2_filter()
+        ctx.junctions_finalize()
+        res.append((marks, mask, st, ctx.junction_keys()))
+        ctx.close()
+    assert res[0][0] == res[1][0] > 0 and res[0][2] == res[1][2]
+    assert (res[0][1] == res[1][1]).all() and (res[0][3] == res[1][3]).all()

@@ -46,7 +46,7 @@ int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uin
 
 // partitioned query (tpc_qpartition.hip)
 struct TpcQPlan {
-    int slice_bits, b1, b2, pos_per_round;
+    int slice_bits, b1, b2, pos_per_round, sub_rounds, loads;
     uint32_t perm_mult, perm_inv;
     uint64_t tile0, n_tiles;
     uint32_t nwg1, wpb;

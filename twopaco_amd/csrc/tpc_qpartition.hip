@@ -76,8 +76,8 @@ constexpr int QH_RUN = 16;
 template <int Q, bool GATED>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-         const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
-         uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
+         const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, int sub_rounds,
+         uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
@@ -117,9 +117,11 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
             c_prev = tpc_tile_char(s_b, s_n, g0 - 1, wbase);
             c_first = tpc_tile_char(s_b, s_n, g0, wbase);
         }
-        for (int s0 = 0; s0 < QH_RUN; s0 += pos_per_round) {
-            if (active) {
-                for (int s = s0; s < s0 + pos_per_round; s++) {
+        // a round = pos_per_round positions per thread, or (many small bins) one position for every
+        // sub_rounds-th thread, so that a round never outgrows the rings
+        for (int s0 = 0; s0 < QH_RUN * sub_rounds; s0 += pos_per_round) {
+            if (active && (sub_rounds == 1 || (tid % sub_rounds) == (s0 % sub_rounds))) {
+                for (int s = s0 / sub_rounds; s < s0 / sub_rounds + pos_per_round; s++) {
                     const uint64_t g = g0 + s;
                     const int c_next = tpc_tile_char(s_b, s_n, g + P.k, wbase);
                     const int c_first_nx = tpc_tile_char(s_b, s_n, g + 1, wbase);
@@ -182,7 +184,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 
 // ------------------------------------------------------------------------------------------ B
 __global__ void __launch_bounds__(PT_THREADS)
-k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
+k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,12 +211,12 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
             const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
-            dst[i] = idx < nn ? src[idx] : SENT;
+            dst[i] = (i < loads && idx < nn) ? src[idx] : SENT;
         }
     };
     if (w < nwg1) load(v, w, base, n);
     while (w < nwg1) {
-        uint32_t w2 = w, base2 = base + LOADS * PT_THREADS, n2 = n;
+        uint32_t w2 = w, base2 = base + (uint32_t)loads * PT_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
             do { w2 += wpb; n2 = w2 < nwg1 ? cnt1[(uint64_t)w2 * NB1 + b1] : 0; } while (w2 < nwg1 && n2 == 0);
@@ -403,11 +405,11 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     if (gated) {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     } else {
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
     }
 }
 
@@ -438,6 +440,8 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl)
     const int budget = std::max(1, (1 << pl.b1) * (cap - 16) * 5 / 8);  // entries per round
     const int ppr = budget / (1024 * 6);  // k_q_hash runs 1024 threads x 16 positions
     pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
+    pl.sub_rounds = ppr >= 1 ? 1 : std::min(16, (1024 * 6 + budget - 1) / budget);
+    pl.loads = std::max(1, std::min(8, budget * 9 / 8 / PT_THREADS / 2));  // k_q_split entries per thread per round (level-2 bins see a 2x skew)
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
@@ -501,7 +505,7 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
         const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
         (void)hipFuncSetAttribute((const void *)k_q_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1,
+        hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.loads, pl.nwg1,
                            pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf);
     }
     {
