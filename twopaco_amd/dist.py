@@ -154,12 +154,18 @@ def bench_main(args, rank, world, local_rank):
 
     from . import capi, synth
 
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    backend = os.environ.get("TPC_DIST_BACKEND", "nccl")  # "gloo": several ranks on one GPU (testing only)
+    ngpu = torch.cuda.device_count()
+    device = local_rank % max(ngpu, 1)
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group(backend)
     recs, p = synth.workload(args.workload, scale=args.scale)
     n_kmers = synth.n_kmers(recs, p["k"])
     text = capi.PackedText.from_codes(recs)
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device)
     ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=12345))
     ctx.seq_upload(text)
     be = HipBackend(ctx)
@@ -176,9 +182,10 @@ def bench_main(args, rank, world, local_rank):
             kms[n] += max(ctx.kernel_ms(n), 0.0) / args.steps
     torch.cuda.synchronize()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dev = _dev(dist)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device="cuda")
+    tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
     dist.all_reduce(tot)
     dt = float(dt.item())
     if rank == 0:
