@@ -425,3 +425,53 @@ def test_partitioned_paths_large_filters(capi, L):
         ctx.close()
     assert res[0][0] == res[1][0] > 0 and res[0][2] == res[1][2]
     assert (res[0][1] == res[1][1]).all() and (res[0][3] == res[1][3]).all()
+
+
+def test_randomized_differential_vs_oracle(capi, tmp_path):
+    """40 random configurations (sequence set with N runs / IUPAC / lower case / short records, odd and even k,
+    L, q, rounds, abundance, forced kernel paths): CreateEnumerator's de_bruijn.bin == the oracle's, byte for byte."""
+    rng = np.random.default_rng(20240607)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for trial in range(40):
+        k = int(rng.choice([3, 5, 7, 9, 11, 15, 21, 25, 27, 29, 31, 33, 45, 63, 8, 12]))
+        L = int(rng.integers(8, 23))
+        q = int(rng.integers(1, 9))
+        rounds = int(rng.integers(1, 4))
+        abundance = int(rng.choice([MAXU, MAXU, 2, 5]))
+        base = alphabet[rng.integers(0, 4, int(rng.integers(50, 4000)))].copy()
+        recs = []
+        for r in range(int(rng.integers(1, 7))):
+            s = base.copy()
+            hits = rng.random(s.size) < 0.03
+            s[hits] = alphabet[rng.integers(0, 4, int(hits.sum()))]
+            cut = int(rng.integers(0, s.size))
+            s = np.concatenate([s[cut:], s[:cut]]) if rng.random() < 0.5 else s
+            if rng.random() < 0.5:
+                for _ in range(int(rng.integers(1, 4))):
+                    a = int(rng.integers(0, s.size)); s[a:a + int(rng.integers(1, 30))] = ord("N")
+            if rng.random() < 0.3:
+                s[rng.integers(0, s.size, 3)] = np.frombuffer(b"RYK", dtype=np.uint8)
+            txt = s.tobytes().decode()
+            if rng.random() < 0.3:
+                txt = txt.lower()
+            if rng.random() < 0.15:
+                txt = txt[:int(rng.integers(0, k + 2))]
+            recs.append(txt)
+        fa = str(tmp_path / ("r%d.fa" % trial))
+        with open(fa, "w") as f:
+            for i, t in enumerate(recs):
+                f.write(">s%d\n" % i)
+                for j in range(0, len(t), 61):
+                    f.write(t[j:j + 61] + "\n")
+        seed = int(rng.integers(1, 1 << 40))
+        o = O.Oracle(k, L, q, O.seed_table(seed, q, L))
+        o.add_fasta(fa)
+        o.enumerate(rounds=rounds, abundance=abundance)
+        ref = str(tmp_path / "o.bin")
+        o.write_bin(ref)
+        out = str(tmp_path / "g.bin")
+        e = capi.Enumerator([fa], k, L, q=q, rounds=rounds, abundance=abundance, tmpdir=str(tmp_path), out=out, seed=seed)
+        assert open(out, "rb").read() == open(ref, "rb").read(), (trial, k, L, q, rounds, abundance)
+        assert e.vertices_count() == len(o.keys)
+        e.close()
+        o.close()

@@ -121,7 +121,7 @@ class PackedText:
         self._h = host().tpch_text_new()
 
     def close(self):
-        if self._h:
+        if self._h and host is not None:
             host().tpch_text_free(self._h)
             self._h = None
 
@@ -177,7 +177,7 @@ class Context:
             raise RuntimeError("tpc_ctx_create failed (%d): no HIP device -- there is no CPU fallback" % rc)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and hip is not None:
             hip().tpc_ctx_destroy(self._h)
             self._h = None
 

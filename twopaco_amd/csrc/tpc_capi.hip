@@ -141,6 +141,15 @@ int materialize_reset(tpc_ctx *c)
     return 0;
 }
 
+// Share of the vertices whose hash min(H, H') falls into [lo, hi]: the density of the minimum of two
+// uniform L-bit values is 2(1 - x), so the mass below x is 1 - (1 - x)^2.
+double range_mass(const tpc_ctx *c, uint64_t lo, uint64_t hi)
+{
+    const double size = (double)(c->P.lmask) + 1.0;
+    auto below = [size](double x) { x = std::min(1.0, std::max(0.0, x / size)); return 1.0 - (1.0 - x) * (1.0 - x); };
+    return std::min(1.0, std::max(0.0, below((double)hi + 1.0) - below((double)lo)));
+}
+
 bool ensure_pbuf(tpc_ctx *c, int i, size_t need)
 {
     if (need <= c->pbytes[i]) return true;
@@ -309,6 +318,8 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
     TpcPartPlan pl;
+    const double m_ins = gated ? range_mass(c, lo, hi) : 1.0;
+    const double ins_frac = gated ? std::min(1.0, (1.0 - (1.0 - m_ins) * (1.0 - m_ins)) * 1.15) : 1.0;  // either endpoint in range
     const uint64_t tiles = text_tiles512(c);
     uint64_t batches = 1;
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
@@ -316,7 +327,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         // as few batches of tiles as the buffer budget allows
         for (;; batches *= 2) {
             const uint64_t per = (tiles + batches - 1) / batches;
-            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, pl)) { part = false; break; }
+            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl)) { part = false; break; }
             if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
         }
     }
@@ -422,7 +433,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (part) {
         for (;; batches *= 2) {
             const uint64_t per = (tiles + batches - 1) / batches;
-            const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, pl);
+            const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl);
             if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) { part = false; break; }  // geometry unsupported (not a size problem)
             if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) { part = false; break; }

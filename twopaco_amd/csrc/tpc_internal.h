@@ -36,7 +36,7 @@ struct TpcPartPlan {
     uint64_t *ovf;
     unsigned long long *ovf_cur;  // [0] count, [1] overflow-of-overflow flag
 };
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, TpcPartPlan &pl);  // n_tiles: 512-word tiles per batch
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl);  // n_tiles: 512-word tiles per batch
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
@@ -63,7 +63,7 @@ struct TpcQPlan {
     uint64_t *surv;
     unsigned long long *surv_cur;  // [0..63] counts, [64] overflow flag
 };
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl);  // n_tiles: 512-word tiles per batch
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl);  // n_tiles: 512-word tiles per batch
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 

@@ -271,7 +271,7 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 
 // Partition geometry for a filter of 2^L bits: slices of 2^slice_bits bits, fan-out split over two
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, TpcPartPlan &pl)
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl)
 {
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
@@ -287,8 +287,10 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, TpcPartPlan &
     // positions per thread per round: keep a round's entries near a third of the bin storage
     const int cap = (PT_BIN_BYTES / 4) >> pl.b1;
     int budget = (1 << pl.b1) * (cap - 32) * 5 / 8;  // entries per round
-    int ppr = budget / (PT_THREADS * q);
-    pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
+    // frac: expected share of positions that emit (a gated round only inserts edges touching its
+    // vertex-hash range), so a round can cover more positions before the rings fill
+    int ppr = (int)(budget / (PT_THREADS * q * std::max(frac, 1.0 / 64)));
+    pl.pos_per_round = ppr >= 32 ? 32 : ppr >= 16 ? 16 : ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;

@@ -422,7 +422,7 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 
 }  // namespace
 
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl)
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl)
 {
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
@@ -438,8 +438,9 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, TpcQPlan &pl)
     pl.wpb = 4;
     const int cap = (PT_BIN_BYTES / 8) >> pl.b1;
     const int budget = std::max(1, (1 << pl.b1) * (cap - 16) * 5 / 8);  // entries per round
-    const int ppr = budget / (1024 * 6);  // k_q_hash runs 1024 threads x 16 positions
-    pl.pos_per_round = ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
+    // k_q_hash runs 1024 threads x 16 positions; frac = expected share of vertices inside the round's range
+    const int ppr = (int)(budget / (1024 * 6 * std::max(frac, 1.0 / 64)));
+    pl.pos_per_round = ppr >= 16 ? 16 : ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     pl.sub_rounds = ppr >= 1 ? 1 : std::min(16, (1024 * 6 + budget - 1) / budget);
     pl.loads = std::max(1, std::min(8, budget * 9 / 8 / PT_THREADS / 2));  // k_q_split entries per thread per round (level-2 bins see a 2x skew)
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
