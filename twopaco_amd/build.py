@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_dir():
-    return os.path.join(ROOT, "lib")
+    # TPC_LIB_DIR: load the native libraries from another directory (A/B comparisons of builds)
+    return os.environ.get("TPC_LIB_DIR") or os.path.join(ROOT, "lib")
 
 
 def build_all(verbose=False):

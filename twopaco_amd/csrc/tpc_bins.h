@@ -29,6 +29,32 @@ struct PtPerm {
     __host__ __device__ __forceinline__ uint32_t slice_of(uint32_t permuted) const { return (uint32_t)(((uint64_t)permuted * inv) & (((uint64_t)1 << F) - 1)); }
 };
 
+// Filter sharding over `world` ranks by level-1 bucket: rank r owns the buckets b1 with b1 % world == r
+// (balanced, because buckets are balanced by the permutation).  world == 1: the whole filter, natural layout.
+struct PtShard {
+    uint32_t rank, world;  // world is a power of two
+    __host__ __device__ __forceinline__ uint32_t log_world() const { return 31u - (uint32_t)__builtin_clz(world); }
+};
+
+// Level-1 region index of (workgroup w, bucket b1) in the buffer the hash kernels write: destination
+// major, so that the regions of the buckets owned by rank o form one contiguous block (block o of an
+// equal-split all_to_all).  After the exchange the block received from rank src sits at index src, i.e.
+// region (src, w) of local bucket bl = b1 / world is pt_r1_recv(...).
+__host__ __device__ __forceinline__ uint64_t pt_r1_send(PtShard sh, uint32_t nb1, uint32_t nwg1, uint32_t w, uint32_t b1)
+{
+    const uint32_t lw = sh.log_world();
+    return ((uint64_t)(b1 & (sh.world - 1)) * (nb1 >> lw) + (b1 >> lw)) * nwg1 + w;
+}
+__host__ __device__ __forceinline__ uint64_t pt_r1_recv(PtShard sh, uint32_t nb1, uint32_t nwg1, uint32_t src, uint32_t w, uint32_t bl)
+{
+    return ((uint64_t)src * (nb1 >> sh.log_world()) + bl) * nwg1 + w;
+}
+
+// Word-array position of a PERMUTED address in this rank's filter storage: the natural position when the
+// filter is whole (world == 1), else the compact shard [local bucket][b2][slice]; mine = false when the
+// address belongs to another rank.
+__host__ __device__ __forceinline__ uint64_t pt_local_addr(const struct PtPerm &perm, PtShard sh, int log_nb2, uint64_t a_perm, bool &mine);
+
 inline PtPerm pt_make_perm(int slice_bits, int F)
 {
     PtPerm p;
@@ -38,6 +64,17 @@ inline PtPerm pt_make_perm(int slice_bits, int F)
     for (int i = 0; i < 5; i++) x *= 2u - p.mult * x;
     p.inv = x;
     return p;
+}
+
+__host__ __device__ __forceinline__ uint64_t pt_local_addr(const PtPerm &perm, PtShard sh, int log_nb2, uint64_t a_perm, bool &mine)
+{
+    if (sh.world == 1) { mine = true; return perm.back(a_perm); }
+    const uint64_t smask = ((uint64_t)1 << perm.slice_bits) - 1;
+    const uint32_t sp = (uint32_t)(a_perm >> perm.slice_bits);
+    const uint32_t b1 = sp >> log_nb2;
+    mine = (b1 & (sh.world - 1)) == sh.rank;
+    const uint32_t ls = ((b1 >> sh.log_world()) << log_nb2) | (sp & ((1u << log_nb2) - 1u));
+    return ((uint64_t)ls << perm.slice_bits) | (a_perm & smask);
 }
 
 // exclusive scan over a THREADS-thread workgroup
@@ -174,9 +211,10 @@ struct Bins {
 #endif
     }
 
-    template <class Reg>
-    __device__ __forceinline__ void store_counts(uint32_t *out, Reg reg)
+    // idx(b): position of bin b's count in `out`
+    template <class Reg, class Idx>
+    __device__ __forceinline__ void store_counts(uint32_t *out, Reg reg, Idx idx)
     {
-        for (int b = threadIdx.x; b < NB; b += THREADS) out[b] = (uint32_t)min((uint64_t)head[b], reg((uint32_t)b).cap);
+        for (int b = threadIdx.x; b < NB; b += THREADS) out[idx((uint32_t)b)] = (uint32_t)min((uint64_t)head[b], reg((uint32_t)b).cap);
     }
 };

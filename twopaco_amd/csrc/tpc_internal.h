@@ -35,14 +35,22 @@ struct TpcPartPlan {
     uint32_t *buf1, *cnt1, *buf2, *cnt2;
     uint64_t *ovf;
     unsigned long long *ovf_cur;  // [0] count, [1] overflow-of-overflow flag
+    // filter sharding (tpc_bins.h:PtShard): this rank, number of ranks; the level-1 regions the split
+    // kernel reads (== buf1 / cnt1 when world == 1, the all_to_all receive buffers otherwise)
+    uint32_t rank = 0, world = 1;
+    const uint32_t *rbuf1 = nullptr, *rcnt1 = nullptr;
 };
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl);  // n_tiles: 512-word tiles per batch
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl);
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
                                   unsigned long long *n_kmers);
+// the two halves of the above, for the sharded path (an all_to_all of the level-1 regions sits between them)
+int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers);
+int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh);
 
 // partitioned query (tpc_qpartition.hip)
 struct TpcQPlan {
@@ -62,10 +70,18 @@ struct TpcQPlan {
     unsigned long long *ovf_cur;   // [0] count, [1] overflow flag
     uint64_t *surv;
     unsigned long long *surv_cur;  // [0..63] counts, [64] overflow flag
+    uint32_t rank = 0, world = 1;  // filter sharding, as in TpcPartPlan
+    const uint64_t *rbuf1 = nullptr;
+    const uint32_t *rcnt1 = nullptr;
 };
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl);  // n_tiles: 512-word tiles per batch
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl);
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
+// halves for the sharded path: hash (level 1, marks N-adjacent vertices in rmask), then split + lookup on
+// the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)
+int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
+int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl);
 
 // pass 2 / output (tpc_pass2.hip)
 // Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of

@@ -67,11 +67,11 @@ struct HashEmit {
     }
 };
 
-template <int Q, bool GATED>
+template <int Q, bool GATED, bool SHARDED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
             const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
-            uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, unsigned long long *n_kmers)
+            uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
@@ -87,8 +87,10 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
     const int shift = P.L - LOG_NB;
     HashEmit emit{&bins, &ovf, shift, (uint32_t)((1ull << shift) - 1ull), perm};
-    uint32_t *region = buf1 + (uint64_t)blockIdx.x * NB * cap1;
-    auto reg = [region, cap1](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap1, cap1}; };
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    // one rank: a workgroup's regions are contiguous ([w][b1]); sharded: destination-major (pt_r1_send)
+    auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
+    auto reg = [buf1, cap1, ridx](uint32_t b) { return PtRegion<uint32_t>{buf1 + ridx(b) * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
     const int xw = (P.k + 1) / 32 + 2;
     unsigned hashed = 0;
@@ -114,7 +116,7 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
         }
     }
     bins.flush(true, reg, lost);
-    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, reg);
+    bins.store_counts(cnt1, reg, ridx);
     if (n_kmers) {
         for (int off = 32; off > 0; off >>= 1) hashed += __shfl_down(hashed, off, 64);
         if ((tid & 63) == 0) s_w[tid >> 6] = hashed;
@@ -128,9 +130,10 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
 }
 
 // ------------------------------------------------------------------------------------------ level 2
+template <bool SHARDED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
-             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf)
+             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -138,7 +141,10 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     Bins<uint32_t> bins;
     bins.carve(smem, LOG_NB2);
     bins.init();
-    const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
+    const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
+    const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
+    const uint32_t nvw = SHARDED ? nwg1 * sh.world : nwg1;        // source regions: (source rank, workgroup)
+    auto r1 = [=](uint32_t vw) { return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl; };
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     const int shift1 = L - LOG_NB1;
     uint32_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
@@ -149,26 +155,26 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     // rounds of LOADS x PT_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
     // round's loads are issued before the current round is binned and flushed
     uint32_t w = j, base = 0;
-    uint32_t n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0;
-    while (w < nwg1 && n == 0) { w += wpb; n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0; }
+    uint32_t n = w < nvw ? cnt1[r1(w)] : 0;
+    while (w < nvw && n == 0) { w += wpb; n = w < nvw ? cnt1[r1(w)] : 0; }
     uint32_t v[LOADS], vn[LOADS];
     auto load = [&](uint32_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
-        const uint32_t *src = buf1 + ((uint64_t)ww * NB1 + b1) * cap1;
+        const uint32_t *src = buf1 + r1(ww) * cap1;
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
             const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
             dst[i] = idx < nn ? src[idx] : PT_SENT;
         }
     };
-    if (w < nwg1) load(v, w, base, n);
-    while (w < nwg1) {
+    if (w < nvw) load(v, w, base, n);
+    while (w < nvw) {
         // advance to the next round and prefetch it
         uint32_t w2 = w, base2 = base + LOADS * PT_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
-            do { w2 += wpb; n2 = w2 < nwg1 ? cnt1[(uint64_t)w2 * NB1 + b1] : 0; } while (w2 < nwg1 && n2 == 0);
+            do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
         }
-        if (w2 < nwg1) load(vn, w2, base2, n2);
+        if (w2 < nvw) load(vn, w2, base2, n2);
         {
             uint32_t bb[LOADS], val[LOADS];
             bool ok[LOADS];
@@ -182,21 +188,22 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         w = w2; base = base2; n = n2;
     }
     bins.flush(true, reg, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
 }
 
 // ------------------------------------------------------------------------------------------ level 3
 // One workgroup per 2^slice_bits-bit slice of the filter.
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-             uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm)
+             uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm, PtShard sh)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
     const uint32_t words = 1u << (slice_bits - 5);
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;  // blockIdx = permuted slice index
+    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);  // local bucket, sub-bucket
+    // whole filter: natural slice position of permuted slice blockIdx; shard: compact [local bucket][b2]
+    uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
     const bool wide = (words & 3u) == 0;  // 16-byte accesses whenever the slice allows
     if (fresh) {
         if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
@@ -228,13 +235,15 @@ k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------ level 4
-__global__ void k_part_ovf(const uint64_t *__restrict__ list, const unsigned long long *cursor, uint64_t cap, uint32_t *filter, PtPerm perm)
+__global__ void k_part_ovf(const uint64_t *__restrict__ list, const unsigned long long *cursor, uint64_t cap, uint32_t *filter, PtPerm perm,
+                           PtShard sh, int log_nb2)
 {
     const uint64_t n = min((uint64_t)cursor[0], cap);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t a = perm.back(list[i]);
-        atomicOr(&filter[a >> 5], 1u << ((uint32_t)a & 31u));
+        bool mine;
+        const uint64_t a = pt_local_addr(perm, sh, log_nb2, list[i], mine);  // entries of other ranks are routed by the host layer
+        if (mine) atomicOr(&filter[a >> 5], 1u << ((uint32_t)a & 31u));
     }
 }
 
@@ -243,16 +252,17 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtShard sh{pl.rank, pl.world};
     const size_t lds = Bins<uint32_t>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
-    if (gated) {
-        (void)hipFuncSetAttribute((const void *)k_part_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_part_hash<Q, true>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
-    } else {
-        (void)hipFuncSetAttribute((const void *)k_part_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_part_hash<Q, false>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, n_kmers);
-    }
+#define TPC_HASH_GO(G, S)                                                                                                                   \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_part_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((k_part_hash<Q, G, S>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers);            \
+    } while (0)
+    if (pl.world > 1) { if (gated) TPC_HASH_GO(true, true); else TPC_HASH_GO(false, true); }
+    else { if (gated) TPC_HASH_GO(true, false); else TPC_HASH_GO(false, false); }
+#undef TPC_HASH_GO
     return 0;
 }
 
@@ -260,10 +270,17 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const size_t lds = Bins<uint32_t>::lds_bytes(pl.b2);
-    const dim3 grid((unsigned)((1u << pl.b1) * pl.wpb));
-    (void)hipFuncSetAttribute((const void *)k_part_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_part_split, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1, pl.wpb, pl.buf1,
-                       pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf);
+    const PtShard sh{pl.rank, pl.world};
+    const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
+    if (pl.world > 1) {
+        (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1, pl.wpb, pl.rbuf1,
+                           pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh);
+        return 0;
+    }
+    (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1, pl.wpb, pl.rbuf1,
+                       pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh);
     return 0;
 }
 
@@ -273,6 +290,13 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl)
 {
+    return tpc_part_plan_sharded(L, q, slice_bits, n_tiles, frac, 0, 1, pl);
+}
+
+// n_tiles: the tiles THIS rank hashes; the level-2 regions are sized for the entries of all ranks
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl)
+{
+    pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
@@ -280,6 +304,7 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, 
     pl.b1 = (F + 1) / 2;
     pl.b2 = F / 2;
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;  // entries are remainders below the 0xFFFFFFFF sentinel
+    if (world == 0 || (world & (world - 1)) || world > (1u << pl.b1)) return false;  // ranks own whole buckets
     pl.n_tiles = n_tiles;
     pl.tile0 = 0;
     pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
@@ -294,7 +319,7 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, 
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
-    const double avg2 = a_max / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
+    const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
     const PtPerm pm = pt_make_perm(slice_bits, F);
@@ -304,30 +329,45 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, 
 
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 4; }
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * 4; }
-size_t tpc_part_buf2_bytes(const TpcPartPlan &pl) { return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 4; }
-size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl) { return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * 4; }
+size_t tpc_part_buf2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 4; }
+size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * 4; }
 
-int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
-                                  unsigned long long *n_kmers)
+int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
 {
-    int rc = -1;
     switch (a.P.q) {
-    case 1: rc = launch_hash_q<1>(a, pl, gated, lo, hi, n_kmers); break;
-    case 2: rc = launch_hash_q<2>(a, pl, gated, lo, hi, n_kmers); break;
-    case 3: rc = launch_hash_q<3>(a, pl, gated, lo, hi, n_kmers); break;
-    case 4: rc = launch_hash_q<4>(a, pl, gated, lo, hi, n_kmers); break;
-    case 5: rc = launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers); break;
-    case 6: rc = launch_hash_q<6>(a, pl, gated, lo, hi, n_kmers); break;
-    case 7: rc = launch_hash_q<7>(a, pl, gated, lo, hi, n_kmers); break;
-    case 8: rc = launch_hash_q<8>(a, pl, gated, lo, hi, n_kmers); break;
+    case 1: return launch_hash_q<1>(a, pl, gated, lo, hi, n_kmers);
+    case 2: return launch_hash_q<2>(a, pl, gated, lo, hi, n_kmers);
+    case 3: return launch_hash_q<3>(a, pl, gated, lo, hi, n_kmers);
+    case 4: return launch_hash_q<4>(a, pl, gated, lo, hi, n_kmers);
+    case 5: return launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers);
+    case 6: return launch_hash_q<6>(a, pl, gated, lo, hi, n_kmers);
+    case 7: return launch_hash_q<7>(a, pl, gated, lo, hi, n_kmers);
+    case 8: return launch_hash_q<8>(a, pl, gated, lo, hi, n_kmers);
     }
-    if (rc) return rc;
+    return -1;
+}
+
+int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh)
+{
+    int rc;
     if ((rc = launch_split(a, pl))) return rc;
     const size_t lds = (size_t)4 << (pl.slice_bits - 5);
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
     (void)hipFuncSetAttribute((const void *)k_part_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_part_apply, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, pl.buf2,
-                       pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm);
-    hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm);
+    const PtShard sh{pl.rank, pl.world};
+    hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                       pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+    hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2);
     return 0;
+}
+
+int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl0, uint64_t lo, uint64_t hi, bool gated, bool fresh,
+                                  unsigned long long *n_kmers)
+{
+    TpcPartPlan pl = pl0;
+    pl.rbuf1 = pl.buf1;  // one rank: the split kernel reads what the hash kernel wrote
+    pl.rcnt1 = pl.cnt1;
+    int rc = tpc_launch_insert_part_hash(a, pl, lo, hi, gated, n_kmers);
+    if (rc) return rc;
+    return tpc_launch_insert_part_apply(a, pl, fresh);
 }

@@ -73,11 +73,12 @@ __device__ bool q_tie_break(const TpcHashParams &P, const uint64_t *s_h, const u
 constexpr int QH_THREADS = 1024;  // two threads per packed word: 16 positions each
 constexpr int QH_RUN = 16;
 
-template <int Q, bool GATED>
+template <int Q, bool GATED, bool SHARDED>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, int sub_rounds,
-         uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, uint32_t *__restrict__ rmask)
+         uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
+         uint32_t *__restrict__ rmask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
@@ -91,8 +92,10 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     const int tid = threadIdx.x;
     if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
     const int shift = P.L - LOG_NB;
-    uint64_t *region = buf1 + (uint64_t)blockIdx.x * NB * cap1;
-    auto reg = [region, cap1](uint32_t b) { return PtRegion<uint64_t>{region + (uint64_t)b * cap1, cap1}; };
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    // one rank: a workgroup's regions are contiguous ([w][b1]); sharded: destination-major (pt_r1_send)
+    auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
+    auto reg = [buf1, cap1, ridx](uint32_t b) { return PtRegion<uint64_t>{buf1 + ridx(b) * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
     const int xw = (P.k + 1) / 32 + 2;
     uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
@@ -176,16 +179,18 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
         rmask16[(wfirst * 2) + tid] = (uint16_t)word;  // N-neighbour marks (16 positions per thread); k_q_verify ORs the rest
     }
     bins.flush(true, reg, lost);
-    bins.store_counts(cnt1 + (uint64_t)blockIdx.x * NB, reg);
+    bins.store_counts(cnt1, reg, ridx);
 #ifdef TPC_PROFILE_PHASES
     bins.dump(ovf.cursor + 16);
 #endif
 }
 
 // ------------------------------------------------------------------------------------------ B
+template <bool SHARDED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
-          const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf)
+          const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
+          PtShard sh)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -195,7 +200,10 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
     bins.init();
     for (uint32_t i = threadIdx.x; i <= NB2; i += PT_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
-    const uint32_t b1 = blockIdx.x / wpb, j = blockIdx.x % wpb;
+    const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
+    const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
+    const uint32_t nvw = SHARDED ? nwg1 * sh.world : nwg1;        // source regions: (source rank, workgroup)
+    auto r1 = [=](uint32_t vw) { return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl; };
     const int shift1 = L - LOG_NB1;
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
     // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
@@ -203,25 +211,25 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
     __syncthreads();
     uint32_t w = j, base = 0;
-    uint32_t n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0;
-    while (w < nwg1 && n == 0) { w += wpb; n = w < nwg1 ? cnt1[(uint64_t)w * NB1 + b1] : 0; }
+    uint32_t n = w < nvw ? cnt1[r1(w)] : 0;
+    while (w < nvw && n == 0) { w += wpb; n = w < nvw ? cnt1[r1(w)] : 0; }
     uint64_t v[LOADS], vn[LOADS];
     auto load = [&](uint64_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
-        const uint64_t *src = buf1 + ((uint64_t)ww * NB1 + b1) * cap1;
+        const uint64_t *src = buf1 + r1(ww) * cap1;
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
             const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
             dst[i] = (i < loads && idx < nn) ? src[idx] : SENT;
         }
     };
-    if (w < nwg1) load(v, w, base, n);
-    while (w < nwg1) {
+    if (w < nvw) load(v, w, base, n);
+    while (w < nvw) {
         uint32_t w2 = w, base2 = base + (uint32_t)loads * PT_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
-            do { w2 += wpb; n2 = w2 < nwg1 ? cnt1[(uint64_t)w2 * NB1 + b1] : 0; } while (w2 < nwg1 && n2 == 0);
+            do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
         }
-        if (w2 < nwg1) load(vn, w2, base2, n2);
+        if (w2 < nvw) load(vn, w2, base2, n2);
         {
             uint32_t bb[LOADS];
             bool ok[LOADS];
@@ -235,7 +243,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         w = w2; base = base2; n = n2;
     }
     bins.flush(true, reg, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
 #ifdef TPC_PROFILE_PHASES
     bins.dump(ovf.cursor + 8);
 #endif
@@ -247,7 +255,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 constexpr int QL_STAGE = 3072;
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
@@ -256,7 +264,8 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     uint32_t *s_ctl = reinterpret_cast<uint32_t *>(stage + QL_STAGE);  // [0] staged count, [2..3] flush base
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    const uint32_t *src_slice = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;  // blockIdx = permuted slice index
+    // whole filter: natural position of permuted slice blockIdx; shard: compact [local bucket][b2]
+    const uint32_t *src_slice = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
     if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
     else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
     if (threadIdx.x == 0) s_ctl[0] = 0;
@@ -319,13 +328,14 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 
 // Region-overflow entries: first probe straight from the filter; hits join sub-list 0.
 __global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long long *cursor, uint64_t cap, const uint32_t *__restrict__ filter,
-                        uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+                        uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh, int log_nb2)
 {
     const uint64_t n = min((uint64_t)cursor[0], cap);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t a = perm.back(list[2 * i]);
-        if ((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u) {
+        bool mine;
+        const uint64_t a = pt_local_addr(perm, sh, log_nb2, list[2 * i], mine);  // entries of other ranks are routed by the host layer
+        if (mine && ((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u)) {
             const unsigned long long o = atomicAdd(&surv_cur[0], 1ull);
             if (o < surv_cap) surv[o] = list[2 * i + 1]; else surv_cur[QS_LISTS] = 1ull;
         }
@@ -401,16 +411,17 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 {
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtShard sh{pl.rank, pl.world};
     const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
-    if (gated) {
-        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_q_hash<Q, true>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
-    } else {
-        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_q_hash<Q, false>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, rmask);
-    }
+#define TPC_QHASH_GO(G, S)                                                                                                                  \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        hipLaunchKernelGGL((k_q_hash<Q, G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, rmask); \
+    } while (0)
+    if (pl.world > 1) { if (gated) TPC_QHASH_GO(true, true); else TPC_QHASH_GO(false, true); }
+    else { if (gated) TPC_QHASH_GO(true, false); else TPC_QHASH_GO(false, false); }
+#undef TPC_QHASH_GO
 }
 
 template <int Q>
@@ -424,6 +435,14 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl)
 {
+    return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl);
+}
+
+// n_tiles: the tiles THIS rank hashes; the level-2 regions cover the slices this rank owns and are sized
+// for the entries of all ranks
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl)
+{
+    pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
@@ -432,6 +451,7 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPl
     pl.b1 = (F + 1) / 2;
     pl.b2 = F / 2;
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;
+    if (world == 0 || (world & (world - 1)) || world > (1u << pl.b1)) return false;  // ranks own whole buckets
     pl.n_tiles = n_tiles;
     pl.tile0 = 0;
     pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
@@ -452,14 +472,14 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPl
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
     // level-2 region sizes: a region is one filter slice, and every query address is a function-0 address
     // whose density over the slices falls linearly from 2x to 0 (tpc_bins.h)
-    const uint64_t nreg = (uint64_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2);
-    const double avg2 = a_max / (double)nreg;
+    const uint64_t nreg = (uint64_t)((1u << pl.b1) / world) * pl.wpb * (1u << pl.b2);  // local regions
+    const double avg2 = a_max * world / ((double)nreg * world);  // entries of all ranks over all regions
     const double S = (double)(1ull << F);
     pl.off2_host.resize(nreg + 1);
     uint64_t o = 0;
     for (uint64_t r = 0; r < nreg; r++) {
-        const uint32_t b1 = (uint32_t)(r / ((uint64_t)pl.wpb << pl.b2)), b2 = (uint32_t)(r & ((1u << pl.b2) - 1));
-        const uint32_t s = pm.slice_of((b1 << pl.b2) | b2);
+        const uint32_t bl = (uint32_t)(r / ((uint64_t)pl.wpb << pl.b2)), b2 = (uint32_t)(r & ((1u << pl.b2) - 1));
+        const uint32_t s = pm.slice_of(((bl * world + rank) << pl.b2) | b2);  // the filter slice behind this region
         const double d = avg2 * 2.0 * (1.0 - ((double)s + 0.5) / S) + avg2 * 0.02;
         pl.off2_host[r] = o;
         o += ((uint64_t)(d * 1.25 + 8 * std::sqrt(d) + 96) + 15) & ~15ull;
@@ -475,7 +495,7 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     case 0: return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 8;
     case 1: return (size_t)pl.nwg1 * (1u << pl.b1) * 4;
     case 2: return (size_t)pl.buf2_entries * 8;
-    case 3: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * 4;
+    case 3: return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * 4;
     case 4: return pl.ovf_cap * 16;
     case 5: return 32 * sizeof(unsigned long long);
     case 6: return (size_t)QS_LISTS * pl.surv_cap * 8;
@@ -485,12 +505,8 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     return 0;
 }
 
-// Launches A-D on the stream.  The caller zeroes ovf_cur / surv_cur first and reads both flags back
-// afterwards: surv_cur[QS_LISTS] != 0 or ovf_cur[1] != 0 means a list overflowed and the mask is
-// incomplete (re-run the direct kernel).
-int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
+int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
 {
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
     switch (a.P.q) {
     case 1: launch_qhash<1>(a, pl, gated, lo, hi, rmask); break;
     case 2: launch_qhash<2>(a, pl, gated, lo, hi, rmask); break;
@@ -502,21 +518,49 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
     case 8: launch_qhash<8>(a, pl, gated, lo, hi, rmask); break;
     default: return -1;
     }
+    return 0;
+}
+
+int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
+{
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtShard sh{pl.rank, pl.world};
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
         const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
-        (void)hipFuncSetAttribute((const void *)k_q_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_split, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.loads, pl.nwg1,
-                           pl.wpb, pl.buf1, pl.cnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf);
+        if (pl.world > 1) {
+            (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L,
+                               pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L,
+                               pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh);
+        }
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, pl.buf2,
-                           pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+        hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                           pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
     }
-    hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+    hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
+                       sh, pl.b2);
+    return 0;
+}
+
+// Launches A-D on the stream (one rank, whole filter).  The caller zeroes ovf_cur / surv_cur first and
+// reads both flags back afterwards: surv_cur[QS_LISTS] != 0 or ovf_cur[1] != 0 means a list overflowed and
+// the mask is incomplete (re-run the direct kernel).
+int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
+{
+    TpcQPlan pl = pl0;
+    pl.rbuf1 = pl.buf1;
+    pl.rcnt1 = pl.cnt1;
+    int rc = tpc_launch_query_part_hash(a, pl, rmask, lo, hi, gated);
+    if (rc) return rc;
+    if ((rc = tpc_launch_query_part_lookup(a, pl))) return rc;
     switch (a.P.q) {
     case 1: launch_qverify<1>(a, pl, rmask); break;
     case 2: launch_qverify<2>(a, pl, rmask); break;
