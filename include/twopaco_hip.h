@@ -50,7 +50,9 @@ enum {
     TPC_K_SORT = 6,         /* BifurcationStorage::Init sort, bifurcationstorage.h:65          */
     TPC_K_EMIT = 7,         /* EdgeConstructionWorker id lookup, VE.h:927-958                  */
     TPC_K_SPLIT = 8,        /* InitialFilterFillerWorker, VE.h:503-583                         */
-    TPC_K_COUNT = 9
+    TPC_K_SHARD_HASH = 9,   /* tpc_shard_hash: level 1 of a sharded pass                       */
+    TPC_K_SHARD_APPLY = 10, /* tpc_shard_apply: levels 2-3 of a sharded pass                   */
+    TPC_K_COUNT = 11
 };
 
 /* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:
@@ -129,8 +131,59 @@ int tpc_emit(tpc_ctx *ctx, uint64_t *n_marked, uint64_t *n_valid);
 /* Copy the emit lists to the host: g_host[n_marked], id_host[n_marked]. */
 int tpc_emit_fetch(tpc_ctx *ctx, uint64_t *g_host, int64_t *id_host);
 
+/* ---- address-sharded filter (multi-GPU) -------------------------------------------------
+ * The Bloom filter (ConcurrentBitVector bitVector, VE.h:257) is cut over `world` ranks (a power of
+ * two) by bit address: the partitioned passes route every address to the workgroup that owns its
+ * filter slice, and rank r owns the slices of the level-1 buckets b1 with b1 % world == r.  Every
+ * rank holds the whole packed text and hashes 1/world of its tiles; the level-1 regions are what
+ * travels (one equal-split all_to_all per pass and batch).  The library does no communication:
+ * the caller (twopaco_amd/dist.py over torch.distributed, or MPI/RCCL in a C++ host) moves the
+ * DEVICE buffers named below between the calls.  All ranks must make the same calls with the
+ * same lo/hi.  tpc_pass1_insert / tpc_pass1_query refuse to run on a sharded context.
+ *
+ *   tpc_shard_config   rank/world; reallocates the filter to the 2^L/world-bit shard
+ *   tpc_shard_plan     geometry of one pass (TPC_SHARD_INSERT / TPC_SHARD_QUERY), geom[16]:
+ *                        [0] batches  [1] tiles (of 16384 positions) per rank and batch
+ *                        [2] bytes of one destination block of the region buffer
+ *                        [3] bytes of one destination block of the count buffer
+ *                        [4] survivor capacity (entries)  [5] overflow capacity (entries)
+ *                        [6] bytes per overflow entry  [7] slice_bits  [8] b1  [9] b2
+ *                        [10] slice permutation multiplier  [11] its inverse
+ *                      send and receive buffers hold `world` blocks each
+ *   tpc_shard_hash     level 1 of the pass over this rank's tiles of `batch` into send_regions /
+ *                      send_counts (block d = entries for rank d); the query also marks the
+ *                      N-adjacent vertices of those tiles; *n_overflow = entries that did not fit
+ *                      a region (>= 2^63: the overflow list itself overflowed -> unsupported skew)
+ *   tpc_shard_overflow_get / _set   the overflow list of the pass (full addresses, any owner):
+ *                      ranks all-gather their lists and set the concatenation before _apply
+ *   tpc_shard_apply    levels 2-3 over the received blocks: insert ORs the owned slices; query
+ *                      tests the first probe of every received edge and keeps the hits as the
+ *                      survivor list (*n_survivors; ids relative to the batch)
+ *   tpc_shard_survivors       copy the survivor ids to a device buffer
+ *   tpc_shard_verify_addrs    for hash function fn: owner rank and shard-local bit address of
+ *                             every survivor id in sid_dev
+ *   tpc_shard_probe           answer probes against this rank's shard (hit_dev[i] = 0/1)
+ *   tpc_shard_mark            set the candidate mark of every id in sid_dev (all q probes hit)
+ *   tpc_mask_export / tpc_mask_merge   round mask to / OR of `count` masks from a device buffer:
+ *                             the union over ranks is the mask tpc_pass1_query would produce */
+#define TPC_SHARD_INSERT 0
+#define TPC_SHARD_QUERY 1
+int tpc_shard_config(tpc_ctx *ctx, uint32_t rank, uint32_t world);
+int tpc_shard_plan(tpc_ctx *ctx, int pass, uint64_t lo, uint64_t hi, uint64_t *geom);
+int tpc_shard_hash(tpc_ctx *ctx, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions_dev, void *send_counts_dev,
+                   uint64_t *n_overflow);
+int tpc_shard_overflow_get(tpc_ctx *ctx, int pass, void *dst_dev, uint64_t n);
+int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t n);
+int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
+int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
+int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
+int tpc_shard_probe(tpc_ctx *ctx, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev);
+int tpc_shard_mark(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n);
+int tpc_mask_export(tpc_ctx *ctx, uint32_t *dst_dev);
+int tpc_mask_merge(tpc_ctx *ctx, const uint32_t *src_dev, uint32_t count);
+
 /* ---- parity taps (debug; used by tests/) ---------------------------------------------- */
-uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 */
+uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 (sharded: 2^L/32/world) */
 int tpc_filter_download(tpc_ctx *ctx, uint32_t *words_host); /* tpc_filter_words words       */
 uint64_t tpc_mask_words(const tpc_ctx *ctx);                 /* n_text/32 + 1                 */
 int tpc_mask_download(tpc_ctx *ctx, int run_wide, uint32_t *words_host);

@@ -69,3 +69,49 @@ def worker(rank, world, port, case, files, use_gpu, result_path):
             pickle.dump(gathered, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def addr_worker(rank, world, port, spec, result_path):
+    """Address-sharded filter: `world` ranks (gloo rendezvous, every context on GPU 0).  Each rank
+    reports its filter shard after the insert, the merged candidate mask after the query and the
+    final (position, id) list; the test reassembles the shards and compares with the oracle."""
+    import pickle
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from twopaco_amd import capi, synth
+    from twopaco_amd import dist as tdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    if spec.get("files"):
+        text = capi.PackedText.from_fasta(spec["files"])
+    else:
+        recs, _ = synth.workload(spec["workload"], scale=spec["scale"])
+        text = capi.PackedText.from_codes(recs)
+    ctx = capi.Context(0)
+    for opt, val in spec.get("options", {}).items():
+        ctx.set_option(opt, val)
+    ctx.set_params(spec["k"], spec["L"], spec["q"], capi.seed_table(spec["q"], spec["L"], seed=spec["seed"]))
+    ctx.seq_upload(text)
+    sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0))
+    out = {"rounds": []}
+    for lo, hi in spec["ranges"]:
+        geom = sh.insert(lo, hi)
+        shard = ctx.filter_download()
+        qgeom = sh.query(lo, hi)
+        out["rounds"].append({"geom": geom, "qgeom": qgeom, "shard": shard, "mask": ctx.mask_download(False),
+                              "survivors": sh.stats["survivors"]})
+    st = tdist.address_sharded_step(sh, spec["abundance"], fetch=True)
+    out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], moved=sh.comm.bytes_moved)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        with open(result_path, "wb") as f:
+            pickle.dump(gathered, f)
+    dist.barrier()
+    dist.destroy_process_group()

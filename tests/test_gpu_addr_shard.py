@@ -1,0 +1,97 @@
+"""GPU (-m gpu): the address-sharded filter (include/twopaco_hip.h tpc_shard_*, twopaco_amd/dist.py
+AddressSharded) on 2 and 4 ranks sharing GPU 0 over a gloo rendezvous.  Checked against the oracle:
+the shards reassemble into the oracle's Bloom filter bit for bit, every rank ends the query with the
+oracle's candidate mask, and the final (position, id) list is the single-process one."""
+import pickle
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from helpers import case_files, golden_cases
+from oracle import oracle as O
+from test_dist_cpu import free_port
+
+pytestmark = pytest.mark.gpu
+CASES = {c["name"]: c for c in golden_cases()}
+
+
+def assemble(shards, geom, L, world):
+    """Filter words of the whole filter from the per-rank shards: shard layout is [local bucket][b2][slice],
+    rank r owns the level-1 buckets b1 = bl * world + r of the PERMUTED slice index."""
+    sb, b1, b2 = geom["slice_bits"], geom["b1"], geom["b2"]
+    F = b1 + b2
+    words = 1 << (sb - 5)
+    full = np.zeros(((1 << L) >> 5) + 1, dtype=np.uint32)
+    for r in range(world):
+        sh = shards[r][:-1].reshape(-1, words)
+        assert sh.shape[0] == (1 << F) // world
+        ls = np.arange(sh.shape[0], dtype=np.uint64)
+        permuted = (((ls >> np.uint64(b2)) * np.uint64(world) + np.uint64(r)) << np.uint64(b2)) | (ls & np.uint64((1 << b2) - 1))
+        s = (permuted * np.uint64(geom["perm_inv"])) & np.uint64((1 << F) - 1)
+        full[:-1].reshape(-1, words)[s.astype(np.int64)] = sh
+    return full
+
+
+def run(spec, world, tmp_path):
+    from dist_worker import addr_worker
+    res = str(tmp_path / "res.pkl")
+    mp.spawn(addr_worker, args=(world, free_port(), spec, res), nprocs=world, join=True)
+    with open(res, "rb") as f:
+        return pickle.load(f)
+
+
+def check(spec, o, gathered, world):
+    for i, (lo, hi) in enumerate(spec["ranges"]):
+        o.fill_only(lo, hi)
+        marks = o.check_only(lo, hi)
+        rounds = [g["rounds"][i] for g in gathered]
+        full = assemble([r["shard"] for r in rounds], rounds[0]["geom"], spec["L"], world)
+        assert (full == o.filter).all(), (lo, hi)
+        for r in rounds:
+            assert (r["mask"] == o.round_mask).all()
+            assert int(np.unpackbits(r["mask"].view(np.uint8)).sum()) == marks
+    o.enumerate(rounds=1, abundance=spec["abundance"])
+    seq, pos, ids = o.records
+    for g in gathered:  # every rank holds the complete result
+        assert g["junctions"] == len(o.keys)
+        keep = g["ids"] != (1 << 63) - 1
+        got = sorted(zip(g["g"][keep].tolist(), g["ids"][keep].tolist()))
+        start = np.asarray(o.rec_start, dtype=np.int64)
+        want = sorted((int(start[s] + p), int(i)) for s, p, i in zip(seq.tolist(), pos.tolist(), ids.tolist()) if abs(i) <= len(o.keys))
+        assert got == want
+
+
+@pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("rand6_k9_fp", 8, 4), ("rand6_k9_q8", 9, 2), ("rand6_k9_q1", 12, 2),
+                                                   ("rand6_k25_q3", 12, 4), ("c2_k51_r2", 16, 2), ("edge_k5", 7, 2), ("rand6_k9_a3", 8, 2),
+                                                   ("c2_k125", 14, 4)])
+def test_address_sharded_golden_cases(name, slice_bits, world, tmp_path):
+    case = CASES[name]
+    files = case_files(case, tmp_path)
+    ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+    spec = {"files": files, "k": case["k"], "L": case["L"], "q": case["q"], "seed": case["seed"], "ranges": ranges,
+            "abundance": case["abundance"] if case["abundance"] is not None else (1 << 64) - 1, "options": {"slice_bits": slice_bits}}
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in files:
+        o.add_fasta(f)
+    check(spec, o, run(spec, world, tmp_path), world)
+
+
+@pytest.mark.parametrize("world,budget", [(2, 40 << 30), (4, 3 << 20)])
+def test_address_sharded_synthetic_batches(world, budget, tmp_path):
+    """8 x 50 kbp genomes, default slice size; the small budget cuts each pass into several batches."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.01)
+    spec = {"workload": "m1", "scale": 0.01, "k": 25, "L": 26, "q": 5, "seed": 11, "ranges": [(0, 1 << 26)], "abundance": (1 << 64) - 1,
+            "options": {"slice_bits": 14, "part_min_tiles": 1, "part_budget_bytes": budget}}
+    o = O.Oracle(25, 26, 5, O.seed_table(11, 5, 26))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    gathered = run(spec, world, tmp_path)
+    if budget < (1 << 30):
+        assert gathered[0]["rounds"][0]["geom"]["batches"] > 1 and gathered[0]["rounds"][0]["qgeom"]["batches"] > 1
+    # the survivor lists shrink from one hash function to the next
+    tr = gathered[0]["rounds"][0]["survivors"][0]
+    assert len(tr) == 5 and tr[-1] <= tr[0]
+    check(spec, o, gathered, world)

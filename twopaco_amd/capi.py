@@ -9,14 +9,17 @@ import numpy as np
 from .build import lib_dir
 
 INVALID_VERTEX = (1 << 63) - 1
-KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8}
+KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8,
+           "shard_hash": 9, "shard_apply": 10}
 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
                "tpc_run_begin", "tpc_filter_reset", "tpc_pass1_insert", "tpc_pass1_split_hist", "tpc_pass1_query", "tpc_pass2_filter",
                "tpc_junctions_finalize", "tpc_key_words", "tpc_junction_keys", "tpc_junction_keys_raw", "tpc_junction_keys_set", "tpc_get_id", "tpc_emit",
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
-               "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option"]
+               "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
+               "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
+               "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge"]
 
 _hip = None
 _host = None
@@ -65,6 +68,19 @@ def hip():
         L.tpc_kernel_ms.restype = ctypes.c_double
         L.tpc_kernel_ms.argtypes = [p, ci]
         L.tpc_set_option.argtypes = [p, ctypes.c_char_p, i64]
+        u32 = ctypes.c_uint32
+        L.tpc_shard_config.argtypes = [p, u32, u32]
+        L.tpc_shard_plan.argtypes = [p, ci, u64, u64, p]
+        L.tpc_shard_hash.argtypes = [p, ci, u64, u64, u64, p, p, p]
+        L.tpc_shard_overflow_get.argtypes = [p, ci, p, u64]
+        L.tpc_shard_overflow_set.argtypes = [p, ci, p, u64]
+        L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]
+        L.tpc_shard_survivors.argtypes = [p, p]
+        L.tpc_shard_verify_addrs.argtypes = [p, ci, p, u64, p, p]
+        L.tpc_shard_probe.argtypes = [p, p, u64, p]
+        L.tpc_shard_mark.argtypes = [p, p, u64]
+        L.tpc_mask_export.argtypes = [p, p]
+        L.tpc_mask_merge.argtypes = [p, p, u32]
         _hip = L
     return _hip
 
@@ -285,6 +301,54 @@ class Context:
 
     def kernel_ms(self, name):
         return hip().tpc_kernel_ms(self._h, KERNELS[name])
+
+    # ---- address-sharded filter: device pointers in, no communication here (see twopaco_amd/dist.py)
+    def shard_config(self, rank, world):
+        self._ck(hip().tpc_shard_config(self._h, rank, world))
+
+    def shard_plan(self, which, lo=0, hi=None):
+        g = np.zeros(16, dtype=np.uint64)
+        self._ck(hip().tpc_shard_plan(self._h, which, lo, (1 << self.L) if hi is None else hi, g.ctypes.data))
+        names = ["batches", "tiles_per_rank", "region_block_bytes", "count_block_bytes", "survivor_cap", "overflow_cap", "overflow_entry_bytes",
+                 "slice_bits", "b1", "b2", "perm_mult", "perm_inv"]
+        return {n: int(g[i]) for i, n in enumerate(names)}
+
+    def shard_hash(self, which, batch, send_regions_ptr, send_counts_ptr, lo=0, hi=None):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_hash(self._h, which, batch, lo, (1 << self.L) if hi is None else hi, send_regions_ptr, send_counts_ptr, ctypes.byref(n)))
+        return n.value
+
+    def shard_overflow_get(self, which, dst_ptr, n):
+        self._ck(hip().tpc_shard_overflow_get(self._h, which, dst_ptr, n))
+
+    def shard_overflow_set(self, which, src_ptr, n):
+        self._ck(hip().tpc_shard_overflow_set(self._h, which, src_ptr, n))
+
+    def shard_apply(self, which, batch, recv_regions_ptr, recv_counts_ptr):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_apply(self._h, which, batch, recv_regions_ptr, recv_counts_ptr, ctypes.byref(n)))
+        return n.value
+
+    def shard_survivors(self, sid_ptr):
+        self._ck(hip().tpc_shard_survivors(self._h, sid_ptr))
+
+    def shard_verify_addrs(self, fn, sid_ptr, n, addr_ptr, owner_ptr):
+        self._ck(hip().tpc_shard_verify_addrs(self._h, fn, sid_ptr, n, addr_ptr, owner_ptr))
+
+    def shard_probe(self, addr_ptr, n, hit_ptr):
+        self._ck(hip().tpc_shard_probe(self._h, addr_ptr, n, hit_ptr))
+
+    def shard_mark(self, sid_ptr, n):
+        self._ck(hip().tpc_shard_mark(self._h, sid_ptr, n))
+
+    def mask_export(self, dst_ptr):
+        self._ck(hip().tpc_mask_export(self._h, dst_ptr))
+
+    def mask_merge(self, src_ptr, count):
+        self._ck(hip().tpc_mask_merge(self._h, src_ptr, count))
+
+    def mask_words(self):
+        return int(hip().tpc_mask_words(self._h))
 
 
 class Enumerator:

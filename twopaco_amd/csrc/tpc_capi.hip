@@ -64,6 +64,13 @@ struct tpc_ctx {
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = (int64_t)40 << 30;  // bytes of partition buffers per batch (first ~48 GiB of hipMalloc are cheap)
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
+    // address-sharded filter (tpc_shard_*)
+    uint32_t sh_rank = 0, sh_world = 1;
+    TpcPartPlan sh_ipl;
+    TpcQPlan sh_qpl;
+    bool sh_have[2] = {false, false};
+    uint64_t sh_per[2] = {0, 0}, sh_batches[2] = {0, 0};
+    uint64_t sh_nsurv = 0;
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
@@ -161,6 +168,11 @@ bool ensure_pbuf(tpc_ctx *c, int i, size_t need)
     return true;
 }
 
+uint64_t filter_words_for(int L, uint32_t world)
+{   // concurrentbitvector.cpp:12; a shard holds 2^L/world bits
+    return std::max<uint64_t>(1, ((1ull << L) >> 5) / world) + 1;
+}
+
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
 int compact_mask(tpc_ctx *c, const uint32_t *m)
@@ -249,7 +261,8 @@ int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
             c->tab_host[TPC_TAB_HK + i * 5 + ch] = rotln_host(h, L, c->P.rk);
         }
     HIPCHK(c, hipMemcpy(c->tab, c->tab_host, sizeof c->tab_host, hipMemcpyHostToDevice));
-    const uint64_t fw = ((1ull << L) >> 5) + 1;  // concurrentbitvector.cpp:12
+    const uint64_t fw = filter_words_for(L, c->sh_world);
+    c->sh_have[0] = c->sh_have[1] = false;
     if (fw != c->filter_words) {
         if (c->filter) (void)hipFree(c->filter);
         c->filter = nullptr;
@@ -314,6 +327,7 @@ int tpc_filter_reset(tpc_ctx *c)
 int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
@@ -384,6 +398,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
 int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint32_t *bins_host)
 {
     if (!c || !c->have_params || !c->bases || !bins_host) return fail(c, -1, "bad arguments");
+    if (c->sh_world > 1) return fail(c, -1, "the split pass needs the whole filter as scratch: not available on a sharded context");
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t BINS = 1ull << 24;  // VE.h:471
     c->filter_zero_pending = false;  // the split pass zeroes its scratch filter itself
@@ -422,6 +437,7 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
 int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     { int rc0 = materialize_reset(c); if (rc0) return rc0; }
@@ -457,6 +473,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             const uint64_t per = pl.n_tiles;
             for (uint64_t t0 = 0; t0 < tiles && !overflowed; t0 += per) {
                 pl.tile0 = t0;
+                pl.tile0_global = t0;
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
                 HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
@@ -708,6 +725,252 @@ int tpc_emit_fetch(tpc_ctx *c, uint64_t *g_host, int64_t *id_host)
         HIPCHK(c, hipMemcpy(g_host, c->marks, c->n_emit * sizeof(uint64_t), hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(id_host, c->emit_id, c->n_emit * sizeof(int64_t), hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ address-sharded filter
+int tpc_shard_config(tpc_ctx *c, uint32_t rank, uint32_t world)
+{
+    if (!c) return -1;
+    if (world == 0 || (world & (world - 1)) || rank >= world) return fail(c, -1, "world must be a power of two and rank < world");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->sh_rank = rank; c->sh_world = world;
+    c->sh_have[0] = c->sh_have[1] = false;
+    if (c->have_params) {
+        const uint64_t fw = filter_words_for(c->P.L, world);
+        if (fw != c->filter_words) {
+            if (c->filter) (void)hipFree(c->filter);
+            c->filter = nullptr; c->filter_words = 0;
+            HIPCHK(c, hipMalloc((void **)&c->filter, fw * sizeof(uint32_t)));
+            c->filter_words = fw;
+        }
+        c->filter_zero_pending = true;
+    }
+    return 0;
+}
+
+int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geom)
+{
+    if (!c || !c->have_params || !c->bases || !geom) return fail(c, -1, "set_params and seq_upload first");
+    if (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) return fail(c, -1, "bad pass");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    const uint64_t W = c->sh_world, tiles = text_tiles512(c);
+    const uint64_t per_total = (tiles + W - 1) / W;
+    const double m = gated ? range_mass(c, lo, hi) : 1.0;
+    uint64_t per = per_total;
+    if (pass == TPC_SHARD_INSERT) {
+        const double frac = gated ? std::min(1.0, (1.0 - (1.0 - m) * (1.0 - m)) * 1.15) : 1.0;
+        TpcPartPlan &pl = c->sh_ipl;
+        for (uint64_t batches = 1;; batches *= 2) {
+            per = (per_total + batches - 1) / batches;
+            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl))
+                return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
+            if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+        }
+        const size_t need[6] = { 0, 0, tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl), pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
+        for (int i = 2; i < 6; i++) if (!ensure_pbuf(c, i, need[i])) return fail(c, -10, "out of device memory for the partition buffers");
+        pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        geom[2] = tpc_part_buf1_bytes(pl) / W; geom[3] = tpc_part_cnt1_bytes(pl) / W;
+        geom[4] = 0; geom[5] = pl.ovf_cap; geom[6] = 8;
+        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv;
+    } else {
+        TpcQPlan &pl = c->sh_qpl;
+        for (uint64_t batches = 1;; batches *= 2) {
+            per = (per_total + batches - 1) / batches;
+            const bool fits = per * W * (uint64_t)(512 * TPC_RUN) <= (1ull << 30);  // survivor ids hold a 30-bit position relative to the batch
+            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl);
+            if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
+            if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
+            if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");
+        }
+        for (int i = 2; i < 9; i++) if (!ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");
+        pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        pl.surv = (uint64_t *)c->pbuf[6]; pl.surv_cur = (unsigned long long *)c->pbuf[7]; pl.off2 = (const uint64_t *)c->pbuf[8];
+        if (c->off2_uploaded != pl.off2_host) {
+            HIPCHK(c, hipMemcpy(c->pbuf[8], pl.off2_host.data(), pl.off2_host.size() * 8, hipMemcpyHostToDevice));
+            c->off2_uploaded = pl.off2_host;
+        }
+        geom[2] = tpc_qpart_bytes(pl, 0) / W; geom[3] = tpc_qpart_bytes(pl, 1) / W;
+        geom[4] = 64 * pl.surv_cap; geom[5] = pl.ovf_cap; geom[6] = 16;
+        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv;
+    }
+    c->sh_per[pass] = per;
+    c->sh_batches[pass] = (tiles + W * per - 1) / (W * per);
+    c->sh_have[pass] = true;
+    c->sh_have[1 - pass] = false;  // the two passes share the partition buffers
+    geom[0] = c->sh_batches[pass]; geom[1] = per;
+    for (int i = 12; i < 16; i++) geom[i] = 0;
+    return 0;
+}
+
+int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions, void *send_counts, uint64_t *n_overflow)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
+    if (!send_regions || !send_counts || batch >= c->sh_batches[pass]) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
+    const uint64_t t_batch = batch * W * per, t0 = t_batch + c->sh_rank * per;
+    const uint64_t n = t0 < tiles ? std::min<uint64_t>(per, tiles - t0) : 0;
+    unsigned long long ov[2] = {0, 0};
+    if (pass == TPC_SHARD_INSERT) {
+        TpcPartPlan pl = c->sh_ipl;
+        pl.tile0 = t0; pl.n_tiles = n;
+        pl.buf1 = (uint32_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
+        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
+        {
+            Timed t(c, TPC_K_SHARD_HASH);
+            if (tpc_launch_insert_part_hash(make_launch(c), pl, lo, hi, gated, nullptr)) return fail(c, -1, "hash launch failed");
+        }
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        TpcQPlan pl = c->sh_qpl;
+        pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t_batch;
+        pl.buf1 = (uint64_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
+        { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+        // marks of this batch's survivors land anywhere in the batch, the hash kernel only rewrites this rank's tiles
+        if (batch == 0) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));
+        c->marks_valid = false;
+        {
+            Timed t(c, TPC_K_SHARD_HASH);
+            if (tpc_launch_query_part_hash(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "hash launch failed");
+        }
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's collective runs on another stream
+    if (n_overflow) *n_overflow = ov[1] ? (1ull << 63) : (uint64_t)ov[0];
+    return 0;
+}
+
+int tpc_shard_overflow_get(tpc_ctx *c, int pass, void *dst, uint64_t n)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass] || (!dst && n)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t cap = pass == TPC_SHARD_INSERT ? c->sh_ipl.ovf_cap : c->sh_qpl.ovf_cap;
+    if (n > cap) return fail(c, -1, "overflow list holds at most %llu entries", (unsigned long long)cap);
+    if (n) HIPCHK(c, hipMemcpy(dst, c->pbuf[4], n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+int tpc_shard_overflow_set(tpc_ctx *c, int pass, const void *src, uint64_t n)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass] || (!src && n)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t cap = pass == TPC_SHARD_INSERT ? c->sh_ipl.ovf_cap : c->sh_qpl.ovf_cap;
+    if (n > cap) return fail(c, -1, "gathered overflow lists (%llu entries) exceed the capacity %llu: skew beyond what the sharded path handles",
+                             (unsigned long long)n, (unsigned long long)cap);
+    if (n) HIPCHK(c, hipMemcpy(c->pbuf[4], src, n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));
+    const unsigned long long cur[2] = {n, 0};
+    HIPCHK(c, hipMemcpy(c->pbuf[5], cur, sizeof cur, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, uint64_t *n_survivors)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
+    if (!recv_regions || !recv_counts || batch >= c->sh_batches[pass]) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long ov[2] = {0, 0};
+    if (pass == TPC_SHARD_INSERT) {
+        TpcPartPlan pl = c->sh_ipl;
+        pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts;
+        {
+            Timed t(c, TPC_K_SHARD_APPLY);
+            if (tpc_launch_insert_part_apply(make_launch(c), pl, c->filter_zero_pending)) return fail(c, -1, "apply launch failed");
+        }
+        c->filter_zero_pending = false;  // every owned slice has been written
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ov[1]) return fail(c, -20, "overflow list overflowed (address skew beyond what the sharded path handles)");
+        if (n_survivors) *n_survivors = 0;
+        return 0;
+    }
+    TpcQPlan pl = c->sh_qpl;
+    pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts;
+    const uint64_t W = c->sh_world, per = c->sh_per[pass];
+    pl.tile0_global = batch * W * per;
+    c->sh_qpl.tile0_global = pl.tile0_global;  // survivor ids handed out below are relative to this batch
+    unsigned long long cur[65];
+    {
+        Timed t(c, TPC_K_SHARD_APPLY);
+        if (tpc_launch_query_part_lookup(make_launch(c), pl)) return fail(c, -1, "lookup launch failed");
+    }
+    HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cur, pl.surv_cur, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ov[1] || cur[64]) return fail(c, -20, "overflow or survivor list overflowed (address skew beyond what the sharded path handles)");
+    uint64_t ns = 0;
+    for (int i = 0; i < 64; i++) ns += std::min<uint64_t>(cur[i], pl.surv_cap);
+    c->sh_nsurv = ns;
+    if (n_survivors) *n_survivors = ns;
+    return 0;
+}
+
+int tpc_shard_survivors(tpc_ctx *c, uint64_t *sid_dev)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || (!sid_dev && c->sh_nsurv)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->sh_nsurv) tpc_launch_surv_gather(make_launch(c), c->sh_qpl, sid_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_verify_addrs(tpc_ctx *c, int fn, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || (n && (!sid_dev || !addr_dev || !owner_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (tpc_launch_verify_addrs(make_launch(c), c->sh_qpl, fn, sid_dev, n, addr_dev, owner_dev)) return fail(c, -1, "bad hash function index %d", fn);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_probe(tpc_ctx *c, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev)
+{
+    if (!c || !c->filter || (n && (!addr_dev || !hit_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    tpc_launch_shard_probe(make_launch(c), addr_dev, n, hit_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_mark(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || (n && !sid_dev)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    tpc_launch_shard_mark(make_launch(c), c->sh_qpl, sid_dev, n, c->rmask);
+    c->marks_valid = false;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_mask_export(tpc_ctx *c, uint32_t *dst_dev)
+{
+    if (!c || !c->rmask || !dst_dev) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst_dev, c->rmask, c->n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_mask_merge(tpc_ctx *c, const uint32_t *src_dev, uint32_t count)
+{
+    if (!c || !c->rmask || (!src_dev && count)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++) tpc_launch_mask_or(c->stream, c->rmask, src_dev + (uint64_t)i * c->n_words, c->n_words);
+    c->marks_valid = false;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -57,6 +57,7 @@ struct TpcQPlan {
     int slice_bits, b1, b2, pos_per_round, sub_rounds, loads;
     uint32_t perm_mult, perm_inv;
     uint64_t tile0, n_tiles;
+    uint64_t tile0_global = 0;  // first tile of the batch (positions in entries are relative to it; == tile0 unless sharded)
     uint32_t nwg1, wpb;
     uint64_t cap1;         // entries (uint64) per level-1 region, multiple of 16
     std::vector<uint64_t> off2_host;  // level-2 region offsets (entries), one per (b1, j, b2) + end
@@ -82,6 +83,11 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
 // the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl);
+// sharded verification of first-probe survivors (survivor id = edge | position << 3, batch relative)
+int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out);  // 64 sub-lists -> one list (sum of min(surv_cur, surv_cap) entries)
+int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out);
+int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n, uint8_t *hit);
+int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask);
 
 // pass 2 / output (tpc_pass2.hip)
 // Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, int sub_rounds,
          uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
-         uint32_t *__restrict__ rmask)
+         uint64_t gbase, uint32_t *__restrict__ rmask)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
@@ -136,7 +136,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                         if (c_prev == TPC_CODE_N || c_next == TPC_CODE_N) {
                             word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
                         } else {
-                            const uint64_t sid_g = (g - tile0 * (uint64_t)(PT_THREADS * TPC_RUN)) << 3;  // position relative to the batch
+                            const uint64_t sid_g = (g - gbase) << 3;  // position relative to the batch
                             uint32_t eb[8];
                             uint64_t ev[8];
                             bool eok[8];
@@ -406,6 +406,94 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------------ sharded verification
+// With the filter sharded by bit address the q-1 remaining probes of a survivor live on other ranks:
+// k_v_addrs gives, for hash function fn, the (owner rank, address inside the owner's shard) of every
+// survivor's edge; the host layer exchanges them, k_v_probe answers on the owner, the survivors that miss
+// are dropped, and after function q-1 k_v_mark sets the marks.  Each probe rejects all but a fill-rate
+// share of the false survivors, so the exchanged volume falls geometrically from one function to the next.
+template <int Q>
+__global__ void __launch_bounds__(256)
+k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ sid_list, uint64_t n,
+          uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
+{
+    __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
+    if (threadIdx.x < Q * 5) { s_h[threadIdx.x] = tab[threadIdx.x]; s_hk[threadIdx.x] = tab[TPC_TAB_HK + threadIdx.x]; }
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const uint64_t sid = sid_list[idx];
+        const int e = (int)(sid & 7);
+        const uint64_t g = gbase + (sid >> 3);
+        uint64_t pos[Q], neg[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
+        for (int t0 = 0; t0 < P.k; t0 += 32) {
+            uint64_t w = tpc_text_word(bases, g + t0);
+            const int m = min(32, P.k - t0);
+            for (int t = 0; t < m; t++) {
+                const int c = (int)(w & 3);
+                w >>= 2;
+#pragma unroll
+                for (int i = 0; i < Q; i++) pos[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+            }
+        }
+        for (int t1 = P.k; t1 > 0; t1 -= 32) {
+            const int m = min(32, t1);
+            const uint64_t w = tpc_text_word(bases, g + t1 - m);
+            for (int t = m - 1; t >= 0; t--) {
+                const int c = 3 - (int)((w >> (2 * t)) & 3);
+#pragma unroll
+                for (int i = 0; i < Q; i++) neg[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+            }
+        }
+        const int c = e & 3;
+        uint64_t p[Q], nn[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            if (e < 4) { p[i] = s_hk[i * 5 + c] ^ pos[i]; nn[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c]; }
+            else { p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c]; nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c]; }
+        }
+        const bool ng = tpc_pick_neg<Q>(p, nn);
+        uint64_t a = 0;
+#pragma unroll
+        for (int i = 0; i < Q; i++) if (i == fn) a = ng ? nn[i] : p[i];
+        const uint64_t ap = perm.fwd(a);
+        bool mine;
+        addr_out[idx] = pt_local_addr(perm, sh, log_nb2, ap, mine);
+        owner_out[idx] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+    }
+}
+
+// the 64 survivor sub-lists as one contiguous list
+__global__ void k_surv_gather(const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t *__restrict__ out)
+{
+    const int list = blockIdx.y;
+    uint64_t off = 0;
+    for (int i = 0; i < list; i++) off += min((uint64_t)surv_cur[i], surv_cap);
+    const uint64_t n = min((uint64_t)surv_cur[list], surv_cap);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[off + i] = surv[(uint64_t)list * surv_cap + i];
+}
+
+__global__ void k_v_probe(const uint32_t *__restrict__ filter, const uint64_t *__restrict__ addr, uint64_t n, uint8_t *__restrict__ hit)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t a = addr[i];
+        hit[i] = (uint8_t)((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u);
+    }
+}
+
+__global__ void k_v_mark(const uint64_t *__restrict__ sid_list, uint64_t n, uint64_t gbase, uint32_t *rmask)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t g = gbase + (sid_list[i] >> 3);
+        atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
+    }
+}
+
 template <int Q>
 void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
 {
@@ -417,7 +505,8 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_q_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         hipLaunchKernelGGL((k_q_hash<Q, G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, rmask); \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,              \
+                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
     } while (0)
     if (pl.world > 1) { if (gated) TPC_QHASH_GO(true, true); else TPC_QHASH_GO(false, true); }
     else { if (gated) TPC_QHASH_GO(true, false); else TPC_QHASH_GO(false, false); }
@@ -428,7 +517,7 @@ template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
     hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
-                       pl.tile0 * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+                       pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
 }
 
 }  // namespace
@@ -571,5 +660,42 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32
     case 7: launch_qverify<7>(a, pl, rmask); break;
     case 8: launch_qverify<8>(a, pl, rmask); break;
     }
+    return 0;
+}
+
+int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out)
+{
+    if (n == 0) return 0;
+    if (fn < 0 || fn >= a.P.q) return -1;
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtShard sh{pl.rank, pl.world};
+    const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
+    const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
+#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2, fn, addr_out, owner_out)
+    switch (a.P.q) {
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;
+    default: return -1;
+    }
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n, uint8_t *hit)
+{
+    if (n) hipLaunchKernelGGL(k_v_probe, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, a.stream, a.filter, addr, n, hit);
+    return 0;
+}
+
+int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask)
+{
+    if (n) hipLaunchKernelGGL(k_v_mark, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, a.stream, sid, n,
+                              pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+    return 0;
+}
+
+int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out)
+{
+    hipLaunchKernelGGL(k_surv_gather, dim3(64, QS_LISTS), dim3(256), 0, a.stream, pl.surv, pl.surv_cur, pl.surv_cap, out);
     return 0;
 }

@@ -14,9 +14,11 @@ Range boundaries: the reference balances rounds with a split-pass histogram; the
 min(H(v), H(rc v)) of two well-mixed L-bit hashes, whose density on [0, 2^L) is 2(1-x), so the
 equal-mass quantiles x_r = 1 - sqrt(1 - r/world) give the same balance without the extra pass.
 
-The address-sharded filter with an all-to-all of Bloom addresses (BASELINE.json north_star) builds on
-the partitioned insert (csrc/tpc_partition.hip: level-1 buckets are the unit that would travel);
-it is the next step and is described in DESIGN.md.
+A second decomposition, `address_sharded_round`, cuts the Bloom filter itself over the ranks by bit
+address (BASELINE.json north_star): the filter of 2^L bits no longer has to fit one GPU.  Every rank
+hashes 1/world of the text; the level-1 regions of the partitioned passes (csrc/tpc_partition.hip,
+tpc_qpartition.hip) are exactly "the addresses for rank d", so one equal-split all_to_all per pass
+moves them to the owner of their filter slices.  See the docstring of `address_sharded_round`.
 """
 import json
 import math
@@ -105,6 +107,205 @@ def sharded_step(backend, dist, L, abundance=(1 << 64) - 1, fetch=False):
     st["range"] = (lo, hi)
     if fetch:
         st["g"], st["ids"] = backend.emit_fetch()
+    return st
+
+
+class _Comm:
+    """The collectives of the address-sharded path over torch.distributed.  backend "nccl" (RCCL) moves
+    device tensors directly; with "gloo" (tests: several ranks on one GPU) they are staged through
+    the host."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.dist, self.torch, self.device = dist, torch, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.direct = dist.get_backend() == "nccl"
+        self.bytes_moved = 0
+
+    def sync(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def _in(self, t):
+        return t if self.direct else t.cpu()
+
+    def _out(self, t):
+        return t if self.direct else t.to(self.device)
+
+    def a2a_equal(self, send):
+        """Block d of `send` goes to rank d; block s of the result came from rank s."""
+        self.sync()
+        s = self._in(send)
+        r = self.torch.empty_like(s)
+        self.dist.all_to_all_single(r, s)
+        self.bytes_moved += send.numel() * send.element_size()
+        return self._out(r)
+
+    def a2a_var(self, send, counts):
+        """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source)."""
+        torch = self.torch
+        self.sync()
+        sc = torch.as_tensor(counts, dtype=torch.int64)
+        if self.direct:
+            scd = sc.to(self.device)
+            rcd = torch.empty_like(scd)
+            self.dist.all_to_all_single(rcd, scd)
+            rc = rcd.cpu()
+        else:
+            rc = torch.empty(self.world, dtype=torch.int64)
+            self.dist.all_to_all_single(rc, sc)
+        rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in sc.tolist()]
+        s = self._in(send)
+        r = torch.empty(sum(rcl), dtype=send.dtype, device=s.device)
+        self.dist.all_to_all_single(r, s, output_split_sizes=rcl, input_split_sizes=scl)
+        self.bytes_moved += send.numel() * send.element_size()
+        return self._out(r), rcl
+
+    def all_gather(self, t):
+        """[world, *t.shape]"""
+        torch = self.torch
+        self.sync()
+        s = self._in(t.contiguous())
+        out = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        self.dist.all_gather_into_tensor(out, s) if self.direct else self.dist.all_gather(list(out.unbind(0)), s)
+        self.bytes_moved += t.numel() * t.element_size() * self.world
+        return self._out(out)
+
+    def max_ints(self, values):
+        torch = self.torch
+        v = torch.as_tensor(values, dtype=torch.int64)
+        v = v.to(self.device) if self.direct else v
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        return [int(x) for x in v.cpu().tolist()]
+
+
+INSERT, QUERY = 0, 1
+
+
+class AddressSharded:
+    """Address-sharded first pass for one rank (context `ctx`, already holding parameters and text).
+
+    Per pass and batch of tiles:
+      hash    tpc_shard_hash: this rank's tiles -> level-1 regions, destination major
+      move    all_to_all (equal blocks) of the regions and their fill counts
+      apply   tpc_shard_apply: levels 2-3 on the owned filter slices (insert: OR; query: first probe)
+    Query only: the survivors of the first probe (edge ids) are checked against hash functions
+    1..q-1 one function at a time -- addresses to their owners (variable all_to_all), one byte back
+    per address -- so only a fill-rate share survives each step; survivors of the last function are
+    the candidate marks.  Finally the per-rank masks are OR-ed (all_gather: RCCL has no bitwise-OR
+    reduction), after which every rank holds the mask tpc_pass1_query would have produced and the
+    second pass runs as on one GPU.
+    Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
+    list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
+
+    def __init__(self, ctx, dist, device):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.comm = _Comm(dist, device)
+        self.device = device
+        self.rank, self.world = self.comm.rank, self.comm.world
+        ctx.shard_config(self.rank, self.world)
+        self._bufs = {}
+        self.stats = {}
+
+    def _buf(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < nbytes:
+            b = self.torch.empty(max(nbytes, 16), dtype=self.torch.uint8, device=self.device)
+            self._bufs[name] = b
+        return b[:nbytes]
+
+    def _exchange(self, which, geom, batch, lo, hi):
+        W = self.world
+        send_r = self._buf("send_r", W * geom["region_block_bytes"])
+        send_c = self._buf("send_c", W * geom["count_block_bytes"])
+        n_ovf = self.ctx.shard_hash(which, batch, send_r.data_ptr(), send_c.data_ptr(), lo, hi)
+        recv_c = self.comm.a2a_equal(send_c)
+        recv_r = self.comm.a2a_equal(send_r)
+        # skew path: entries that did not fit their level-1 region, for any owner
+        m = self.comm.max_ints([n_ovf])[0]
+        if m >= (1 << 63):
+            raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
+        if m > 0:
+            eb = geom["overflow_entry_bytes"]
+            mine = self.torch.zeros(m * eb + 8, dtype=self.torch.uint8, device=self.device)
+            self.ctx.shard_overflow_get(which, mine.data_ptr() + 8, n_ovf)
+            mine[:8] = self.torch.tensor([n_ovf], dtype=self.torch.int64).view(self.torch.uint8).to(self.device)
+            allv = self.comm.all_gather(mine)
+            parts = []
+            for r in range(W):
+                n = int(allv[r, :8].view(self.torch.int64).item())
+                parts.append(allv[r, 8:8 + n * eb])
+            cat = self.torch.cat(parts).contiguous()
+            self.comm.sync()
+            self.ctx.shard_overflow_set(which, cat.data_ptr(), cat.numel() // eb)
+        self.comm.sync()
+        return recv_r, recv_c
+
+    def insert(self, lo=0, hi=None):
+        geom = self.ctx.shard_plan(INSERT, lo, hi)
+        self.ctx.filter_reset()
+        for b in range(geom["batches"]):
+            recv_r, recv_c = self._exchange(INSERT, geom, b, lo, hi)
+            self.ctx.shard_apply(INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
+        return geom
+
+    def query(self, lo=0, hi=None):
+        torch, ctx, W = self.torch, self.ctx, self.world
+        geom = ctx.shard_plan(QUERY, lo, hi)
+        survivors = []
+        for b in range(geom["batches"]):
+            recv_r, recv_c = self._exchange(QUERY, geom, b, lo, hi)
+            n = ctx.shard_apply(QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
+            sid = torch.empty(n, dtype=torch.int64, device=self.device)
+            ctx.shard_survivors(sid.data_ptr())
+            trace = [n]
+            for fn in range(1, ctx.q):
+                n = sid.numel()
+                addr = torch.empty(n, dtype=torch.int64, device=self.device)
+                owner = torch.empty(n, dtype=torch.int32, device=self.device)
+                ctx.shard_verify_addrs(fn, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
+                owner = owner.to(torch.int64)
+                order = torch.argsort(owner, stable=True)
+                counts = torch.bincount(owner, minlength=W).cpu().tolist()
+                req, rcounts = self.comm.a2a_var(addr[order].contiguous(), counts)
+                hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
+                self.comm.sync()
+                ctx.shard_probe(req.data_ptr(), req.numel(), hit.data_ptr())
+                back, _ = self.comm.a2a_var(hit, rcounts)
+                keep = torch.empty(n, dtype=torch.bool, device=self.device)
+                keep[order] = back.to(torch.bool)
+                sid = sid[keep].contiguous()
+                trace.append(sid.numel())
+            self.comm.sync()
+            ctx.shard_mark(sid.data_ptr(), sid.numel())
+            survivors.append(trace)
+        words = ctx.mask_words()
+        m = torch.empty(words, dtype=torch.int32, device=self.device)
+        ctx.mask_export(m.data_ptr())
+        allm = self.comm.all_gather(m).contiguous()
+        self.comm.sync()
+        ctx.mask_merge(allm.data_ptr(), W)
+        self.stats["survivors"] = survivors
+        return geom
+
+    def round(self, lo=0, hi=None, abundance=(1 << 64) - 1):
+        self.insert(lo, hi)
+        self.query(lo, hi)
+        return self.ctx.pass2_filter(abundance)
+
+
+def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False):
+    """One whole enumeration with the filter sharded by address.  After the first pass every rank
+    holds the full candidate mask, so pass 2, the key sort and the id lookup run replicated and
+    every rank ends with the complete result (rank 0 writes it)."""
+    ctx = sharded.ctx
+    ctx.run_begin()
+    st = sharded.round(0, None, abundance)
+    st["junctions"] = ctx.junctions_finalize()
+    st["n_marked"], st["n_valid"] = ctx.emit()
+    st["marks"] = st["n_marked"]
+    if fetch:
+        st["g"], st["ids"] = ctx.emit_fetch()
     return st
 
 
