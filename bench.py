@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomposition", default="ranges", choices=["ranges", "address"],
+                    help="multi-GPU: vertex-hash ranges (default) or the address-sharded filter (power-of-two N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -160,8 +160,8 @@ int tpc_emit_fetch(tpc_ctx *ctx, uint64_t *g_host, int64_t *id_host);
  *                      tests the first probe of every received edge and keeps the hits as the
  *                      survivor list (*n_survivors; ids relative to the batch)
  *   tpc_shard_survivors       copy the survivor ids to a device buffer
- *   tpc_shard_verify_addrs    for hash function fn: owner rank and shard-local bit address of
- *                             every survivor id in sid_dev
+ *   tpc_shard_verify_addrs    for hash functions fn .. fn+fn_count-1: owner rank and shard-local bit
+ *                             address of every survivor id in sid_dev (entry i*fn_count + j)
  *   tpc_shard_probe           answer probes against this rank's shard (hit_dev[i] = 0/1)
  *   tpc_shard_mark            set the candidate mark of every id in sid_dev (all q probes hit)
  *   tpc_mask_export / tpc_mask_merge   round mask to / OR of `count` masks from a device buffer:
@@ -176,7 +176,7 @@ int tpc_shard_overflow_get(tpc_ctx *ctx, int pass, void *dst_dev, uint64_t n);
 int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t n);
 int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
 int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
-int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
+int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
 int tpc_shard_probe(tpc_ctx *ctx, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev);
 int tpc_shard_mark(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n);
 int tpc_mask_export(tpc_ctx *ctx, uint32_t *dst_dev);

@@ -93,5 +93,5 @@ def test_address_sharded_synthetic_batches(world, budget, tmp_path):
         assert gathered[0]["rounds"][0]["geom"]["batches"] > 1 and gathered[0]["rounds"][0]["qgeom"]["batches"] > 1
     # the survivor lists shrink from one hash function to the next
     tr = gathered[0]["rounds"][0]["survivors"][0]
-    assert len(tr) == 5 and tr[-1] <= tr[0]
+    assert len(tr) == 3 and tr[2] <= tr[1] <= tr[0]
     check(spec, o, gathered, world)

@@ -14,3 +14,28 @@ def test_two_ranks_on_gpu(name, tmp_path):
     case = CASES[name]
     files = case_files(case, tmp_path)
     check_against_single(case, files, run_world(case, files, 2, tmp_path, use_gpu=True))
+
+
+@pytest.mark.parametrize("decomposition", ["ranges", "address"])
+def test_bench_single_rank_over_rccl(decomposition):
+    """bench.py's distributed path with the real backend ("nccl" = RCCL) and one rank: the collectives
+    of both decompositions run on device tensors; the result equals the plain single-GPU bench's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
+            "--no-cpu-baseline"]
+    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("TPC_DIST_BACKEND", None)
+    out = subprocess.run(base + ["--decomposition", decomposition], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    dist_line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    env1 = {k: v for k, v in os.environ.items() if k != "TPC_FORCE_DIST"}
+    out1 = subprocess.run(base, env=env1, capture_output=True, text=True, timeout=600)
+    assert out1.returncode == 0, out1.stderr[-2000:]
+    single = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
+    assert dist_line["result"]["junctions"] == single["result"]["junctions"] > 0
+    assert dist_line["result"]["junction_occurrences"] == single["result"]["junction_occurrences"]
+    assert dist_line["result"]["candidate_marks"] == single["result"]["candidate_marks"]

@@ -76,7 +76,7 @@ def hip():
         L.tpc_shard_overflow_set.argtypes = [p, ci, p, u64]
         L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]
         L.tpc_shard_survivors.argtypes = [p, p]
-        L.tpc_shard_verify_addrs.argtypes = [p, ci, p, u64, p, p]
+        L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
         L.tpc_shard_probe.argtypes = [p, p, u64, p]
         L.tpc_shard_mark.argtypes = [p, p, u64]
         L.tpc_mask_export.argtypes = [p, p]
@@ -332,8 +332,8 @@ class Context:
     def shard_survivors(self, sid_ptr):
         self._ck(hip().tpc_shard_survivors(self._h, sid_ptr))
 
-    def shard_verify_addrs(self, fn, sid_ptr, n, addr_ptr, owner_ptr):
-        self._ck(hip().tpc_shard_verify_addrs(self._h, fn, sid_ptr, n, addr_ptr, owner_ptr))
+    def shard_verify_addrs(self, fn, fn_count, sid_ptr, n, addr_ptr, owner_ptr):
+        self._ck(hip().tpc_shard_verify_addrs(self._h, fn, fn_count, sid_ptr, n, addr_ptr, owner_ptr))
 
     def shard_probe(self, addr_ptr, n, hit_ptr):
         self._ck(hip().tpc_shard_probe(self._h, addr_ptr, n, hit_ptr))

@@ -922,11 +922,12 @@ int tpc_shard_survivors(tpc_ctx *c, uint64_t *sid_dev)
     return 0;
 }
 
-int tpc_shard_verify_addrs(tpc_ctx *c, int fn, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev)
+int tpc_shard_verify_addrs(tpc_ctx *c, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev)
 {
     if (!c || !c->sh_have[TPC_SHARD_QUERY] || (n && (!sid_dev || !addr_dev || !owner_dev))) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (tpc_launch_verify_addrs(make_launch(c), c->sh_qpl, fn, sid_dev, n, addr_dev, owner_dev)) return fail(c, -1, "bad hash function index %d", fn);
+    if (tpc_launch_verify_addrs(make_launch(c), c->sh_qpl, fn, fn_count, sid_dev, n, addr_dev, owner_dev))
+        return fail(c, -1, "bad hash function range %d+%d", fn, fn_count);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;

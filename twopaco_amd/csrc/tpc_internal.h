@@ -85,7 +85,7 @@ int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t 
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl);
 // sharded verification of first-probe survivors (survivor id = edge | position << 3, batch relative)
 int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out);  // 64 sub-lists -> one list (sum of min(surv_cur, surv_cap) entries)
-int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out);
+int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out);
 int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n, uint8_t *hit);
 int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask);
 

@@ -408,14 +408,15 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
 
 // ------------------------------------------------------------------------------------------ sharded verification
 // With the filter sharded by bit address the q-1 remaining probes of a survivor live on other ranks:
-// k_v_addrs gives, for hash function fn, the (owner rank, address inside the owner's shard) of every
-// survivor's edge; the host layer exchanges them, k_v_probe answers on the owner, the survivors that miss
-// are dropped, and after function q-1 k_v_mark sets the marks.  Each probe rejects all but a fill-rate
-// share of the false survivors, so the exchanged volume falls geometrically from one function to the next.
+// k_v_addrs gives, for hash functions fn .. fn+fn_count-1, the (owner rank, address inside the owner's
+// shard) of every survivor's edge; the host layer exchanges them, k_v_probe answers on the owner, the
+// survivors with a miss are dropped, and k_v_mark sets the marks of those that passed all q functions.
+// (The driver probes function 1 alone first -- it rejects all but a fill-rate share of the Bloom false
+// positives -- and functions 2..q-1 together for what is left, which is mostly true second edges.)
 template <int Q>
 __global__ void __launch_bounds__(256)
 k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ sid_list, uint64_t n,
-          uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
+          uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
 {
     __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
     if (threadIdx.x < Q * 5) { s_h[threadIdx.x] = tab[threadIdx.x]; s_hk[threadIdx.x] = tab[TPC_TAB_HK + threadIdx.x]; }
@@ -455,13 +456,14 @@ k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
             else { p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c]; nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c]; }
         }
         const bool ng = tpc_pick_neg<Q>(p, nn);
-        uint64_t a = 0;
 #pragma unroll
-        for (int i = 0; i < Q; i++) if (i == fn) a = ng ? nn[i] : p[i];
-        const uint64_t ap = perm.fwd(a);
-        bool mine;
-        addr_out[idx] = pt_local_addr(perm, sh, log_nb2, ap, mine);
-        owner_out[idx] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+        for (int i = 0; i < Q; i++) {
+            if (i < fn || i >= fn + fn_count) continue;
+            const uint64_t ap = perm.fwd(ng ? nn[i] : p[i]);
+            bool mine;
+            addr_out[idx * fn_count + (i - fn)] = pt_local_addr(perm, sh, log_nb2, ap, mine);
+            owner_out[idx * fn_count + (i - fn)] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+        }
     }
 }
 
@@ -663,15 +665,16 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32
     return 0;
 }
 
-int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out)
+int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out,
+                            int32_t *owner_out)
 {
+    if (fn < 0 || fn_count < 1 || fn + fn_count > a.P.q) return -1;
     if (n == 0) return 0;
-    if (fn < 0 || fn >= a.P.q) return -1;
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
-#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2, fn, addr_out, owner_out)
+#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2, fn, fn_count, addr_out, owner_out)
     switch (a.P.q) {
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;

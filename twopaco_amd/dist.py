@@ -189,9 +189,9 @@ class AddressSharded:
       move    all_to_all (equal blocks) of the regions and their fill counts
       apply   tpc_shard_apply: levels 2-3 on the owned filter slices (insert: OR; query: first probe)
     Query only: the survivors of the first probe (edge ids) are checked against hash functions
-    1..q-1 one function at a time -- addresses to their owners (variable all_to_all), one byte back
-    per address -- so only a fill-rate share survives each step; survivors of the last function are
-    the candidate marks.  Finally the per-rank masks are OR-ed (all_gather: RCCL has no bitwise-OR
+    1..q-1 -- addresses to their owners (variable all_to_all), one byte back per address; function 1
+    alone first, which rejects most Bloom false positives, then the rest in one exchange -- and the
+    survivors of all q functions are the candidate marks.  Finally the per-rank masks are OR-ed (all_gather: RCCL has no bitwise-OR
     reduction), after which every rank holds the mask tpc_pass1_query would have produced and the
     second pass runs as on one GPU.
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
@@ -206,6 +206,11 @@ class AddressSharded:
         ctx.shard_config(self.rank, self.world)
         self._bufs = {}
         self.stats = {}
+        self.t = {}   # seconds per phase, accumulated (host clock; every phase ends synchronised)
+
+    def _tick(self, name, t0):
+        self.t[name] = self.t.get(name, 0.0) + (time.perf_counter() - t0)
+        return time.perf_counter()
 
     def _buf(self, name, nbytes):
         b = self._bufs.get(name)
@@ -218,9 +223,14 @@ class AddressSharded:
         W = self.world
         send_r = self._buf("send_r", W * geom["region_block_bytes"])
         send_c = self._buf("send_c", W * geom["count_block_bytes"])
+        tag = "insert" if which == INSERT else "query"
+        t0 = time.perf_counter()
         n_ovf = self.ctx.shard_hash(which, batch, send_r.data_ptr(), send_c.data_ptr(), lo, hi)
+        t0 = self._tick(tag + "_hash", t0)
         recv_c = self.comm.a2a_equal(send_c)
         recv_r = self.comm.a2a_equal(send_r)
+        self.comm.sync()
+        t0 = self._tick(tag + "_all_to_all", t0)
         # skew path: entries that did not fit their level-1 region, for any owner
         m = self.comm.max_ints([n_ovf])[0]
         if m >= (1 << 63):
@@ -246,7 +256,9 @@ class AddressSharded:
         self.ctx.filter_reset()
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(INSERT, geom, b, lo, hi)
+            t0 = time.perf_counter()
             self.ctx.shard_apply(INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
+            self._tick("insert_apply", t0)
         return geom
 
     def query(self, lo=0, hi=None):
@@ -255,15 +267,18 @@ class AddressSharded:
         survivors = []
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(QUERY, geom, b, lo, hi)
+            t0 = time.perf_counter()
             n = ctx.shard_apply(QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
+            t0 = self._tick("query_apply", t0)
             sid = torch.empty(n, dtype=torch.int64, device=self.device)
             ctx.shard_survivors(sid.data_ptr())
             trace = [n]
-            for fn in range(1, ctx.q):
+            # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange
+            for fn, cnt in ([(1, 1)] if ctx.q > 1 else []) + ([(2, ctx.q - 2)] if ctx.q > 2 else []):
                 n = sid.numel()
-                addr = torch.empty(n, dtype=torch.int64, device=self.device)
-                owner = torch.empty(n, dtype=torch.int32, device=self.device)
-                ctx.shard_verify_addrs(fn, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
+                addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
+                owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
+                ctx.shard_verify_addrs(fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
                 owner = owner.to(torch.int64)
                 order = torch.argsort(owner, stable=True)
                 counts = torch.bincount(owner, minlength=W).cpu().tolist()
@@ -272,19 +287,22 @@ class AddressSharded:
                 self.comm.sync()
                 ctx.shard_probe(req.data_ptr(), req.numel(), hit.data_ptr())
                 back, _ = self.comm.a2a_var(hit, rcounts)
-                keep = torch.empty(n, dtype=torch.bool, device=self.device)
-                keep[order] = back.to(torch.bool)
-                sid = sid[keep].contiguous()
+                ok = torch.empty(n * cnt, dtype=torch.bool, device=self.device)
+                ok[order] = back.to(torch.bool)
+                sid = sid[ok.view(n, cnt).all(dim=1)].contiguous()
                 trace.append(sid.numel())
             self.comm.sync()
             ctx.shard_mark(sid.data_ptr(), sid.numel())
+            self._tick("query_verify", t0)
             survivors.append(trace)
+        t0 = time.perf_counter()
         words = ctx.mask_words()
         m = torch.empty(words, dtype=torch.int32, device=self.device)
         ctx.mask_export(m.data_ptr())
         allm = self.comm.all_gather(m).contiguous()
         self.comm.sync()
         ctx.mask_merge(allm.data_ptr(), W)
+        self._tick("mask_union", t0)
         self.stats["survivors"] = survivors
         return geom
 
@@ -369,16 +387,22 @@ def bench_main(args, rank, world, local_rank):
     ctx = capi.Context(device)
     ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=12345))
     ctx.seq_upload(text)
-    be = HipBackend(ctx)
+    address = getattr(args, "decomposition", "ranges") == "address"
+    if address:
+        sh = AddressSharded(ctx, dist, torch.device("cuda", device))
+        step = lambda: address_sharded_step(sh)
+    else:
+        be = HipBackend(ctx)
+        step = lambda: sharded_step(be, dist, p["L"])
     for _ in range(args.warmup):
-        sharded_step(be, dist, p["L"])
-    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit"]
+        step()
+    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit"] + (["shard_hash", "shard_apply"] if address else [])
     kms = {n: 0.0 for n in names}
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = sharded_step(be, dist, p["L"])
+        st = step()
         for n in names:
             kms[n] += max(ctx.kernel_ms(n), 0.0) / args.steps
     torch.cuda.synchronize()
@@ -387,7 +411,8 @@ def bench_main(args, rank, world, local_rank):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
-    dist.all_reduce(tot)
+    if not address:  # address-sharded: every rank already holds the whole result
+        dist.all_reduce(tot)
     dt = float(dt.item())
     if rank == 0:
         out = {
@@ -397,9 +422,13 @@ def bench_main(args, rank, world, local_rank):
             "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d"
                                    % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
                        "kmers": n_kmers, "filter_bytes": (1 << p["L"]) // 8,
-                       "parallelism": "%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world},
+                       "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of level-1 regions per pass, per-function survivor probes, all_gather of the mask" % world)
+                       if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
             "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
             "kernel_ms_rank0": kms,
+            "exchange_bytes_rank0_per_step": (sh.comm.bytes_moved // (args.steps + args.warmup)) if address else None,
+            "phase_ms_rank0_per_step": {k: v * 1e3 / (args.steps + args.warmup) for k, v in sh.t.items()} if address else None,
+            "survivors_rank0": sh.stats.get("survivors") if address else None,
             "result": {"candidate_marks": int(tot[1].item()), "junctions": st["junctions"], "junction_occurrences": int(tot[0].item())},
         }
         print(json.dumps(out))
