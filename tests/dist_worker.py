@@ -115,3 +115,39 @@ def addr_worker(rank, world, port, spec, result_path):
             pickle.dump(gathered, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def comm_worker(rank, world, port, result_path):
+    """The collectives of the address-sharded driver (twopaco_amd/dist.py:_Comm) over gloo on host tensors."""
+    import pickle
+
+    import torch
+    import torch.distributed as dist
+
+    from twopaco_amd import dist as tdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = tdist._Comm(dist, torch.device("cpu"))
+    out = {}
+    # equal blocks: block d of rank r holds (r, d)
+    send = torch.stack([torch.full((5,), 16 * rank + d, dtype=torch.uint8) for d in range(world)]).reshape(-1)
+    out["equal"] = comm.a2a_equal(send).tolist()
+    # variable: rank r sends (r + d) % 3 elements to d, values 100 r + d
+    counts = [(rank + d) % 3 for d in range(world)]
+    send = torch.cat([torch.full((c,), 100 * rank + d, dtype=torch.int64) for d, c in enumerate(counts)] + [torch.zeros(0, dtype=torch.int64)])
+    recv, rc = comm.a2a_var(send, counts)
+    out["var"] = (recv.tolist(), rc)
+    # answers travel back along the same route
+    back, bc = comm.a2a_var((recv % 100 + 1).to(torch.uint8), rc)
+    out["back"] = (back.tolist(), bc)
+    out["gather"] = comm.all_gather(torch.arange(3, dtype=torch.int32) + 10 * rank).tolist()
+    out["max"] = comm.max_ints([rank, 7 - rank])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        with open(result_path, "wb") as f:
+            pickle.dump(gathered, f)
+    dist.barrier()
+    dist.destroy_process_group()

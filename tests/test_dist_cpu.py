@@ -77,3 +77,27 @@ def test_three_ranks(tmp_path):
     case = CASES["rand6_k25_q3"]
     files = case_files(case, tmp_path)
     check_against_single(case, files, run_world(case, files, 3, tmp_path))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_address_sharded_collectives(world, tmp_path):
+    """Routing primitives of the address-sharded driver (equal-block all_to_all of the level-1 regions,
+    variable all_to_all of probe addresses and of the answers coming back, all_gather of the masks)."""
+    from dist_worker import comm_worker
+    res = str(tmp_path / "res.pkl")
+    mp.spawn(comm_worker, args=(world, free_port(), res), nprocs=world, join=True)
+    with open(res, "rb") as f:
+        got = pickle.load(f)
+    for r in range(world):
+        assert got[r]["equal"] == [16 * s + r for s in range(world) for _ in range(5)]
+        want, rc = [], []
+        for s in range(world):
+            c = (s + r) % 3
+            want += [100 * s + r] * c
+            rc.append(c)
+        assert got[r]["var"] == (want, rc)
+        # rank r asked d about counts[d] elements and gets one answer each, in the order sent
+        counts = [(r + d) % 3 for d in range(world)]
+        assert got[r]["back"] == ([d + 1 for d in range(world) for _ in range(counts[d])], counts)
+        assert got[r]["gather"] == [[10 * s + i for i in range(3)] for s in range(world)]
+        assert got[r]["max"] == [world - 1, 7]

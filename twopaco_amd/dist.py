@@ -123,7 +123,8 @@ class _Comm:
         self.bytes_moved = 0
 
     def sync(self):
-        self.torch.cuda.current_stream(self.device).synchronize()
+        if self.torch.device(self.device).type == "cuda":
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def _in(self, t):
         return t if self.direct else t.cpu()
