@@ -52,7 +52,8 @@ enum {
     TPC_K_SPLIT = 8,        /* InitialFilterFillerWorker, VE.h:503-583                         */
     TPC_K_SHARD_HASH = 9,   /* tpc_shard_hash: level 1 of a sharded pass                       */
     TPC_K_SHARD_APPLY = 10, /* tpc_shard_apply: levels 2-3 of a sharded pass                   */
-    TPC_K_COUNT = 11
+    TPC_K_STREAM = 11,      /* tpc_emit_stream: FlushEdgeResults + JunctionPositionWriter bytes  */
+    TPC_K_COUNT = 12
 };
 
 /* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:
@@ -130,6 +131,21 @@ int64_t tpc_get_id(tpc_ctx *ctx, const char *kmer);
 int tpc_emit(tpc_ctx *ctx, uint64_t *n_marked, uint64_t *n_valid);
 /* Copy the emit lists to the host: g_host[n_marked], id_host[n_marked]. */
 int tpc_emit_fetch(tpc_ctx *ctx, uint64_t *g_host, int64_t *id_host);
+
+/* The output file's bytes, built on the device after tpc_emit: FlushEdgeResults (VE.h:837-854) +
+ * JunctionPositionWriter::WriteJunction (junctionapi.h:118-132).  12-byte little-endian records
+ * (u32 position in its sequence, i64 id) in (sequence, position) order; the first / last k-mer of
+ * every sequence of >= k bases without a junction id gets a stub id n_junctions + 42, + 43, ...
+ * (VE.h:419, 942-948); one separator (0xFFFFFFFF, INT64_MAX) per sequence-id step before the first
+ * record of a sequence (junctionapi.h:120-123).  rec_start / rec_len: global text position and
+ * length of EVERY input sequence (n_rec of them, short ones included: they consume an id).
+ * n_bytes = stream length, n_records = records without separators ("True marks count", VE.h:451).
+ * tpc_emit_stream_fetch copies [offset, offset + nbytes) to the host and may be called from several
+ * threads at once (each into its own buffer; pinned buffers from tpc_host_alloc copy fastest). */
+int tpc_emit_stream(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint64_t *n_bytes, uint64_t *n_records);
+int tpc_emit_stream_fetch(tpc_ctx *ctx, uint64_t offset, uint64_t nbytes, void *dst_host);
+int tpc_host_alloc(void **ptr, uint64_t bytes);
+void tpc_host_free(void *ptr);
 
 /* ---- address-sharded filter (multi-GPU) -------------------------------------------------
  * The Bloom filter (ConcurrentBitVector bitVector, VE.h:257) is cut over `world` ranks (a power of

@@ -10,7 +10,7 @@ from .build import lib_dir
 
 INVALID_VERTEX = (1 << 63) - 1
 KERNELS = {"filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8,
-           "shard_hash": 9, "shard_apply": 10}
+           "shard_hash": 9, "shard_apply": 10, "stream": 11}
 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
@@ -19,7 +19,8 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
-               "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge"]
+               "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
+               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free"]
 
 _hip = None
 _host = None
@@ -81,6 +82,10 @@ def hip():
         L.tpc_shard_mark.argtypes = [p, p, u64]
         L.tpc_mask_export.argtypes = [p, p]
         L.tpc_mask_merge.argtypes = [p, p, u32]
+        L.tpc_emit_stream.argtypes = [p, p, p, u32, p, p]
+        L.tpc_emit_stream_fetch.argtypes = [p, u64, u64, p]
+        L.tpc_host_alloc.argtypes = [ctypes.POINTER(p), u64]
+        L.tpc_host_free.argtypes = [p]
         _hip = L
     return _hip
 
@@ -283,6 +288,17 @@ class Context:
         ids = np.zeros(self.n_marked, dtype=np.int64)
         self._ck(hip().tpc_emit_fetch(self._h, g.ctypes.data, ids.ctypes.data))
         return g, ids
+
+    def emit_stream(self, rec_start, rec_len):
+        """The bytes of de_bruijn.bin (after emit()); returns (bytes, records without separators)."""
+        rs = np.ascontiguousarray(rec_start, dtype=np.uint64)
+        rl = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        nb, nr = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(hip().tpc_emit_stream(self._h, rs.ctypes.data, rl.ctypes.data, rs.size, ctypes.byref(nb), ctypes.byref(nr)))
+        buf = np.zeros(nb.value, dtype=np.uint8)
+        if hip().tpc_emit_stream_fetch(self._h, 0, nb.value, buf.ctypes.data) != 0:
+            raise RuntimeError("tpc_emit_stream_fetch failed")
+        return buf.tobytes(), nr.value
 
     def filter_download(self):
         w = np.zeros(hip().tpc_filter_words(self._h), dtype=np.uint32)

@@ -50,6 +50,9 @@ struct tpc_ctx {
     // emit
     int64_t *emit_id = nullptr;
     uint64_t emit_cap = 0, n_emit = 0;
+    // junction stream (bytes of the output file)
+    uint32_t *stream_buf = nullptr;
+    uint64_t stream_cap = 0, stream_bytes = 0;
     // scalars
     unsigned long long *counters = nullptr;  // device, 8 words
     // options
@@ -175,6 +178,20 @@ uint64_t filter_words_for(int L, uint32_t world)
 
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
+// Tile batching of the partitioned query under the buffer budget; false: use the direct kernel.
+bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan &pl)
+{
+    const uint64_t tiles = text_tiles512(c);
+    if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
+    for (uint64_t batches = 1;; batches *= 2) {
+        const uint64_t per = (tiles + batches - 1) / batches;
+        const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl);
+        if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) return false;  // geometry unsupported (not a size problem)
+        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) return true;
+        if (per <= 1) return false;
+    }
+}
+
 int compact_mask(tpc_ctx *c, const uint32_t *m)
 {   // ordered list of the set bits of m -> c->marks / c->n_marks
     Timed t(c, TPC_K_COMPACT);
@@ -219,7 +236,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->pbuf[8], c->scan_blocks };
+                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->pbuf[8], c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -346,9 +363,13 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         }
     }
     if (part) {
-        const size_t need[6] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
-                                 pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
-        for (int i = 0; i < 6 && part; i++) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
+        size_t need[9] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                           pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0 };
+        // the query of the same round shares these buffers: size them for both now (one allocation, not free + grow)
+        TpcQPlan qpl;
+        const bool qpart = plan_query(c, lo, hi, gated, qpl);
+        for (int i = 0; i < 9 && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
+        for (int i = 0; i < 9 && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
     }
     if (part) {
         pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
@@ -444,17 +465,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     c->marks_valid = false;
     TpcQPlan pl;
     const uint64_t tiles = text_tiles512(c);
-    uint64_t batches = 1;
-    bool part = c->opt_query_mode != 1 && !(c->opt_query_mode == 0 && c->P.L < 28);  // small filters are cache resident: direct loads win
-    if (part) {
-        for (;; batches *= 2) {
-            const uint64_t per = (tiles + batches - 1) / batches;
-            const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl);
-            if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) { part = false; break; }  // geometry unsupported (not a size problem)
-            if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
-            if (per <= 1) { part = false; break; }
-        }
-    }
+    bool part = plan_query(c, lo, hi, gated, pl);
     if (part)
         for (int i = 0; i < 9 && part; i++) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
     if (part) {
@@ -715,6 +726,66 @@ int tpc_emit(tpc_ctx *c, uint64_t *n_marked, uint64_t *n_valid)
     if (n_marked) *n_marked = c->n_marks;
     if (n_valid) *n_valid = nv;
     return 0;
+}
+
+int tpc_emit_stream(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint64_t *n_bytes, uint64_t *n_records)
+{
+    if (!c || !c->finalized || !rec_start || !rec_len || !n_rec) return fail(c, -1, "tpc_emit first; records required");
+    if (c->n_emit != c->n_marks || (c->n_marks && !c->emit_id)) return fail(c, -1, "tpc_emit first");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t r_last = 0;
+    for (uint32_t r = 0; r < n_rec; r++) if (rec_len[r] >= (uint64_t)c->P.k) r_last = r;
+    uint64_t *d_rec = nullptr, *vscan = nullptr;
+    void *plan = nullptr;
+    int rc = 0;
+    uint64_t totals[2] = {0, 0};
+    if (hipMalloc((void **)&d_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc(&plan, tpc_stream_plan_bytes(n_rec)) != hipSuccess) rc = -10;
+    if (rc == 0 && (hipMemcpyAsync(d_rec, rec_start, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_rec + n_rec, rec_len, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)) rc = -10;
+    if (rc == 0) {
+        Timed t(c, TPC_K_STREAM);
+        rc = tpc_launch_stream_plan(c->stream, d_rec, d_rec + n_rec, n_rec, c->P.k, c->marks, c->emit_id, c->n_marks, vscan, plan, r_last, totals);
+        if (rc == 0) {
+            const uint64_t bytes = totals[1] * 12;
+            if (bytes > c->stream_cap) {
+                if (c->stream_buf) (void)hipFree(c->stream_buf);
+                c->stream_buf = nullptr; c->stream_cap = 0;
+                if (hipMalloc((void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
+            }
+            if (rc == 0 && bytes)
+                rc = tpc_launch_stream_write(c->stream, d_rec, d_rec + n_rec, n_rec, c->P.k, c->marks, c->emit_id, c->n_marks, vscan, plan, r_last,
+                                             c->n_keys + 42, c->stream_buf);
+            c->stream_bytes = bytes;
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    for (void *p : { (void *)d_rec, (void *)vscan, plan }) if (p) (void)hipFree(p);
+    if (rc) return fail(c, rc, "junction stream failed (%d)", rc);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    if (n_bytes) *n_bytes = c->stream_bytes;
+    if (n_records) *n_records = totals[0];
+    return 0;
+}
+
+int tpc_emit_stream_fetch(tpc_ctx *c, uint64_t offset, uint64_t nbytes, void *dst_host)
+{   // no context state is modified: safe from several host threads at once
+    if (!c || (nbytes && !dst_host) || offset + nbytes > c->stream_bytes) return -1;
+    if (hipSetDevice(c->device) != hipSuccess) return -10;
+    if (nbytes && hipMemcpy(dst_host, (const char *)c->stream_buf + offset, nbytes, hipMemcpyDeviceToHost) != hipSuccess) return -10;
+    return 0;
+}
+
+int tpc_host_alloc(void **ptr, uint64_t bytes)
+{
+    if (!ptr) return -1;
+    return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? 0 : -10;
+}
+
+void tpc_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 int tpc_emit_fetch(tpc_ctx *c, uint64_t *g_host, int64_t *id_host)

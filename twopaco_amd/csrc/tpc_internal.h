@@ -120,3 +120,10 @@ int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J
 int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap);
 int tpc_launch_emit(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
                     const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid);
+
+// junction stream = the bytes of the output file (tpc_stream.hip)
+size_t tpc_stream_plan_bytes(uint32_t n_rec);
+int tpc_launch_stream_plan(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
+                           const int64_t *ids, uint64_t n_marks, uint64_t *vscan, void *rec, uint32_t r_last, uint64_t *totals_host);
+int tpc_launch_stream_write(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
+                            const int64_t *ids, uint64_t n_marks, const uint64_t *vscan, const void *rec, uint32_t r_last, uint64_t first_stub, uint32_t *out);

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 #include <iostream>
 #include <cstdlib>
 #include <ctime>
@@ -122,7 +124,13 @@ namespace TwoPaCo
 				Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
 				// a one-shot run never amortises device allocations, and on MI355X hipMalloc gets slow
 				// (~25 ms per GiB) beyond the first ~48 GiB: keep the partition buffers small and batch
-				Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(20) << 30), "set_option");
+				{
+					// partition buffers per tile batch: a cold process pays for every GiB it allocates (page clearing),
+					// an extra batch costs 2-3 ms of kernel time
+					const char * gb = std::getenv("TWOPACO_PART_BUDGET_GB");
+					const double budget = gb ? std::atof(gb) : 20.0;
+					Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(budget * double(1ull << 30))), "set_option");
+				}
 				Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
 				timer.Lap("context + upload");
@@ -185,19 +193,23 @@ namespace TwoPaCo
 
 					logStream << "Round " << round << ", " << low << ":" << high << std::endl;
 					logStream << "Pass\tFilling\tFiltering" << std::endl << "1\t";
+					PhaseTimer sub;
 					Check(tpc_filter_reset(ctx_), "filter_reset");
 					uint64_t kmers = 0;
 					Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+					sub.Lap("  round: insert");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
 					uint64_t marks = 0;
 					Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
+					sub.Lap("  round: query");
 					logStream << time(0) - mark << "\t" << std::endl;
 
 					mark = time(0);
 					logStream << "2\t";
 					uint64_t truePositives = 0, falsePositives = 0, hashTableSize = 0;
 					Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
+					sub.Lap("  round: exact filter");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
 					logStream << time(0) - mark << std::endl;
@@ -220,163 +232,91 @@ namespace TwoPaCo
 				mark = time(0);
 				uint64_t marked = 0, valid = 0;
 				Check(tpc_emit(ctx_, &marked, &valid), "emit");
-				std::vector<uint64_t> g(marked);
-				std::vector<int64_t> id(marked);
-				Check(tpc_emit_fetch(ctx_, g.data(), id.data()), "emit_fetch");
-				timer.Lap("sort + id lookup + fetch");
-
-				// EdgeConstructionWorker, reference vertexenumerator.h:927-958, in (sequence, position)
-				// order -- the order the reference's -t 1 run assigns stub ids in.  The byte stream is what
-				// JunctionPositionWriter::WriteJunction would produce (junctionapi.h): 12-byte records, one
-				// separator per sequence-id step.  Plan: a sequential walk over the records fixes every
-				// output offset (records, stubs, separators); the records are then formatted by `threads`
-				// workers and written with one call.
-				uint64_t occurence = 0;
-				uint64_t currentStubVertexId = verticesCount + 42;  // vertexenumerator.h:419
-				struct Piece { size_t begin, end; uint64_t first; uint64_t offset; };  // marks [begin,end) of one record -> byte offset
-				std::vector<Piece> pieces;
-				std::vector<char> out;
-				const size_t RECORD = sizeof(uint32_t) + sizeof(int64_t);
-				auto put = [&out](uint64_t offset, uint32_t p, int64_t v)
+				// EdgeConstructionWorker + FlushEdgeResults + JunctionPositionWriter (reference vertexenumerator.h:837-854,
+				// 927-958, junctionapi.h:118-132): the device formats the whole junction stream -- records in
+				// (sequence, position) order, stub ids for sequence ends, one separator per sequence-id step
+				// (csrc/tpc_stream.hip) -- and `threads` writers move it to the file in chunks through pinned buffers.
+				uint64_t streamBytes = 0, occurence = 0;
+				if (text.recStart.size() > UINT32_MAX)
 				{
-					std::memcpy(&out[offset], &p, sizeof(p));
-					std::memcpy(&out[offset + sizeof(p)], &v, sizeof(v));
-				};
-
-				// pass 1 (parallel): number of valid ids in each block of marks
-				const size_t BLOCK = size_t(1) << 16;
-				const size_t blocks = (marked + BLOCK - 1) / BLOCK;
-				std::vector<uint64_t> validBefore(blocks + 1, 0);
-				const size_t workers = std::max<size_t>(1, std::min<size_t>(threads, 64));
-				{
-					std::vector<std::thread> pool;
-					for (size_t t = 0; t < workers; t++)
-					{
-						pool.emplace_back([&, t]()
-						{
-							for (size_t bl = t; bl < blocks; bl += workers)
-							{
-								uint64_t n = 0;
-								const size_t e = std::min(marked, (bl + 1) * BLOCK);
-								for (size_t i = bl * BLOCK; i < e; i++) n += id[i] != INVALID_VERTEX;
-								validBefore[bl + 1] = n;
-							}
-						});
-					}
-					for (std::thread & th : pool) th.join();
-				}
-				for (size_t bl = 0; bl < blocks; bl++) validBefore[bl + 1] += validBefore[bl];
-				auto validUpTo = [&](size_t i)  // valid ids among marks [0, i)
-				{
-					const size_t bl = i / BLOCK;
-					uint64_t n = validBefore[bl];
-					for (size_t j = bl * BLOCK; j < i; j++) n += id[j] != INVALID_VERTEX;
-					return n;
-				};
-
-				// pass 2 (sequential over the records): offsets, stubs, separators
-				struct Fixed { uint64_t offset; uint32_t pos; int64_t id; };
-				std::vector<Fixed> fixed;
-				uint64_t offset = 0;
-				uint32_t nowChr = 0;
-				size_t cur = 0;
-				for (size_t r = 0; r < text.recStart.size(); r++)
-				{
-					const uint64_t len = text.recLength[r];
-					if (len < vertexLength)
-					{
-						continue;
-					}
-
-					const uint64_t first = text.recStart[r];
-					const uint64_t last = first + len - vertexLength;
-					cur = size_t(std::lower_bound(g.begin() + cur, g.end(), first) - g.begin());
-					const size_t end = size_t(std::upper_bound(g.begin() + cur, g.end(), last) - g.begin());
-					const bool firstValid = cur < end && g[cur] == first && id[cur] != INVALID_VERTEX;
-					const bool lastValid = cur < end && g[end - 1] == last && id[end - 1] != INVALID_VERTEX;
-					for (; nowChr < r; ++nowChr)  // JunctionPositionWriter: one separator per sequence-id step
-					{
-						fixed.push_back(Fixed{offset, UINT32_MAX, INT64_MAX});
-						offset += RECORD;
-					}
-
-					// first / last k-mer of the sequence without a junction id get a stub id (vertexenumerator.h:942-948)
-					if (!firstValid)
-					{
-						fixed.push_back(Fixed{offset, 0, int64_t(currentStubVertexId++)});
-						offset += RECORD;
-						++occurence;
-					}
-
-					const uint64_t nValid = validUpTo(end) - validUpTo(cur);
-					pieces.push_back(Piece{cur, end, first, offset});
-					offset += nValid * RECORD;
-					occurence += nValid;
-					if (last != first && !lastValid)
-					{
-						fixed.push_back(Fixed{offset, uint32_t(last - first), int64_t(currentStubVertexId++)});
-						offset += RECORD;
-						++occurence;
-					}
-
-					cur = end;
+					throw std::runtime_error("Too many sequences");
 				}
 
-				out.resize(offset);
-				for (const Fixed & f : fixed) put(f.offset, f.pos, f.id);
-
-				// pass 3 (parallel): format the junction records of every piece, in blocks of marks
-				struct Task { size_t begin, end; uint64_t first; uint64_t offset; };
-				std::vector<Task> tasks;
-				for (const Piece & p : pieces)
+				Check(tpc_emit_stream(ctx_, text.recStart.data(), text.recLength.data(), uint32_t(text.recStart.size()), &streamBytes, &occurence), "emit_stream");
+				timer.Lap("sort + id lookup + junction stream");
 				{
-					uint64_t off = p.offset;
-					for (size_t b0 = p.begin; b0 < p.end;)
-					{
-						const size_t e0 = std::min(p.end, (b0 / BLOCK + 1) * BLOCK);
-						tasks.push_back(Task{b0, e0, p.first, off});
-						off += (validUpTo(e0) - validUpTo(b0)) * RECORD;
-						b0 = e0;
-					}
-				}
-				{
-					std::vector<std::thread> pool;
-					for (size_t t = 0; t < workers; t++)
-					{
-						pool.emplace_back([&, t]()
-						{
-							for (size_t k = t; k < tasks.size(); k += workers)
-							{
-								uint64_t off = tasks[k].offset;
-								for (size_t i = tasks[k].begin; i < tasks[k].end; i++)
-								{
-									if (id[i] != INVALID_VERTEX)
-									{
-										put(off, uint32_t(g[i] - tasks[k].first), id[i]);
-										off += RECORD;
-									}
-								}
-							}
-						});
-					}
-					for (std::thread & th : pool) th.join();
-				}
-
-				{
-					std::FILE * f = std::fopen(outFileName.c_str(), "wb");
-					if (!f)
+					const int fd = ::open(outFileName.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+					if (fd < 0)
 					{
 						throw std::runtime_error("Can't create the output file");
 					}
 
-					const bool ok = out.empty() || std::fwrite(out.data(), 1, out.size(), f) == out.size();
-					if (std::fclose(f) != 0 || !ok)
+					const uint64_t CHUNK = uint64_t(8) << 20;
+					const uint64_t chunks = (streamBytes + CHUNK - 1) / CHUNK;
+					const size_t workers = size_t(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, 8), chunks)));
+					std::vector<int> failed(workers, 0);
+					std::vector<std::thread> pool;
+					for (size_t t = 0; t < workers; t++)
 					{
-						throw std::runtime_error("Can't write to the output file");
+						pool.emplace_back([&, t]()
+						{
+							void * pinned = 0;
+							std::vector<char> pageable;
+							char * buf = 0;
+							if (tpc_host_alloc(&pinned, CHUNK) == 0)
+							{
+								buf = static_cast<char*>(pinned);
+							}
+							else
+							{
+								pageable.resize(CHUNK);
+								buf = pageable.data();
+							}
+
+							for (uint64_t c = t; c < chunks && !failed[t]; c += workers)
+							{
+								const uint64_t off = c * CHUNK;
+								const uint64_t n = std::min(CHUNK, streamBytes - off);
+								if (tpc_emit_stream_fetch(ctx_, off, n, buf) != 0)
+								{
+									failed[t] = 1;
+									break;
+								}
+
+								for (uint64_t done = 0; done < n;)
+								{
+									const ssize_t w = ::pwrite(fd, buf + done, size_t(n - done), off_t(off + done));
+									if (w <= 0)
+									{
+										failed[t] = 2;
+										break;
+									}
+
+									done += uint64_t(w);
+								}
+							}
+
+							tpc_host_free(pinned);
+						});
+					}
+
+					for (std::thread & th : pool) th.join();
+					const bool closed = ::close(fd) == 0;
+					for (size_t t = 0; t < workers; t++)
+					{
+						if (failed[t] == 1)
+						{
+							throw std::runtime_error("Can't fetch the junction stream from the device");
+						}
+
+						if (failed[t] == 2 || !closed)
+						{
+							throw std::runtime_error("Can't write to the output file");
+						}
 					}
 				}
 
-				timer.Lap("merge + write junction stream");
+				timer.Lap("write junction stream");
 				logStream << "True marks count: " << occurence << std::endl;
 				logStream << "Edges construction time: " << time(0) - mark << std::endl;
 				logStream << std::string(80, '-') << std::endl;
