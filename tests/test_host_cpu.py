@@ -72,6 +72,37 @@ def test_text_packer_from_codes_and_threads(capi, tmp_path):
     assert synth.n_kmers(recs, 25) == sum(r.size - 24 for r in recs)
 
 
+@pytest.mark.parametrize("threads", [1, 5])
+def test_text_packer_ragged_records_in_parallel(capi, tmp_path, threads):
+    """Many short and empty records (several per packed word), N runs, lower case, over several files: the
+    parallel placement (host/textpack.cpp) must give the text of the sequential from_codes path."""
+    rng = np.random.default_rng(7)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    files, recs = [], []
+    for f in range(4):
+        path = str(tmp_path / ("r%d.fa" % f))
+        with open(path, "w") as out:
+            for r in range(60):
+                n = int(rng.choice([0, 1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 1000, 4097]))
+                codes = rng.integers(0, 4, n).astype(np.uint8)
+                if n > 4 and rng.random() < 0.5:
+                    a = int(rng.integers(0, n - 1))
+                    codes[a:a + int(rng.integers(1, 40))] = 4
+                recs.append(codes)
+                text = letters[codes].tobytes().decode()
+                if rng.random() < 0.3:
+                    text = text.lower()
+                out.write(">s%d_%d\n" % (f, r))
+                for i in range(0, n, 70):
+                    out.write(text[i:i + 70] + "\n")
+        files.append(path)
+    a = capi.PackedText.from_codes(recs)
+    b = capi.PackedText.from_fasta(files, threads=threads)
+    assert a.length == b.length
+    assert (a.rec_start == b.rec_start).all() and (a.rec_length == b.rec_length).all()
+    assert (a.bases == b.bases).all() and (a.nmask == b.nmask).all()
+
+
 def test_fasta_errors(capi, tmp_path):
     bad = tmp_path / "bad.fa"
     bad.write_text(">x\nACGT!ACGT\n")

@@ -16,7 +16,10 @@ for i, r in enumerate(recs):
     files.append(f)
 exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
 out = os.path.join(tmp, "out.bin")
-for rep in range(2):
+pause = float(os.environ.get("E2E_PAUSE", "3"))  # the driver releases the previous process's 30+ GiB asynchronously: measure isolated runs
+for rep in range(int(os.environ.get("E2E_RUNS", "3"))):
+    time.sleep(pause)
+    out = os.path.join(tmp, "out%d.bin" % rep)  # a fresh file each time (truncating a cached 500 MB file costs ~90 ms)
     t0 = time.time()
     res = subprocess.run([exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", "12345", "-o", out] + files,
                          env=dict(os.environ, TWOPACO_TIMING="1"), capture_output=True, text=True)

@@ -8,7 +8,11 @@
 // (reference constructor.cpp:179-188).
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <unistd.h>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -54,8 +58,33 @@ namespace
 	}
 }
 
+namespace
+{
+	// TWOPACO_TIMING=1: milliseconds since the process was started (exec), from /proc/self/stat
+	double SinceProcessStart()
+	{
+		std::FILE * f = std::fopen("/proc/self/stat", "r");
+		if (!f) return -1;
+		char buf[2048];
+		size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+		std::fclose(f);
+		buf[n] = 0;
+		const char * p = std::strrchr(buf, ')');
+		if (!p) return -1;
+		unsigned long long start = 0;
+		int field = 2;
+		for (p++; *p && field < 22; p++) if (*p == ' ') { field++; if (field == 22) { start = std::strtoull(p + 1, 0, 10); break; } }
+		struct timespec ts;
+		clock_gettime(CLOCK_BOOTTIME, &ts);
+		const double now = ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+		return now - double(start) * 1e3 / double(sysconf(_SC_CLK_TCK));
+	}
+}
+
 int main(int argc, char * argv[])
 {
+	const bool timing = std::getenv("TWOPACO_TIMING") != 0;
+	if (timing) std::cerr << "[timing] exec -> main: " << SinceProcessStart() << " ms" << std::endl;
 	try
 	{
 		unsigned int kvalue = 25, hashFunctions = 5, rounds = 1, threads = 1;
@@ -125,6 +154,18 @@ int main(int argc, char * argv[])
 			std::cout << "Distinct junctions = " << vid->GetVerticesCount() << std::endl;
 			std::cout << std::endl;
 		}
+
+		if (timing) std::cerr << "[timing] exec -> output complete: " << SinceProcessStart() << " ms" << std::endl;
+		if (std::getenv("TWOPACO_FAST_EXIT"))
+		{
+			std::cout.flush();
+			std::fflush(0);
+			vid.release();
+			std::_Exit(0);
+		}
+
+		vid.reset();
+		if (timing) std::cerr << "[timing] exec -> context destroyed: " << SinceProcessStart() << " ms" << std::endl;
 	}
 	catch (ArgError & e)
 	{

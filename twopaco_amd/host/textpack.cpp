@@ -1,6 +1,12 @@
 #include "textpack.h"
 
+#include <algorithm>
 #include <atomic>
+#include <cstring>
+#include <functional>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <thread>
 
@@ -145,21 +151,114 @@ namespace TwoPaCo
 			for (std::thread & t : pool) t.join();
 		}
 
-		out.BeginText();
 		for (size_t f = 0; f < fileName.size(); f++)
 		{
 			if (parsed[f].error)
 			{
 				throw *parsed[f].error;
 			}
+		}
 
-			for (Record & rec : parsed[f].records)
+		// Layout of T = N rec0 N rec1 N ...: every record's start follows from the lengths alone, so the records are
+		// placed by all threads at once.  A destination word inside one record is written by that record's thread
+		// only; the first and last word of its span may be shared with the neighbours and are OR-ed atomically.
+		struct Placed { const Record * rec; uint64_t start; };
+		std::vector<Placed> placed;
+		uint64_t length = 1;
+		for (Parsed & p : parsed)
+		{
+			for (Record & rec : p.records)
 			{
-				out.AppendPacked(rec.bases.data(), rec.nmask.data(), rec.n);
-				out.EndRecord(rec.n);
-				std::vector<uint64_t>().swap(rec.bases);
-				std::vector<uint32_t>().swap(rec.nmask);
+				placed.push_back(Placed{&rec, length});
+				length += rec.n + 1;
 			}
 		}
+
+		const uint64_t words = (length + 31) / 32;
+		out.bases.clear();
+		out.nmask.clear();
+		out.bases.resize(words);  // uninitialised (DefaultInitAllocator): zeroed below, in parallel
+		out.nmask.resize(words);
+		out.recStart.resize(placed.size());
+		out.recLength.resize(placed.size());
+		out.length = length;
+		uint64_t * const B = out.bases.data();
+		uint32_t * const M = out.nmask.data();
+		auto setN = [M](uint64_t g) { __atomic_fetch_or(&M[g >> 5], uint32_t(1) << (g & 31), __ATOMIC_RELAXED); };
+		auto place = [&](const Placed & p)
+		{
+			const uint64_t n = p.rec->n;
+			setN(p.start + n);  // trailing separator
+			if (n == 0) return;
+			const uint64_t * b = p.rec->bases.data();
+			const uint32_t * m = p.rec->nmask.data();
+			const uint64_t w0 = p.start >> 5;
+			const unsigned o = unsigned(p.start & 31);
+			const uint64_t nw = (n + 31) / 32;
+			const uint64_t last = (p.start + n - 1) >> 5;  // last destination word holding a character of the record
+			for (uint64_t j = w0; j <= last; j++)
+			{
+				const uint64_t i = j - w0;
+				uint64_t vb = 0;
+				uint32_t vm = 0;
+				if (i < nw)
+				{
+					vb = b[i] << (2 * o);
+					vm = m[i] << o;
+				}
+
+				if (o != 0 && i >= 1)
+				{
+					vb |= b[i - 1] >> (64 - 2 * o);
+					vm |= m[i - 1] >> (32 - o);
+				}
+
+				if (j == w0 || j == last)
+				{
+					__atomic_fetch_or(&B[j], vb, __ATOMIC_RELAXED);
+					__atomic_fetch_or(&M[j], vm, __ATOMIC_RELAXED);
+				}
+				else
+				{
+					B[j] = vb;
+					M[j] = vm;
+				}
+			}
+		};
+
+		// phase 1: zero fill in parallel chunks (span ends are OR-ed into); phase 2: place the records
+		const size_t team = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+		auto parallel = [team](size_t items, const std::function<void(size_t)> & fn)
+		{
+			if (team <= 1 || items <= 1)
+			{
+				for (size_t i = 0; i < items; i++) fn(i);
+				return;
+			}
+
+			std::atomic<size_t> cursor(0);
+			std::vector<std::thread> pool;
+			for (size_t t = 0; t < std::min(team, items); t++)
+			{
+				pool.emplace_back([&]() { for (size_t i = cursor++; i < items; i = cursor++) fn(i); });
+			}
+
+			for (std::thread & th : pool) th.join();
+		};
+
+		const uint64_t CHUNK = uint64_t(1) << 18;  // words
+		parallel(size_t((words + CHUNK - 1) / CHUNK), [&](size_t c)
+		{
+			const uint64_t a = c * CHUNK, e = std::min(words, a + CHUNK);
+			std::memset(B + a, 0, (e - a) * sizeof(uint64_t));
+			std::memset(M + a, 0, (e - a) * sizeof(uint32_t));
+		});
+		setN(0);  // leading separator
+		parallel(placed.size(), [&](size_t r)
+		{
+			place(placed[r]);
+			out.recStart[r] = placed[r].start;
+			out.recLength[r] = placed[r].rec->n;
+		});
 	}
 }

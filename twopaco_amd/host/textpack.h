@@ -10,15 +10,30 @@
 #define _TPC_TEXTPACK_H_
 
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace TwoPaCo
 {
+	// std::allocator whose value-less construct() leaves trivially constructible elements uninitialised, so that
+	// resize(n) does not run a serial fill over hundreds of MB (the packer's threads zero their own ranges)
+	template<class T>
+	struct DefaultInitAllocator : std::allocator<T>
+	{
+		template<class U> struct rebind { typedef DefaultInitAllocator<U> other; };
+		DefaultInitAllocator() {}
+		template<class U> DefaultInitAllocator(const DefaultInitAllocator<U> &) {}
+		template<class U> void construct(U * p) { ::new(static_cast<void*>(p)) U; }
+		template<class U, class... Args> void construct(U * p, Args &&... args) { ::new(static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+	};
+
 	struct PackedText
 	{
-		std::vector<uint64_t> bases;     // base g at bits 2*(g%32) of bases[g/32]
-		std::vector<uint32_t> nmask;     // bit g%32 of nmask[g/32]: T[g] is 'N'
+		std::vector<uint64_t, DefaultInitAllocator<uint64_t> > bases;  // base g at bits 2*(g%32) of bases[g/32]
+		std::vector<uint32_t, DefaultInitAllocator<uint32_t> > nmask;  // bit g%32 of nmask[g/32]: T[g] is 'N'
 		uint64_t length;                 // characters in T
 		std::vector<uint64_t> recStart;  // global position of the first base of record r
 		std::vector<uint64_t> recLength; // bases in record r

@@ -111,27 +111,50 @@ namespace TwoPaCo
 				std::vector<uint64_t> table = MakeSeedTable(hashFunctions, filterSize, options.pinnedSeed, options.seed);
 				seed_ = VertexRollingHashSeed(hashFunctions, vertexLength, filterSize, table);
 
+				// the device context and the filter allocation (HIP start-up, 2^L/8 bytes of hipMalloc) do not depend
+				// on the input: they are set up by a second thread while this one parses and packs the FASTA files
+				std::string setupError;
+				std::thread setup([&]()
+				{
+					try
+					{
+						if (tpc_ctx_create(options.device, &ctx_) != 0)
+						{
+							throw std::runtime_error("Can't create a GPU context (no MI355X visible?)");
+						}
+
+						Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
+						// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
+						// ~25 ms per GiB, beyond the first ~48 GiB), an extra batch costs 15-20 ms of kernel time at f=36
+						const char * gb = std::getenv("TWOPACO_PART_BUDGET_GB");
+						const double budget = gb ? std::atof(gb) : 20.0;
+						Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(budget * double(1ull << 30))), "set_option");
+						Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
+					}
+					catch (std::exception & e)
+					{
+						setupError = e.what();
+					}
+				});
+
 				PackedText text;
-				PackFastaFiles(fileName, threads, text);
+				try
+				{
+					PackFastaFiles(fileName, threads, text);
+				}
+				catch (...)
+				{
+					setup.join();
+					throw;
+				}
+
 				timer.Lap("parse + pack FASTA");
-
-				int rc = tpc_ctx_create(options.device, &ctx_);
-				if (rc != 0)
+				setup.join();
+				if (!setupError.empty())
 				{
-					throw std::runtime_error("Can't create a GPU context (no MI355X visible?)");
+					throw std::runtime_error(setupError);
 				}
 
-				Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
-				// a one-shot run never amortises device allocations, and on MI355X hipMalloc gets slow
-				// (~25 ms per GiB) beyond the first ~48 GiB: keep the partition buffers small and batch
-				{
-					// partition buffers per tile batch: a cold process pays for every GiB it allocates (page clearing),
-					// an extra batch costs 2-3 ms of kernel time
-					const char * gb = std::getenv("TWOPACO_PART_BUDGET_GB");
-					const double budget = gb ? std::atof(gb) : 20.0;
-					Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(budget * double(1ull << 30))), "set_option");
-				}
-				Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
 				timer.Lap("context + upload");
 
