@@ -353,6 +353,49 @@ def test_cli_binary_writes_reference_bytes(tmp_path):
     assert "Splitting the input kmers set..." in r.stdout and r.stdout.count("Round ") == case["n_rounds"]
 
 
+def test_cli_pipeline_twopaco_then_graphdump(tmp_path):
+    """The two tools chained as users chain them: twopaco (unpinned seed, 62-genome-like synthetic input over
+    several files) then graphdump -f gfa1; every path spells its input sequence back through the segments."""
+    import subprocess
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m2", scale=0.004)   # 62 x 20 kbp, with N runs
+    recs = recs[:12]
+    files = []
+    for i, r in enumerate(recs):
+        f = str(tmp_path / ("g%d.fa" % i))
+        synth.write_fasta(f, [r], first_id=i)
+        files.append(f)
+    k = 25
+    bindir = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin")
+    out = str(tmp_path / "db.bin")
+    r = subprocess.run([os.path.join(bindir, "twopaco"), "-k", str(k), "-f", "28", "-t", "4", "--tmpdir", str(tmp_path), "-o", out] + files,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    args = [os.path.join(bindir, "graphdump"), out, "-f", "gfa1", "-k", str(k)]
+    for f in files:
+        args += ["-s", f]
+    g = subprocess.run(args, capture_output=True, text=True)
+    assert g.returncode == 0, g.stderr
+    seg, paths = {}, {}
+    for line in g.stdout.splitlines():
+        f = line.split("\t")
+        if f[0] == "S" and f[2] != "*":
+            seg[f[1]] = f[2]
+        elif f[0] == "P":
+            paths[f[1]] = f[2].split(",")
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    assert len(paths) == len(recs)
+    for i, rec in enumerate(recs):
+        spelled = []
+        for item in paths[str(i)]:
+            body = seg[item[:-1]]
+            if item[-1] == "-":
+                body = "".join(comp.get(c, "N") for c in reversed(body))
+            spelled.append(body if not spelled else body[k:])
+        assert "".join(spelled) == letters[rec].tobytes().decode()
+
+
 def test_cli_selftest(tmp_path):
     """twopaco --test: the reference's randomized differential self-test (test.cpp), shortened via env."""
     import subprocess
