@@ -210,8 +210,17 @@ int tpc_hash_dump(tpc_ctx *ctx, uint64_t g0, uint64_t n, uint64_t *out_host);
 /* Duration in ms of the most recent launch(es) of kernel `which`, measured with hipEvents on
  * the stream the kernel ran on; <0 if it has not run. */
 double tpc_kernel_ms(const tpc_ctx *ctx, int which);
-/* Insert-kernel variant: 0 = atomicOr per address, 1 = test-then-atomicOr (VE.h:1088). */
+/* Tuning knobs (results never depend on them):
+ *   insert_test_first  direct insert kernel: 0 = atomicOr per address, 1 = test-then-atomicOr (VE.h:1088)
+ *   insert_mode / query_mode   0 = automatic, 1 = direct scattered kernel, 2 = LDS write-combining passes
+ *   slice_bits         log2 bits of a filter slice held in LDS (6..20, default 20)
+ *   part_levels        0 = automatic (three binning levels when L - slice_bits > 18), 2, 3
+ *   part_budget_bytes  partition buffers per tile batch (default 40 GiB); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
+/* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
+ * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
+ * "insert_batches" / "query_batches" = tile batches.  -1: unknown name. */
+int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);
 
 #ifdef __cplusplus
 }

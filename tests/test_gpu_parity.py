@@ -443,10 +443,66 @@ def test_m2_full_size_partitioned_equals_direct(capi):
     assert results[0] == results[1]
 
 
-@pytest.mark.parametrize("L", [37, 38])
+@pytest.mark.parametrize("name,slice_bits", [("rand6_k9_fp", 8), ("rand6_k9_q8", 9), ("rand6_k25_q3", 12), ("rand6_k9_L33", 20), ("c2_k51_r2", 14),
+                                             ("edge_k5", 7), ("rand6_k9_fp_r4", 10), ("c2_k125", 12)])
+def test_three_level_partition_matches_oracle(capi, tmp_path, name, slice_bits):
+    """The three-level geometry (what filters beyond 2^38 bits use) forced on small filters: same Bloom bitmap,
+    same candidate mask and mark count as the oracle, whole range and gated round ranges."""
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", slice_bits), ("part_levels", 3)):
+        ctx.set_option(opt, val)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+    for lo, hi in ranges:
+        o.fill_only(lo, hi)
+        marks = o.check_only(lo, hi)
+        ctx.filter_reset()
+        ctx.pass1_insert(lo, hi)
+        assert (ctx.filter_download() == o.filter).all(), (name, lo, hi)
+        ctx.pass1_insert(lo, hi)  # accumulate mode
+        assert (ctx.filter_download() == o.filter).all()
+        assert ctx.pass1_query(lo, hi) == marks
+        assert (ctx.mask_download(False) == o.round_mask).all(), (name, lo, hi)
+        assert ctx.stat("insert_path") == 3 and ctx.stat("query_path") == 3
+    ctx.close()
+
+
+def test_three_level_partition_in_batches_with_skew(capi):
+    """Three levels, several tile batches, and a skewed text (repeats + poly-A) that overflows regions at every
+    level: result equals the direct kernels'."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.01)
+    recs = list(recs) + [np.zeros(60000, dtype=np.uint8), np.tile(recs[0][:500], 100)]
+    text = capi.PackedText.from_codes(recs)
+    res = []
+    for mode in (2, 1):
+        ctx = capi.Context(0)
+        for opt, val in (("insert_mode", mode), ("query_mode", mode), ("slice_bits", 12), ("part_levels", 3), ("part_min_tiles", 1),
+                         ("part_budget_bytes", 6 << 20)):
+            ctx.set_option(opt, val)
+        ctx.set_params(25, 27, 5, capi.seed_table(5, 27, seed=5))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        f = ctx.filter_download()
+        marks = ctx.pass1_query()
+        res.append((f, marks, ctx.mask_download(False)))
+        if mode == 2:
+            assert ctx.stat("insert_path") % 10 == 3 and ctx.stat("query_path") % 10 == 3
+            assert ctx.stat("insert_batches") > 1 and ctx.stat("query_batches") > 1
+        ctx.close()
+    assert (res[0][0] == res[1][0]).all() and res[0][1] == res[1][1] > 0 and (res[0][2] == res[1][2]).all()
+
+
+@pytest.mark.parametrize("L", [37, 38, 39, 40])
 def test_partitioned_paths_large_filters(capi, L):
-    """f=37/38 (16/32 GiB filter, 512 bins per level, rings of 32 uint64 entries): partitioned insert and
-    query against the direct kernels on the same text -- same candidate mask, marks and junction keys."""
+    """f=37/38 (16/32 GiB filter, 512 bins per level, rings of 32 uint64 entries) and f=39/40 (64/128 GiB,
+    three levels): partitioned insert and query against the direct kernels on the same text -- same
+    candidate mask, marks and junction keys."""
     from twopaco_amd import synth
     recs, _ = synth.workload("m1", scale=0.02)
     text = capi.PackedText.from_codes(recs)
@@ -465,6 +521,8 @@ def test_partitioned_paths_large_filters(capi, L):
         st = ctx.pass2_filter()
         ctx.junctions_finalize()
         res.append((marks, mask, st, ctx.junction_keys()))
+        want = 1 if mode == 1 else (3 if L > 38 else 2)
+        assert ctx.stat("insert_path") == want and ctx.stat("query_path") == want
         ctx.close()
     assert res[0][0] == res[1][0] > 0 and res[0][2] == res[1][2]
     assert (res[0][1] == res[1][1]).all() and (res[0][3] == res[1][3]).all()

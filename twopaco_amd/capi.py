@@ -20,7 +20,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
-               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free"]
+               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat"]
 
 _hip = None
 _host = None
@@ -86,6 +86,8 @@ def hip():
         L.tpc_emit_stream_fetch.argtypes = [p, u64, u64, p]
         L.tpc_host_alloc.argtypes = [ctypes.POINTER(p), u64]
         L.tpc_host_free.argtypes = [p]
+        L.tpc_get_stat.restype = i64
+        L.tpc_get_stat.argtypes = [p, ctypes.c_char_p]
         _hip = L
     return _hip
 
@@ -211,6 +213,9 @@ class Context:
 
     def set_option(self, name, value):
         self._ck(hip().tpc_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name):
+        return int(hip().tpc_get_stat(self._h, name.encode()))
 
     def set_params(self, k, L, q, table):
         table = np.ascontiguousarray(table, dtype=np.uint64)

@@ -61,9 +61,14 @@ struct tpc_ctx {
     int opt_slice_bits = 20;
     // partitioned insert
     bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
-    void *pbuf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // shared by insert and query
-    size_t pbytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<uint64_t> off2_uploaded;   // level-2 region offsets currently in pbuf[8]
+    static constexpr int NPBUF = 12;  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
+    void *pbuf[NPBUF] = {};   // shared by insert and query
+    size_t pbytes[NPBUF] = {};
+    std::vector<uint64_t> off2_uploaded, off3_uploaded;   // region offset tables currently in pbuf[8] / pbuf[11]
+    int opt_part_levels = 0;   // 0 auto (three levels when L - slice_bits > 18), 2, 3
+    // what the last insert / query actually ran (tpc_get_stat)
+    int stat_path[2] = {0, 0};       // 1 direct kernel, 2 / 3 partitioned with that many levels (+10: partitioned, then completed by the direct kernel)
+    int64_t stat_batches[2] = {0, 0};
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = (int64_t)40 << 30;  // bytes of partition buffers per batch (first ~48 GiB of hipMalloc are cheap)
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
@@ -166,6 +171,7 @@ bool ensure_pbuf(tpc_ctx *c, int i, size_t need)
     if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
     c->pbuf[i] = nullptr; c->pbytes[i] = 0;
     if (i == 8) c->off2_uploaded.clear();
+    if (i == 11) c->off3_uploaded.clear();
     if (hipMalloc(&c->pbuf[i], need) != hipSuccess) { (void)hipGetLastError(); return false; }
     c->pbytes[i] = need;
     return true;
@@ -185,9 +191,16 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
     for (uint64_t batches = 1;; batches *= 2) {
         const uint64_t per = (tiles + batches - 1) / batches;
-        const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl);
+        const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl, c->opt_part_levels);
         if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) return false;  // geometry unsupported (not a size problem)
-        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) return true;
+        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) {
+            // Every batch streams the whole filter through LDS once.  That pays while a slice sees a few thousand probes per
+            // batch; below that (sparse huge filters: f >= 39 on the 62-genome input) the direct loads are cheaper.
+            // tools/large_filter_bench.py: f=38 3.5 k probes per slice and batch 52 vs 61 ms, f=39 1.8 k 64 vs 61, f=40 0.9 k 99 vs 63.
+            const double per_slice = 6.0 * (gated ? range_mass(c, lo, hi) : 1.0) * (double)per * 512 * TPC_RUN / (double)(1ull << (c->P.L - pl.slice_bits));
+            if (c->opt_query_mode == 0 && batches > 1 && per_slice < 2500.0) return false;
+            return true;
+        }
         if (per <= 1) return false;
     }
 }
@@ -236,8 +249,9 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], c->pbuf[4], c->pbuf[5], c->pbuf[6], c->pbuf[7], c->pbuf[8], c->scan_blocks };
+                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -253,8 +267,19 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "slice_bits")) { c->opt_slice_bits = (int)value; return 0; }
     if (!strcmp(name, "query_mode")) { c->opt_query_mode = (int)value; return 0; }
     if (!strcmp(name, "part_budget_bytes")) { c->opt_part_budget = value; return 0; }
+    if (!strcmp(name, "part_levels")) { c->opt_part_levels = (int)value; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     return fail(c, -1, "unknown option %s", name);
+}
+
+int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
+{
+    if (!c || !name) return -1;
+    if (!strcmp(name, "insert_path")) return c->stat_path[0];
+    if (!strcmp(name, "query_path")) return c->stat_path[1];
+    if (!strcmp(name, "insert_batches")) return c->stat_batches[0];
+    if (!strcmp(name, "query_batches")) return c->stat_batches[1];
+    return -1;
 }
 
 int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
@@ -358,29 +383,38 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         // as few batches of tiles as the buffer budget allows
         for (;; batches *= 2) {
             const uint64_t per = (tiles + batches - 1) / batches;
-            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl)) { part = false; break; }
-            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl, c->opt_part_levels)) { part = false; break; }
+            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+        }
+        // A batch after the first loads and stores every filter slice (2 x 2^L/8 bytes at ~5 TB/s) to save ~40 ps per address
+        // against the direct atomics: worth it only above ~2^slice_bits/800 addresses per slice and batch.
+        if (part && c->opt_insert_mode == 0 && batches > 1) {
+            const double per_slice = (double)c->P.q * ins_frac * (double)pl.n_tiles * 512 * TPC_RUN / (double)(1ull << (c->P.L - pl.slice_bits));
+            if (per_slice < (double)(1ull << pl.slice_bits) / 800.0) part = false;
         }
     }
     if (part) {
-        size_t need[9] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
-                           pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0 };
+        size_t need[tpc_ctx::NPBUF] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                                        pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, tpc_part_buf3_bytes(pl), tpc_part_cnt3_bytes(pl), 0 };
         // the query of the same round shares these buffers: size them for both now (one allocation, not free + grow)
         TpcQPlan qpl;
         const bool qpart = plan_query(c, lo, hi, gated, qpl);
-        for (int i = 0; i < 9 && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
-        for (int i = 0; i < 9 && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
+        for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
+        for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
     }
     if (part) {
         pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
         bool fresh = c->filter_zero_pending;
         unsigned long long ov[2] = {0, 0};
         bool overflowed = false;
+        uint64_t per_batch = 1;
         {
             Timed t(c, TPC_K_INSERT);
             if (fresh) HIPCHK(c, hipMemsetAsync(c->filter + (c->filter_words - 1), 0, sizeof(uint32_t), c->stream));
             const uint64_t per = pl.n_tiles;
+            per_batch = per;
             for (uint64_t t0 = 0; t0 < tiles; t0 += per) {
                 pl.tile0 = t0;
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
@@ -396,6 +430,8 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         overflowed = overflowed || ov[1] != 0;
+        c->stat_path[0] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
+        c->stat_batches[0] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (!overflowed) {
             if (n_kmers) return read_counter(c, 0, n_kmers);
             return 0;
@@ -406,6 +442,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     }
     int rc = materialize_reset(c);
     if (rc) return rc;
+    if (!part) { c->stat_path[0] = 1; c->stat_batches[0] = 1; }
     {
         Timed t(c, TPC_K_INSERT);
         if (tpc_launch_insert(make_launch(c), lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
@@ -467,7 +504,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     const uint64_t tiles = text_tiles512(c);
     bool part = plan_query(c, lo, hi, gated, pl);
     if (part)
-        for (int i = 0; i < 9 && part; i++) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
+        for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (tpc_qpart_bytes(pl, i)) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
     if (part) {
         pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
@@ -477,11 +514,18 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             HIPCHK(c, hipMemcpy(c->pbuf[8], pl.off2_host.data(), pl.off2_host.size() * 8, hipMemcpyHostToDevice));
             c->off2_uploaded = pl.off2_host;
         }
+        pl.buf3 = (uint64_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];
+        if (pl.b3 && c->off3_uploaded != pl.off3_host) {
+            HIPCHK(c, hipMemcpy(c->pbuf[11], pl.off3_host.data(), pl.off3_host.size() * 8, hipMemcpyHostToDevice));
+            c->off3_uploaded = pl.off3_host;
+        }
         unsigned long long f1[2] = {0, 0}, f2 = 0;
         bool overflowed = false;
+        uint64_t per_batch = 1;
         {
             Timed t(c, TPC_K_QUERY);
             const uint64_t per = pl.n_tiles;
+            per_batch = per;
             for (uint64_t t0 = 0; t0 < tiles && !overflowed; t0 += per) {
                 pl.tile0 = t0;
                 pl.tile0_global = t0;
@@ -500,6 +544,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         int rc = read_counter(c, 1, &n);
         if (rc) return rc;
         overflowed = overflowed || f1[1] != 0 || f2 != 0;
+        c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
+        c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (getenv("TPC_PROFILE_PHASES")) {
             unsigned long long pr[32];
             (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
@@ -512,6 +558,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         }
         // an overflow list overflowed (pathological skew): the direct kernel below rewrites the whole mask
     }
+    if (!part) { c->stat_path[1] = 1; c->stat_batches[1] = 1; }
     HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
     {
         Timed t(c, TPC_K_QUERY);
@@ -835,7 +882,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         TpcPartPlan &pl = c->sh_ipl;
         for (uint64_t batches = 1;; batches *= 2) {
             per = (per_total + batches - 1) / batches;
-            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl))
+            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->sh_world > 1 ? 2 : c->opt_part_levels))
                 return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
             if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
         }
@@ -850,7 +897,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         for (uint64_t batches = 1;; batches *= 2) {
             per = (per_total + batches - 1) / batches;
             const bool fits = per * W * (uint64_t)(512 * TPC_RUN) <= (1ull << 30);  // survivor ids hold a 30-bit position relative to the batch
-            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl);
+            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, 2);
             if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
             if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");

@@ -27,12 +27,16 @@ int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *
 // partitioned insert (tpc_partition.hip)
 struct TpcPartPlan {
     int slice_bits, b1, b2, pos_per_round;
+    int b3 = 0;           // > 0: three levels (filters beyond 2^38 bits at the default slice size)
     uint32_t perm_mult, perm_inv;  // slice-index permutation (tpc_bins.h:PtPerm)
     uint64_t tile0, n_tiles;  // 512-word tiles of the text handled by this batch
     uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
+    uint32_t wpb3 = 1;    // level-3 workgroups per (b1, b2) bucket
     uint64_t cap1, cap2;  // entries per private region (multiples of 32)
+    uint64_t cap3 = 0;
     uint64_t ovf_cap;
     uint32_t *buf1, *cnt1, *buf2, *cnt2;
+    uint32_t *buf3 = nullptr, *cnt3 = nullptr;
     uint64_t *ovf;
     unsigned long long *ovf_cur;  // [0] count, [1] overflow-of-overflow flag
     // filter sharding (tpc_bins.h:PtShard): this rank, number of ranks; the level-1 regions the split
@@ -40,12 +44,14 @@ struct TpcPartPlan {
     uint32_t rank = 0, world = 1;
     const uint32_t *rbuf1 = nullptr, *rcnt1 = nullptr;
 };
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl);  // n_tiles: 512-word tiles per batch
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch; levels 0 = auto
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl);
+size_t tpc_part_buf3_bytes(const TpcPartPlan &pl);
+size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl);
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels = 0);
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
                                   unsigned long long *n_kmers);
 // the two halves of the above, for the sharded path (an all_to_all of the level-1 regions sits between them)
@@ -55,6 +61,14 @@ int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool
 // partitioned query (tpc_qpartition.hip)
 struct TpcQPlan {
     int slice_bits, b1, b2, pos_per_round, sub_rounds, loads;
+    int b3 = 0, loads3 = 1;  // three-level geometry (b3 > 0), as in TpcPartPlan
+    uint32_t wpb3 = 1;
+    uint64_t cap2 = 0;       // three levels: uniform size of the middle regions
+    std::vector<uint64_t> off3_host;  // region offsets of the third level (one region per slice)
+    uint64_t buf3_entries = 0;
+    uint64_t *buf3 = nullptr;
+    uint32_t *cnt3 = nullptr;
+    const uint64_t *off3 = nullptr;
     uint32_t perm_mult, perm_inv;
     uint64_t tile0, n_tiles;
     uint64_t tile0_global = 0;  // first tile of the batch (positions in entries are relative to it; == tile0 unless sharded)
@@ -75,9 +89,9 @@ struct TpcQPlan {
     const uint64_t *rbuf1 = nullptr;
     const uint32_t *rcnt1 = nullptr;
 };
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl);  // n_tiles: 512-word tiles per batch
-size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl);
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch
+size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0);
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 // halves for the sharded path: hash (level 1, marks N-adjacent vertices in rmask), then split + lookup on
 // the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)

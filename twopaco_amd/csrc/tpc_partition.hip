@@ -133,8 +133,9 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
 template <bool SHARDED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
-             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh)
-{
+             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
+{   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
+    // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 16;
@@ -143,8 +144,11 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     bins.init();
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
-    const uint32_t nvw = SHARDED ? nwg1 * sh.world : nwg1;        // source regions: (source rank, workgroup)
-    auto r1 = [=](uint32_t vw) { return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl; };
+    const uint32_t nvw = prev_wpb ? prev_wpb : SHARDED ? nwg1 * sh.world : nwg1;  // source regions: (source rank, workgroup)
+    auto r1 = [=](uint32_t vw) {
+        if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
+        return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl;
+    };
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     const int shift1 = L - LOG_NB1;
     uint32_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
@@ -251,7 +255,7 @@ template <int Q>
 int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_t lo, uint64_t hi, unsigned long long *n_kmers)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const size_t lds = Bins<uint32_t>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
 #define TPC_HASH_GO(G, S)                                                                                                                   \
@@ -269,18 +273,21 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
 int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-    const size_t lds = Bins<uint32_t>::lds_bytes(pl.b2);
     const PtShard sh{pl.rank, pl.world};
-    const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
-    if (pl.world > 1) {
-        (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1, pl.wpb, pl.rbuf1,
-                           pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh);
-        return 0;
-    }
+    const size_t lds = Bins<uint32_t>::lds_bytes(std::max(pl.b2, pl.b3));
+    (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.nwg1, pl.wpb, pl.rbuf1,
-                       pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh);
+    const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
+    const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
+    if (pl.world > 1)
+        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
+    else
+        hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
+    if (pl.b3)  // third level: bucket (b1, b2), input = the regions written above
+        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PT_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
+                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2);
     return 0;
 }
 
@@ -288,21 +295,33 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 
 // Partition geometry for a filter of 2^L bits: slices of 2^slice_bits bits, fan-out split over two
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
-bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl)
+bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels)
 {
-    return tpc_part_plan_sharded(L, q, slice_bits, n_tiles, frac, 0, 1, pl);
+    return tpc_part_plan_sharded(L, q, slice_bits, n_tiles, frac, 0, 1, pl, levels);
 }
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions are sized for the entries of all ranks
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl)
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
     pl.slice_bits = slice_bits;
-    pl.b1 = (F + 1) / 2;
-    pl.b2 = F / 2;
+    // fan-out 2^F over two levels of <= 9 bits, or three when F > 18 (L > 38 at the default slice size) or asked for;
+    // level-1 entries are the L - b1 low address bits in a uint32 below the 0xFFFFFFFF sentinel
+    const bool three = levels == 3 || (levels == 0 && F > 18);
+    if (three) {
+        if (F < 3 || world > 1) return false;  // the sharded path exchanges two-level regions only
+        pl.b1 = std::max((F + 2) / 3, L - 31);
+        pl.b2 = (F - pl.b1 + 1) / 2;
+        pl.b3 = F - pl.b1 - pl.b2;
+        if (pl.b1 > 9 || pl.b2 < 1 || pl.b3 < 1 || pl.b2 > 9) return false;
+    } else {
+        pl.b1 = (F + 1) / 2;
+        pl.b2 = F / 2;
+        pl.b3 = 0;
+    }
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;  // entries are remainders below the 0xFFFFFFFF sentinel
     if (world == 0 || (world & (world - 1)) || world > (1u << pl.b1)) return false;  // ranks own whole buckets
     pl.n_tiles = n_tiles;
@@ -321,6 +340,9 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
     const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
+    pl.wpb3 = 1;
+    const double avg3 = a_max / ((double)(1ull << F) * pl.wpb3);
+    pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
@@ -331,6 +353,8 @@ size_t tpc_part_buf1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * 4; }
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 4; }
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * 4; }
+size_t tpc_part_buf3_bytes(const TpcPartPlan &pl) { return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * pl.cap3 * 4 : 0; }
+size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * 4 : 0; }
 
 int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
 {
@@ -352,11 +376,15 @@ int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool
     int rc;
     if ((rc = launch_split(a, pl))) return rc;
     const size_t lds = (size_t)4 << (pl.slice_bits - 5);
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     (void)hipFuncSetAttribute((const void *)k_part_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const PtShard sh{pl.rank, pl.world};
-    hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                       pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+    if (pl.b3)  // regions of the third level: [(b1, b2)][j][b3]
+        hipLaunchKernelGGL(k_part_apply, dim3(1u << (pl.b1 + pl.b2 + pl.b3)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+                           pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh);
+    else
+        hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                           pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
     hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2);
     return 0;
 }

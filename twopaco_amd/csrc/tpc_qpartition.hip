@@ -190,8 +190,8 @@ template <bool SHARDED>
 __global__ void __launch_bounds__(PT_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
-          PtShard sh)
-{
+          PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
+{   // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 8;
@@ -202,8 +202,11 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     for (uint32_t i = threadIdx.x; i <= NB2; i += PT_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
-    const uint32_t nvw = SHARDED ? nwg1 * sh.world : nwg1;        // source regions: (source rank, workgroup)
-    auto r1 = [=](uint32_t vw) { return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl; };
+    const uint32_t nvw = prev_wpb ? prev_wpb : SHARDED ? nwg1 * sh.world : nwg1;  // source regions: (source rank, workgroup)
+    auto r1 = [=](uint32_t vw) {
+        if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
+        return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl;
+    };
     const int shift1 = L - LOG_NB1;
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
     // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
@@ -500,7 +503,7 @@ template <int Q>
 void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
 {
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
 #define TPC_QHASH_GO(G, S)                                                                                                                  \
@@ -524,14 +527,14 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 
 }  // namespace
 
-bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl)
+bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels)
 {
-    return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl);
+    return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl, levels);
 }
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions cover the slices this rank owns and are sized
 // for the entries of all ranks
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl)
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
@@ -539,8 +542,18 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     if (F < 2 || slice_bits < 6 || slice_bits > 20) return false;
     if (n_text > (1ull << 30)) return false;  // an entry holds a 30-bit position relative to the batch
     pl.slice_bits = slice_bits;
-    pl.b1 = (F + 1) / 2;
-    pl.b2 = F / 2;
+    const bool three = levels == 3 || (levels == 0 && F > 18);  // as in tpc_part_plan_sharded
+    if (three) {
+        if (F < 3 || world > 1) return false;
+        pl.b1 = std::max((F + 2) / 3, L - 31);
+        pl.b2 = (F - pl.b1 + 1) / 2;
+        pl.b3 = F - pl.b1 - pl.b2;
+        if (pl.b1 > 9 || pl.b2 < 1 || pl.b3 < 1 || pl.b2 > 9) return false;
+    } else {
+        pl.b1 = (F + 1) / 2;
+        pl.b2 = F / 2;
+        pl.b3 = 0;
+    }
     if (pl.b1 > 9 || L - pl.b1 > 31) return false;
     if (world == 0 || (world & (world - 1)) || world > (1u << pl.b1)) return false;  // ranks own whole buckets
     pl.n_tiles = n_tiles;
@@ -553,7 +566,12 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     const int ppr = (int)(budget / (1024 * 6 * std::max(frac, 1.0 / 64)));
     pl.pos_per_round = ppr >= 16 ? 16 : ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     pl.sub_rounds = ppr >= 1 ? 1 : std::min(16, (1024 * 6 + budget - 1) / budget);
-    pl.loads = std::max(1, std::min(8, budget * 9 / 8 / PT_THREADS / 2));  // k_q_split entries per thread per round (level-2 bins see a 2x skew)
+    // k_q_split entries per thread per round for a level with 2^bits bins (the last level's bins see a 2x skew)
+    auto loads_for = [](int bits) {
+        const int c = (PT_BIN_BYTES / 8) >> bits;
+        return std::max(1, std::min(8, std::max(1, (1 << bits) * (c - 16) * 5 / 8) * 9 / 8 / PT_THREADS / 2));
+    };
+    pl.loads = loads_for(pl.b3 ? pl.b2 : pl.b1);
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
@@ -561,22 +579,41 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
-    // level-2 region sizes: a region is one filter slice, and every query address is a function-0 address
-    // whose density over the slices falls linearly from 2x to 0 (tpc_bins.h)
-    const uint64_t nreg = (uint64_t)((1u << pl.b1) / world) * pl.wpb * (1u << pl.b2);  // local regions
-    const double avg2 = a_max * world / ((double)nreg * world);  // entries of all ranks over all regions
+    // Region sizes of the LAST level: a region is one filter slice, and every query address is a function-0
+    // address whose density over the slices falls linearly from 2x to 0 (tpc_bins.h).  With three levels the
+    // middle regions each collect 2^b3 slices spread over the whole filter by the permutation: uniform.
     const double S = (double)(1ull << F);
-    pl.off2_host.resize(nreg + 1);
-    uint64_t o = 0;
-    for (uint64_t r = 0; r < nreg; r++) {
-        const uint32_t bl = (uint32_t)(r / ((uint64_t)pl.wpb << pl.b2)), b2 = (uint32_t)(r & ((1u << pl.b2) - 1));
-        const uint32_t s = pm.slice_of(((bl * world + rank) << pl.b2) | b2);  // the filter slice behind this region
-        const double d = avg2 * 2.0 * (1.0 - ((double)s + 0.5) / S) + avg2 * 0.02;
-        pl.off2_host[r] = o;
-        o += ((uint64_t)(d * 1.25 + 8 * std::sqrt(d) + 96) + 15) & ~15ull;
+    auto slice_table = [&](std::vector<uint64_t> &off, uint64_t nreg, int log_last, uint32_t wpb_last, double avg) {
+        off.resize(nreg + 1);
+        uint64_t o = 0;
+        for (uint64_t r = 0; r < nreg; r++) {
+            const uint32_t bl = (uint32_t)(r / ((uint64_t)wpb_last << log_last)), bb = (uint32_t)(r & ((1u << log_last) - 1));
+            const uint32_t s = pm.slice_of(((world > 1 ? bl * world + rank : bl) << log_last) | bb);  // the filter slice behind this region
+            const double d = avg * 2.0 * (1.0 - ((double)s + 0.5) / S) + avg * 0.02;
+            off[r] = o;
+            o += ((uint64_t)(d * 1.25 + 8 * std::sqrt(d) + 96) + 15) & ~15ull;
+        }
+        off[nreg] = o;
+        return o;
+    };
+    const uint64_t nreg2 = (uint64_t)((1u << pl.b1) / world) * pl.wpb * (1u << pl.b2);  // local regions
+    const double avg2 = a_max * world / ((double)nreg2 * world);  // entries of all ranks over all regions
+    pl.wpb3 = 1;
+    pl.loads3 = pl.loads;
+    if (pl.b3) {
+        pl.cap2 = ((uint64_t)(avg2 * 1.3 + 8 * std::sqrt(avg2) + 128) + 15) & ~15ull;
+        pl.off2_host.resize(nreg2 + 1);
+        for (uint64_t r = 0; r <= nreg2; r++) pl.off2_host[r] = r * pl.cap2;
+        pl.buf2_entries = nreg2 * pl.cap2;
+        const uint64_t nreg3 = (uint64_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3);
+        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_max / (double)nreg3);
+        pl.loads3 = loads_for(pl.b3);
+    } else {
+        pl.cap2 = 0;
+        pl.buf2_entries = slice_table(pl.off2_host, nreg2, pl.b2, pl.wpb, avg2);
+        pl.off3_host.clear();
+        pl.buf3_entries = 0;
     }
-    pl.off2_host[nreg] = o;
-    pl.buf2_entries = o;
     return true;
 }
 
@@ -592,6 +629,9 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     case 6: return (size_t)QS_LISTS * pl.surv_cap * 8;
     case 7: return (QS_LISTS + 1) * sizeof(unsigned long long);
     case 8: return pl.off2_host.size() * 8;
+    case 9: return (size_t)pl.buf3_entries * 8;
+    case 10: return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * 4 : 0;
+    case 11: return pl.off3_host.size() * 8;
     }
     return 0;
 }
@@ -614,27 +654,34 @@ int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t 
 
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 {
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-        const size_t lds = Bins<uint64_t>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
-        if (pl.world > 1) {
-            (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L,
-                               pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh);
-        } else {
-            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L,
-                               pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh);
-        }
+        const size_t lds = Bins<uint64_t>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
+        (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
+        if (pl.world > 1)
+            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
+        else
+            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
+        if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
+            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PT_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
+                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                           pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
+        if (pl.b3)
+            hipLaunchKernelGGL(k_q_lookup, dim3(1u << (pl.b1 + pl.b2 + pl.b3)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+                               pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
+        else
+            hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                               pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
                        sh, pl.b2);
@@ -670,7 +717,7 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
 {
     if (fn < 0 || fn_count < 1 || fn + fn_count > a.P.q) return -1;
     if (n == 0) return 0;
-    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
