@@ -137,11 +137,11 @@ def main():
     # measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
     # MI355X_MICROARCH.md prescribes) -- only valid for the workload they were collected on
     traffic_ins = traffic_qry = None
-    pmc = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")  # tools/profile_round.sh + tools/pmc_traffic.py
     if os.path.exists(pmc) and args.workload == "m2" and args.scale == 1.0:
         with open(pmc) as f:
             t = json.load(f)
-        traffic_ins, traffic_qry = t["insert_hbm_bytes_per_launch"], t["query_hbm_bytes_per_launch"]
+        traffic_ins, traffic_qry = t["groups"]["insert"], t["groups"]["query"]
     b_ins = 0.25 + p["q"] * 2 * G_BYTES     # RFO + write-back of one granule per probe
     b_chk = 0.375 + 6 * G_BYTES            # ~6 absent-edge probes per k-mer
     ach_ins = n_kmers * b_ins / (kms["insert"] * 1e-3) / 1e9

@@ -149,7 +149,10 @@ class PackedText:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     @classmethod
     def from_fasta(cls, files, threads=1):
@@ -205,7 +208,10 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def _ck(self, rc):
         if rc != 0:
@@ -395,7 +401,10 @@ class Enumerator:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def vertices_count(self):
         return host().tpch_vertices_count(self._h)
