@@ -72,10 +72,13 @@ def test_text_packer_from_codes_and_threads(capi, tmp_path):
     assert synth.n_kmers(recs, 25) == sum(r.size - 24 for r in recs)
 
 
-@pytest.mark.parametrize("threads", [1, 5])
-def test_text_packer_ragged_records_in_parallel(capi, tmp_path, threads):
+@pytest.mark.parametrize("threads,piece", [(1, None), (5, None), (4, 37), (3, 1)])
+def test_text_packer_ragged_records_in_parallel(capi, tmp_path, threads, piece, monkeypatch):
     """Many short and empty records (several per packed word), N runs, lower case, over several files: the
-    parallel placement (host/textpack.cpp) must give the text of the sequential from_codes path."""
+    parallel pieces (host/textpack.cpp; `piece` bytes each, so records are cut at arbitrary places, inside lines
+    and packed words) must give the text of the sequential from_codes path."""
+    if piece is not None:
+        monkeypatch.setenv("TWOPACO_PARSE_PIECE", str(piece))
     rng = np.random.default_rng(7)
     letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
     files, recs = [], []

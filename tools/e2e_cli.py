@@ -10,10 +10,15 @@ threads = sys.argv[2] if len(sys.argv) > 2 else str(min(64, os.cpu_count()))
 recs, p = synth.workload(wl)
 tmp = tempfile.mkdtemp(dir="/tmp")
 files = []
-for i, r in enumerate(recs):
-    f = os.path.join(tmp, "g%d.fa" % i)
-    synth.write_fasta(f, [r], first_id=i)
+if os.environ.get("E2E_SINGLE_FILE"):  # every genome a record of one big file (exercises within-file parallel parsing)
+    f = os.path.join(tmp, "all.fa")
+    synth.write_fasta(f, recs)
     files.append(f)
+else:
+    for i, r in enumerate(recs):
+        f = os.path.join(tmp, "g%d.fa" % i)
+        synth.write_fasta(f, [r], first_id=i)
+        files.append(f)
 exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
 out = os.path.join(tmp, "out.bin")
 pause = float(os.environ.get("E2E_PAUSE", "3"))  # the driver releases the previous process's 30+ GiB asynchronously: measure isolated runs

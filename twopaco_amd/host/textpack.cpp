@@ -1,6 +1,12 @@
 #include "textpack.h"
 
 #include <algorithm>
+#include <cctype>
+#include <sstream>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <atomic>
 #include <cstring>
 #include <functional>
@@ -111,91 +117,313 @@ namespace TwoPaCo
 		AppendCodes(&n, 1);
 	}
 
-	void PackFastaFiles(const std::vector<std::string> & fileName, size_t threads, PackedText & out)
+	namespace
 	{
-		// per file: the records' code strings
-		struct Record { std::vector<uint64_t> bases; std::vector<uint32_t> nmask; uint64_t n; };
-		struct Parsed { std::vector<Record> records; std::unique_ptr<StreamFastaParser::Exception> error; };
-		std::vector<Parsed> parsed(fileName.size());
-		std::atomic<size_t> next(0);
-		auto work = [&]()
+		// character classes of the reference's parser (streamfastaparser.cpp:61-93): 0..3 = ACGT, 4 = another valid
+		// letter (N after VertexEnumerator's mapping, vertexenumerator.h:1174), 5 = whitespace, 6 = '>', 7 = invalid
+		struct PackClass
 		{
-			for (size_t f = next++; f < fileName.size(); f = next++)
+			uint8_t t[256];
+			PackClass()
 			{
-				try
+				for (int c = 0; c < 256; c++)
 				{
-					StreamFastaParser parser(fileName[f]);
-					while (parser.ReadRecord())
-					{
-						parsed[f].records.emplace_back();
-						Record & rec = parsed[f].records.back();
-						rec.n = parser.ReadSequencePacked(rec.bases, rec.nmask);
-					}
+					const int up = std::toupper(c);
+					if (std::isspace(c)) t[c] = 5;
+					else if (c == '>') t[c] = 6;
+					else if (up == 'A') t[c] = 0;
+					else if (up == 'C') t[c] = 1;
+					else if (up == 'G') t[c] = 2;
+					else if (up == 'T') t[c] = 3;
+					else if (up != 0 && std::strchr("URYKMSWBDHWNXV", up)) t[c] = 4;
+					else t[c] = 7;
 				}
-				catch (const StreamFastaParser::Exception & e)
+			}
+		};
+		const PackClass PACK;
+
+		typedef std::vector<char, DefaultInitAllocator<char> > Bytes;
+
+		struct InputFile
+		{
+			const char * data;      // the file's bytes: a private mapping of the page cache, or `owned` for pipes
+			size_t size;
+			bool mapped;
+			Bytes owned;
+			std::string error;      // first error of the file, in byte order
+			size_t errorAt;
+			InputFile() : data(0), size(0), mapped(false), errorAt(size_t(-1)) {}
+			void Release()
+			{
+				if (mapped && data) ::munmap(const_cast<char*>(data), size);
+				data = 0;
+				mapped = false;
+				Bytes().swap(owned);
+			}
+
+			void Fail(size_t at, const std::string & what)
+			{
+				if (at < errorAt)
 				{
-					parsed[f].error.reset(new StreamFastaParser::Exception(e.what()));
+					errorAt = at;
+					error = what;
 				}
 			}
 		};
 
-		size_t workers = threads < 1 ? 1 : (threads < fileName.size() ? threads : fileName.size());
-		if (workers <= 1)
+		// a run of sequence bytes of one record, packed on its own and placed later
+		struct Piece
 		{
-			work();
+			size_t file, record;      // record: index over all records of all files
+			size_t begin, end;        // byte range in the file
+			std::string header;
+			std::vector<uint64_t> bases;
+			std::vector<uint32_t> nmask;
+			uint64_t n;
+			Piece() : n(0) {}
+		};
+
+		void PackPiece(const InputFile & in, Piece & p, size_t & errorAt, std::string & error)
+		{
+			const unsigned char * d = reinterpret_cast<const unsigned char*>(in.data);
+			uint64_t word = 0;
+			uint32_t mask = 0;
+			unsigned fill = 0;
+			p.bases.reserve((p.end - p.begin) / 32 + 2);
+			p.nmask.reserve((p.end - p.begin) / 32 + 2);
+			for (size_t i = p.begin; i < p.end; ++i)
+			{
+				const uint8_t cls = PACK.t[d[i]];
+				if (cls <= 4)
+				{
+					word |= uint64_t(cls & 3) << (2 * fill);
+					mask |= uint32_t(cls >> 2) << fill;
+					if (++fill == 32)
+					{
+						p.bases.push_back(word);
+						p.nmask.push_back(mask);
+						word = 0; mask = 0; fill = 0;
+					}
+
+					++p.n;
+				}
+				else if (cls == 7)
+				{
+					errorAt = i;
+					error = "Found an invalid character '" + std::string(1, char(d[i])) + "' in sequence " + p.header;
+					return;
+				}
+			}
+
+			if (fill)
+			{
+				p.bases.push_back(word);
+				p.nmask.push_back(mask);
+			}
 		}
-		else
+	}
+
+	// All files are read, indexed (records end at the next '>', streamfastaparser.cpp:61-76), cut into pieces of a few MiB
+	// and packed by `threads` workers, whatever the number of files and the size of their records; the layout of
+	// T = N rec0 N rec1 N ... follows from the piece lengths, so the pieces are then placed by all threads at once.
+	void PackFastaFiles(const std::vector<std::string> & fileName, size_t threads, PackedText & out)
+	{
+		const size_t team = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+		auto parallel = [team](size_t items, const std::function<void(size_t)> & fn)
 		{
+			if (team <= 1 || items <= 1)
+			{
+				for (size_t i = 0; i < items; i++) fn(i);
+				return;
+			}
+
+			std::atomic<size_t> cursor(0);
 			std::vector<std::thread> pool;
-			for (size_t i = 0; i < workers; i++) pool.emplace_back(work);
-			for (std::thread & t : pool) t.join();
+			for (size_t t = 0; t < std::min(team, items); t++)
+			{
+				pool.emplace_back([&]() { for (size_t i = cursor++; i < items; i = cursor++) fn(i); });
+			}
+
+			for (std::thread & th : pool) th.join();
+		};
+
+		const bool timing = std::getenv("TWOPACO_TIMING") != 0;
+		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+		auto lap = [&](const char * what)
+		{
+			if (!timing) return;
+			const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+			std::fprintf(stderr, "[timing]   parse: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+			t0 = t1;
+		};
+
+		size_t pieceBytes = size_t(4) << 20;
+		if (const char * e = std::getenv("TWOPACO_PARSE_PIECE")) pieceBytes = std::max<size_t>(1, size_t(std::atoll(e)));
+
+		// 1. map: the files' page-cache pages are mapped (no copy); pipes and devices are read to the end
+		std::vector<InputFile> input(fileName.size());
+		parallel(fileName.size(), [&](size_t f)
+		{
+			InputFile & in = input[f];
+			const int fd = ::open(fileName[f].c_str(), O_RDONLY);
+			struct stat st;
+			if (fd < 0 || ::fstat(fd, &st) != 0)
+			{
+				if (fd >= 0) ::close(fd);
+				in.Fail(0, "Can't open file " + fileName[f]);
+				return;
+			}
+
+			if (S_ISREG(st.st_mode) && st.st_size > 0)
+			{
+				void * m = ::mmap(0, size_t(st.st_size), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+				if (m != MAP_FAILED)
+				{
+					in.data = static_cast<const char*>(m);
+					in.size = size_t(st.st_size);
+					in.mapped = true;
+					::close(fd);
+					return;
+				}
+			}
+
+			char buf[1 << 16];
+			for (ssize_t got; (got = ::read(fd, buf, sizeof(buf))) > 0;) in.owned.insert(in.owned.end(), buf, buf + got);
+			::close(fd);
+			in.data = in.owned.data();
+			in.size = in.owned.size();
+		});
+		lap("read");
+
+		// 2. index the records of every file (memchr speed) and cut their sequence bytes into pieces
+		std::vector<std::vector<Piece> > filePieces(fileName.size());
+		std::vector<size_t> fileRecords(fileName.size(), 0);
+		parallel(fileName.size(), [&](size_t f)
+		{
+			InputFile & in = input[f];
+			if (!in.error.empty()) return;
+			const char * d = in.data;
+			const size_t size = in.size;
+			size_t pos = 0;
+			while (pos < size)
+			{
+				if (d[pos] != '>')
+				{
+					in.Fail(pos, "The FASTA header should start with a '>', started with '" + std::string(1, d[pos]) + "'");
+					return;
+				}
+
+				const char * nl = static_cast<const char*>(std::memchr(d + pos + 1, '\n', size - pos - 1));
+				Piece first;
+				first.file = f;
+				first.record = fileRecords[f]++;
+				if (!nl)
+				{
+					// header without a newline: a record without sequence (the reference reaches the end of input)
+					first.begin = first.end = size;
+					filePieces[f].push_back(first);
+					return;
+				}
+
+				std::stringstream ss(std::string(d + pos + 1, nl));
+				ss >> first.header;
+				const size_t seqBegin = size_t(nl - d) + 1;
+				const char * gt = static_cast<const char*>(std::memchr(d + seqBegin, '>', size - seqBegin));
+				const size_t seqEnd = gt ? size_t(gt - d) : size;
+				size_t b = seqBegin;
+				do
+				{
+					Piece p;
+					p.file = f;
+					p.record = first.record;
+					p.header = first.header;
+					p.begin = b;
+					p.end = std::min(seqEnd, b + pieceBytes);
+					filePieces[f].push_back(p);
+					b = p.end;
+				}
+				while (b < seqEnd);
+				pos = seqEnd;
+			}
+		});
+
+		lap("index");
+		std::vector<Piece> piece;
+		{
+			size_t recordBase = 0;
+			for (size_t f = 0; f < fileName.size(); f++)
+			{
+				for (Piece & p : filePieces[f])
+				{
+					p.record += recordBase;
+					piece.push_back(std::move(p));
+				}
+
+				recordBase += fileRecords[f];
+				std::vector<Piece>().swap(filePieces[f]);
+			}
 		}
 
+		// 3. pack the pieces
+		std::vector<size_t> pieceErrorAt(piece.size(), size_t(-1));
+		std::vector<std::string> pieceError(piece.size());
+		parallel(piece.size(), [&](size_t i) { PackPiece(input[piece[i].file], piece[i], pieceErrorAt[i], pieceError[i]); });
+		lap("pack");
+		for (size_t i = 0; i < piece.size(); i++)
+		{
+			if (pieceErrorAt[i] != size_t(-1)) input[piece[i].file].Fail(pieceErrorAt[i], pieceError[i]);
+		}
+
+		parallel(fileName.size(), [&](size_t f) { input[f].Release(); });
 		for (size_t f = 0; f < fileName.size(); f++)
 		{
-			if (parsed[f].error)
+			if (!input[f].error.empty())
 			{
-				throw *parsed[f].error;
+				throw StreamFastaParser::Exception(input[f].error);
 			}
 		}
 
-		// Layout of T = N rec0 N rec1 N ...: every record's start follows from the lengths alone, so the records are
-		// placed by all threads at once.  A destination word inside one record is written by that record's thread
-		// only; the first and last word of its span may be shared with the neighbours and are OR-ed atomically.
-		struct Placed { const Record * rec; uint64_t start; };
-		std::vector<Placed> placed;
+		lap("free input");
+		// 4. layout: a record's pieces follow each other, records are separated by one N
+		size_t records = 0;
+		for (const Piece & p : piece) records = std::max(records, p.record + 1);
+		out.recStart.assign(records, 0);
+		out.recLength.assign(records, 0);
+		std::vector<uint64_t> start(piece.size());
 		uint64_t length = 1;
-		for (Parsed & p : parsed)
+		for (size_t i = 0; i < piece.size(); i++)
 		{
-			for (Record & rec : p.records)
-			{
-				placed.push_back(Placed{&rec, length});
-				length += rec.n + 1;
-			}
+			if (i > 0 && piece[i].record != piece[i - 1].record) ++length;  // separator after the previous record
+			if (i == 0 || piece[i].record != piece[i - 1].record) out.recStart[piece[i].record] = length;
+			start[i] = length;
+			length += piece[i].n;
+			out.recLength[piece[i].record] += piece[i].n;
 		}
 
+		if (!piece.empty()) ++length;  // trailing separator
 		const uint64_t words = (length + 31) / 32;
 		out.bases.clear();
 		out.nmask.clear();
 		out.bases.resize(words);  // uninitialised (DefaultInitAllocator): zeroed below, in parallel
 		out.nmask.resize(words);
-		out.recStart.resize(placed.size());
-		out.recLength.resize(placed.size());
 		out.length = length;
 		uint64_t * const B = out.bases.data();
 		uint32_t * const M = out.nmask.data();
 		auto setN = [M](uint64_t g) { __atomic_fetch_or(&M[g >> 5], uint32_t(1) << (g & 31), __ATOMIC_RELAXED); };
-		auto place = [&](const Placed & p)
+		// A destination word inside one piece is written by that piece's thread only; the first and last word of its span
+		// may be shared with the neighbours and are OR-ed atomically.
+		auto place = [&](size_t idx)
 		{
-			const uint64_t n = p.rec->n;
-			setN(p.start + n);  // trailing separator
+			const Piece & p = piece[idx];
+			const uint64_t n = p.n;
+			if (idx + 1 == piece.size() || piece[idx + 1].record != p.record) setN(start[idx] + n);  // separator after the record
 			if (n == 0) return;
-			const uint64_t * b = p.rec->bases.data();
-			const uint32_t * m = p.rec->nmask.data();
-			const uint64_t w0 = p.start >> 5;
-			const unsigned o = unsigned(p.start & 31);
+			const uint64_t * b = p.bases.data();
+			const uint32_t * m = p.nmask.data();
+			const uint64_t w0 = start[idx] >> 5;
+			const unsigned o = unsigned(start[idx] & 31);
 			const uint64_t nw = (n + 31) / 32;
-			const uint64_t last = (p.start + n - 1) >> 5;  // last destination word holding a character of the record
+			const uint64_t last = (start[idx] + n - 1) >> 5;
 			for (uint64_t j = w0; j <= last; j++)
 			{
 				const uint64_t i = j - w0;
@@ -226,26 +454,6 @@ namespace TwoPaCo
 			}
 		};
 
-		// phase 1: zero fill in parallel chunks (span ends are OR-ed into); phase 2: place the records
-		const size_t team = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
-		auto parallel = [team](size_t items, const std::function<void(size_t)> & fn)
-		{
-			if (team <= 1 || items <= 1)
-			{
-				for (size_t i = 0; i < items; i++) fn(i);
-				return;
-			}
-
-			std::atomic<size_t> cursor(0);
-			std::vector<std::thread> pool;
-			for (size_t t = 0; t < std::min(team, items); t++)
-			{
-				pool.emplace_back([&]() { for (size_t i = cursor++; i < items; i = cursor++) fn(i); });
-			}
-
-			for (std::thread & th : pool) th.join();
-		};
-
 		const uint64_t CHUNK = uint64_t(1) << 18;  // words
 		parallel(size_t((words + CHUNK - 1) / CHUNK), [&](size_t c)
 		{
@@ -253,12 +461,9 @@ namespace TwoPaCo
 			std::memset(B + a, 0, (e - a) * sizeof(uint64_t));
 			std::memset(M + a, 0, (e - a) * sizeof(uint32_t));
 		});
+		lap("zero");
 		setN(0);  // leading separator
-		parallel(placed.size(), [&](size_t r)
-		{
-			place(placed[r]);
-			out.recStart[r] = placed[r].start;
-			out.recLength[r] = placed[r].rec->n;
-		});
+		parallel(piece.size(), place);
+		lap("place");
 	}
 }
