@@ -528,9 +528,65 @@ def test_partitioned_paths_large_filters(capi, L):
     assert (res[0][1] == res[1][1]).all() and (res[0][3] == res[1][3]).all()
 
 
+def test_randomized_partition_geometries_vs_oracle(capi, tmp_path):
+    """Random texts x random partition geometries (slice size, two / three levels, tile batches, gated vertex-hash
+    ranges, q, k): the LDS write-combining insert and query give the oracle's Bloom bitmap, candidate mask and count."""
+    trials = int(os.environ.get("TPC_SOAK_TRIALS", "60"))
+    rng = np.random.default_rng(424242)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    code_of = np.zeros(256, dtype=np.uint8)
+    code_of[letters] = np.arange(5, dtype=np.uint8)
+    done = 0
+    for trial in range(trials):
+        k = int(rng.choice([5, 9, 15, 25, 31, 33, 47]))
+        L = int(rng.integers(12, 25))
+        q = int(rng.integers(1, 9))
+        slice_bits = int(rng.integers(6, min(14, L - 3) + 1))
+        levels = int(rng.choice([2, 3]))
+        base = alphabet[rng.integers(0, 4, int(rng.integers(2000, 60000)))].copy()
+        recs = []
+        for r in range(int(rng.integers(1, 6))):
+            s = base.copy()
+            hits = rng.random(s.size) < 0.02
+            s[hits] = alphabet[rng.integers(0, 4, int(hits.sum()))]
+            if rng.random() < 0.5:
+                for _ in range(int(rng.integers(1, 4))):
+                    a = int(rng.integers(0, s.size)); s[a:a + int(rng.integers(1, 60))] = ord("N")
+            if rng.random() < 0.2:
+                s[:int(rng.integers(1, s.size))] = ord("A")  # skew
+            recs.append(code_of[s])
+        seed = int(rng.integers(1, 1 << 40))
+        o = O.Oracle(k, L, q, O.seed_table(seed, q, L))
+        for r in recs:
+            o.add_record(letters[r].tobytes())
+        ctx = capi.Context(0)
+        for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", slice_bits), ("part_levels", levels), ("part_min_tiles", 1),
+                         ("part_budget_bytes", int(rng.choice([40 << 30, 1 << 20, 200 << 10])))):
+            ctx.set_option(opt, val)
+        ctx.set_params(k, L, q, capi.seed_table(q, L, seed=seed))
+        ctx.seq_upload(capi.PackedText.from_codes(recs))
+        size = 1 << L
+        cut = sorted(int(x) for x in rng.integers(0, size, 2))
+        for lo, hi in [(0, size), (cut[0], cut[1]), (0, cut[0])]:
+            o.fill_only(lo, hi)
+            marks = o.check_only(lo, hi)
+            ctx.filter_reset()
+            ctx.pass1_insert(lo, hi)
+            tag = (trial, k, L, q, slice_bits, levels, lo, hi, ctx.stat("insert_path"), ctx.stat("insert_batches"))
+            assert (ctx.filter_download() == o.filter).all(), tag
+            assert ctx.pass1_query(lo, hi) == marks, tag
+            assert (ctx.mask_download(False) == o.round_mask).all(), tag
+            if ctx.stat("insert_path") % 10 in (2, 3):
+                done += 1
+        ctx.close()
+        o.close()
+    assert done >= trials  # the geometry was accepted in at least a third of the rounds (tiny filters fall back to the direct kernels)
+
+
 def test_randomized_differential_vs_oracle(capi, tmp_path):
     """40 random configurations (sequence set with N runs / IUPAC / lower case / short records, odd and even k,
-    L, q, rounds, abundance, forced kernel paths): CreateEnumerator's de_bruijn.bin == the oracle's, byte for byte."""
+    L, q, rounds, abundance): CreateEnumerator's de_bruijn.bin == the oracle's, byte for byte."""
     rng = np.random.default_rng(20240607)
     alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
     for trial in range(40):
