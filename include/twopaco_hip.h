@@ -201,6 +201,9 @@ int tpc_mask_merge(tpc_ctx *ctx, const uint32_t *src_dev, uint32_t count);
 /* ---- parity taps (debug; used by tests/) ---------------------------------------------- */
 uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 (sharded: 2^L/32/world) */
 int tpc_filter_download(tpc_ctx *ctx, uint32_t *words_host); /* tpc_filter_words words       */
+/* Restore a downloaded filter (the reference's commented-out ReloadBloomFilter, VE.h:29,113-121): a
+ * checkpoint of the most expensive state of a run; the next tpc_pass1_query uses these bits. */
+int tpc_filter_upload(tpc_ctx *ctx, const uint32_t *words_host);
 uint64_t tpc_mask_words(const tpc_ctx *ctx);                 /* n_text/32 + 1                 */
 int tpc_mask_download(tpc_ctx *ctx, int run_wide, uint32_t *words_host);
 /* Vertex hashes of the windows at g0..g0+n-1: out[(g-g0)*2q + 2i] = pos_i, +1 = neg_i. */

@@ -396,6 +396,35 @@ def test_cli_pipeline_twopaco_then_graphdump(tmp_path):
         assert "".join(spelled) == letters[rec].tobytes().decode()
 
 
+def test_filter_checkpoint_restore(capi, tmp_path):
+    """tpc_filter_download / tpc_filter_upload: a second context that restores the first one's Bloom filter (and
+    one that restores the ORACLE's bitmap) continues with the query and ends with the same output."""
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp"][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    table = capi.seed_table(case["q"], case["L"], seed=case["seed"])
+    a = capi.Context(0)
+    a.set_params(case["k"], case["L"], case["q"], table)
+    a.seq_upload(text)
+    a.filter_reset()
+    a.pass1_insert()
+    saved = a.filter_download()
+    marks = a.pass1_query()
+    mask = a.mask_download(False)
+    o.fill_only()
+    for bits in (saved, np.array(o.filter)):
+        b = capi.Context(0)
+        b.set_params(case["k"], case["L"], case["q"], table)
+        b.seq_upload(text)
+        b.filter_reset()
+        b.filter_upload(bits)
+        assert b.pass1_query() == marks and (b.mask_download(False) == mask).all()
+        st = b.pass2_filter()
+        assert b.junctions_finalize() == case["distinct"] and st["true"] == case["distinct"]
+        b.close()
+    a.close()
+
+
 def test_cli_selftest(tmp_path):
     """twopaco --test: the reference's randomized differential self-test (test.cpp), shortened via env."""
     import subprocess

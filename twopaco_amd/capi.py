@@ -20,7 +20,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
-               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat"]
+               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload"]
 
 _hip = None
 _host = None
@@ -62,6 +62,7 @@ def hip():
         L.tpc_filter_words.restype = u64
         L.tpc_filter_words.argtypes = [p]
         L.tpc_filter_download.argtypes = [p, p]
+        L.tpc_filter_upload.argtypes = [p, p]
         L.tpc_mask_words.restype = u64
         L.tpc_mask_words.argtypes = [p]
         L.tpc_mask_download.argtypes = [p, ci, p]
@@ -315,6 +316,11 @@ class Context:
         w = np.zeros(hip().tpc_filter_words(self._h), dtype=np.uint32)
         self._ck(hip().tpc_filter_download(self._h, w.ctypes.data))
         return w
+
+    def filter_upload(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        assert w.size == hip().tpc_filter_words(self._h)
+        self._ck(hip().tpc_filter_upload(self._h, w.ctypes.data))
 
     def mask_download(self, run_wide=False):
         w = np.zeros(hip().tpc_mask_words(self._h), dtype=np.uint32)

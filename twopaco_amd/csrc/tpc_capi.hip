@@ -1105,6 +1105,16 @@ int tpc_filter_download(tpc_ctx *c, uint32_t *words_host)
     return 0;
 }
 
+int tpc_filter_upload(tpc_ctx *c, const uint32_t *words_host)
+{
+    if (!c || !c->filter || !words_host) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->filter, words_host, c->filter_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->filter_zero_pending = false;  // the uploaded bits are the filter now
+    return 0;
+}
+
 uint64_t tpc_mask_words(const tpc_ctx *c) { return c ? c->n_words : 0; }
 
 int tpc_mask_download(tpc_ctx *c, int run_wide, uint32_t *words_host)
