@@ -218,7 +218,8 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *   insert_mode / query_mode   0 = automatic, 1 = direct scattered kernel, 2 = LDS write-combining passes
  *   slice_bits         log2 bits of a filter slice held in LDS (6..20, default 20)
  *   part_levels        0 = automatic (three binning levels when L - slice_bits > 18), 2, 3
- *   part_budget_bytes  partition buffers per tile batch (default 40 GiB); part_min_tiles  smallest batch */
+ *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 45 % of the free device
+ *                      memory when that is more); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);

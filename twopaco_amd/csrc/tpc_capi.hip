@@ -70,7 +70,7 @@ struct tpc_ctx {
     int stat_path[2] = {0, 0};       // 1 direct kernel, 2 / 3 partitioned with that many levels (+10: partitioned, then completed by the direct kernel)
     int64_t stat_batches[2] = {0, 0};
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
-    int64_t opt_part_budget = (int64_t)40 << 30;  // bytes of partition buffers per batch (first ~48 GiB of hipMalloc are cheap)
+    int64_t opt_part_budget = 0;  // bytes of partition buffers per batch; 0 = automatic (part_budget())
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
@@ -182,6 +182,18 @@ uint64_t filter_words_for(int L, uint32_t world)
     return std::max<uint64_t>(1, ((1ull << L) >> 5) / world) + 1;
 }
 
+// Buffer budget of one tile batch.  Automatic: 40 GiB (the first ~48 GiB of hipMalloc are cheap on this system), more when
+// the device has room -- fewer batches mean fewer passes over the filter (45 % of what is free plus what is already held).
+int64_t part_budget(const tpc_ctx *c)
+{
+    if (c->opt_part_budget > 0) return c->opt_part_budget;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (int64_t)40 << 30; }
+    size_t held = 0;
+    for (size_t b : c->pbytes) held += b;
+    return std::max<int64_t>((int64_t)40 << 30, (int64_t)((double)(free_b + held) * 0.45));
+}
+
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
 // Tile batching of the partitioned query under the buffer budget; false: use the direct kernel.
@@ -189,11 +201,12 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
 {
     const uint64_t tiles = text_tiles512(c);
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
+    const int64_t budget = part_budget(c);
     for (uint64_t batches = 1;; batches *= 2) {
         const uint64_t per = (tiles + batches - 1) / batches;
         const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl, c->opt_part_levels);
         if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) return false;  // geometry unsupported (not a size problem)
-        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) {
+        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= budget || (int64_t)per <= c->opt_part_min_tiles)) {
             // Every batch streams the whole filter through LDS once.  That pays while a slice sees a few thousand probes per
             // batch; below that (sparse huge filters: f >= 39 on the 62-genome input) the direct loads are cheaper.
             // tools/large_filter_bench.py: f=38 3.5 k probes per slice and batch 52 vs 61 ms, f=39 1.8 k 64 vs 61, f=40 0.9 k 99 vs 63.
@@ -381,10 +394,11 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
     if (part) {
         // as few batches of tiles as the buffer budget allows
+        const int64_t budget = part_budget(c);
         for (;; batches *= 2) {
             const uint64_t per = (tiles + batches - 1) / batches;
             if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl, c->opt_part_levels)) { part = false; break; }
-            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
         }
         // A batch after the first loads and stores every filter slice (2 x 2^L/8 bytes at ~5 TB/s) to save ~40 ps per address
         // against the direct atomics: worth it only above ~2^slice_bits/800 addresses per slice and batch.
@@ -884,7 +898,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
             per = (per_total + batches - 1) / batches;
             if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->sh_world > 1 ? 2 : c->opt_part_levels))
                 return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
-            if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles) break;
+            if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles) break;
         }
         const size_t need[6] = { 0, 0, tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl), pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
         for (int i = 2; i < 6; i++) if (!ensure_pbuf(c, i, need[i])) return fail(c, -10, "out of device memory for the partition buffers");
@@ -899,7 +913,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
             const bool fits = per * W * (uint64_t)(512 * TPC_RUN) <= (1ull << 30);  // survivor ids hold a 30-bit position relative to the batch
             const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, 2);
             if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
-            if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= c->opt_part_budget || (int64_t)per <= c->opt_part_min_tiles)) break;
+            if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");
         }
         for (int i = 2; i < 9; i++) if (!ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");

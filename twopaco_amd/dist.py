@@ -427,6 +427,13 @@ def bench_main(args, rank, world, local_rank):
                        if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
             "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
             "kernel_ms_rank0": kms,
+            # dominant kernel group on rank 0, priced like the single-GPU line (0.375 + 6 x 64 B per queried k-mer);
+            # a rank queries the vertices of its range / its tiles = 1/world of the k-mers
+            "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0 (its 1/%d of the k-mers)" % world,
+                         "achieved": (n_kmers / world) * 384.375 / (max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9) * 1e-3) / 1e9,
+                         "peak": 8000.0, "unit": "GB/s",
+                         "frac": (n_kmers / world) * 384.375 / (max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9) * 1e-3) / 1e9 / 8000.0,
+                         "traffic": None},
             "exchange_bytes_rank0_per_step": (sh.comm.bytes_moved // (args.steps + args.warmup)) if address else None,
             "phase_ms_rank0_per_step": {k: v * 1e3 / (args.steps + args.warmup) for k, v in sh.t.items()} if address else None,
             "survivors_rank0": sh.stats.get("survivors") if address else None,
