@@ -118,6 +118,11 @@ int tpc_junction_keys(tpc_ctx *ctx, uint64_t *keys_host);
  * the multi-GPU driver uses the pair to union the per-rank sets before tpc_junctions_finalize. */
 int tpc_junction_keys_raw(tpc_ctx *ctx, uint64_t *keys_host, uint64_t *n);
 int tpc_junction_keys_set(tpc_ctx *ctx, const uint64_t *keys_host, uint64_t n);
+/* The same pair on DEVICE buffers, so that the union of the per-rank key sets can be all-gathered without
+ * touching the host: _export copies min(n, cap_keys) keys to dst_dev and reports n; _import replaces
+ * (append = 0) or extends (append = 1) the set with n keys from src_dev. */
+int tpc_junction_keys_export(tpc_ctx *ctx, uint64_t *dst_dev, uint64_t cap_keys, uint64_t *n);
+int tpc_junction_keys_import(tpc_ctx *ctx, const uint64_t *src_dev, uint64_t n, int append);
 
 /* BifurcationStorage::GetId (bifurcationstorage.h:100-127) for one k-mer given as k ASCII
  * characters: +(rank+1), -(rank+1) or TPC_INVALID_VERTEX.  Host-side binary search over the

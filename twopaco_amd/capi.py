@@ -20,7 +20,8 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
-               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload"]
+               "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
+               "tpc_junction_keys_export", "tpc_junction_keys_import"]
 
 _hip = None
 _host = None
@@ -55,6 +56,8 @@ def hip():
         L.tpc_junction_keys.argtypes = [p, p]
         L.tpc_junction_keys_raw.argtypes = [p, p, p]
         L.tpc_junction_keys_set.argtypes = [p, p, u64]
+        L.tpc_junction_keys_export.argtypes = [p, p, u64, p]
+        L.tpc_junction_keys_import.argtypes = [p, p, u64, ci]
         L.tpc_get_id.restype = i64
         L.tpc_get_id.argtypes = [p, ctypes.c_char_p]
         L.tpc_emit.argtypes = [p, p, p]
@@ -286,6 +289,17 @@ class Context:
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         self._ck(hip().tpc_junction_keys_set(self._h, keys.ctypes.data, keys.shape[0]))
 
+    def key_words(self):
+        return int(hip().tpc_key_words(self._h))
+
+    def junction_keys_export(self, dst_ptr, cap_keys):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_junction_keys_export(self._h, dst_ptr, cap_keys, ctypes.byref(n)))
+        return n.value
+
+    def junction_keys_import(self, src_ptr, n, append):
+        self._ck(hip().tpc_junction_keys_import(self._h, src_ptr, n, 1 if append else 0))
+
     def get_id(self, kmer):
         return hip().tpc_get_id(self._h, kmer.encode())
 
@@ -414,6 +428,17 @@ class Enumerator:
 
     def vertices_count(self):
         return host().tpch_vertices_count(self._h)
+
+    def key_words(self):
+        return int(hip().tpc_key_words(self._h))
+
+    def junction_keys_export(self, dst_ptr, cap_keys):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_junction_keys_export(self._h, dst_ptr, cap_keys, ctypes.byref(n)))
+        return n.value
+
+    def junction_keys_import(self, src_ptr, n, append):
+        self._ck(hip().tpc_junction_keys_import(self._h, src_ptr, n, 1 if append else 0))
 
     def get_id(self, kmer):
         return host().tpch_get_id(self._h, kmer.encode())

@@ -721,6 +721,40 @@ int tpc_junction_keys_set(tpc_ctx *c, const uint64_t *keys_host, uint64_t n)
     return 0;
 }
 
+int tpc_junction_keys_export(tpc_ctx *c, uint64_t *dst_dev, uint64_t cap_keys, uint64_t *n)
+{
+    if (!c || !n || (!dst_dev && cap_keys)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    *n = c->n_keys;
+    const uint64_t m = std::min(c->n_keys, cap_keys);
+    if (m) HIPCHK(c, hipMemcpyAsync(dst_dev, c->keys, m * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_junction_keys_import(tpc_ctx *c, const uint64_t *src_dev, uint64_t n, int append)
+{
+    if (!c || (!src_dev && n)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t base = append ? c->n_keys : 0;
+    const uint64_t need = base + n;
+    if (need > c->keys_cap) {
+        uint64_t *nk = nullptr;
+        const uint64_t ncap = need + need / 2 + 1024;
+        HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
+        if (base) HIPCHK(c, hipMemcpy(nk, c->keys, base * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        if (c->keys) (void)hipFree(c->keys);
+        c->keys = nk;
+        c->keys_cap = ncap;
+    }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->keys + base * c->C, src_dev, n * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_keys = need;
+    c->finalized = false;
+    c->keys_host.clear();
+    return 0;
+}
+
 int64_t tpc_get_id(tpc_ctx *c, const char *kmer)
 {   // BifurcationStorage::GetId, bifurcationstorage.h:100-127 (host-side: cold query API)
     if (!c || !c->finalized || !kmer) return TPC_INVALID_VERTEX;

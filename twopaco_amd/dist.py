@@ -59,6 +59,32 @@ class HipBackend:
     def set_keys(self, keys):
         self.ctx.junction_keys_set(keys)
 
+    def union_keys_on_device(self, dist):
+        """All-gather of the per-rank junction keys without a host round trip: one message per rank =
+        [count, keys...] in a device buffer of `cap` keys that only grows (every rank sees every count, so all
+        ranks agree when a second, larger exchange is needed)."""
+        import torch
+        ctx, C = self.ctx, self.ctx.key_words()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if not hasattr(self, "_comm"):
+            self._comm = _Comm(dist, dev)
+            self._cap = 1 << 17
+        while True:
+            cap = self._cap
+            buf = getattr(self, "_keybuf", None)
+            if buf is None or buf.numel() != 1 + cap * C:
+                buf = self._keybuf = torch.empty(1 + cap * C, dtype=torch.int64, device=dev)
+            n = ctx.junction_keys_export(buf.data_ptr() + 8, cap)
+            buf[0] = n
+            allb = self._comm.all_gather(buf)
+            counts = [int(x) for x in allb[:, 0].cpu().tolist()]
+            if max(counts) <= cap:
+                break
+            self._cap = int(max(counts) * 1.5) + 1024
+        self._comm.sync()
+        for r, m in enumerate(counts):
+            ctx.junction_keys_import(allb[r].data_ptr() + 8, m, append=r > 0)
+
     def finalize(self):
         return self.ctx.junctions_finalize()
 
@@ -100,8 +126,10 @@ def sharded_step(backend, dist, L, abundance=(1 << 64) - 1, fetch=False):
     lo, hi = vertex_hash_ranges(L, world)[rank]
     backend.run_begin()
     st = backend.round(lo, hi, abundance)
-    keys = allgather_keys(dist, backend.local_keys())
-    backend.set_keys(keys)
+    if hasattr(backend, "union_keys_on_device"):
+        backend.union_keys_on_device(dist)
+    else:
+        backend.set_keys(allgather_keys(dist, backend.local_keys()))
     st["junctions"] = backend.finalize()
     st["n_marked"], st["n_valid"] = backend.emit()
     st["range"] = (lo, hi)
