@@ -131,16 +131,17 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
 }
 
 // ------------------------------------------------------------------------------------------ level 2
+constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips better than 8
 template <bool SHARDED>
-__global__ void __launch_bounds__(PT_THREADS)
+__global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
              uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
 {   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
     // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
-    constexpr int LOADS = 16;
-    Bins<uint32_t> bins;
+    constexpr int LOADS = 8;
+    Bins<uint32_t, PS_THREADS> bins;
     bins.carve(smem, LOG_NB2);
     bins.init();
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
@@ -157,7 +158,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
     auto reg = [region, cap2](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap2, cap2}; };
     __syncthreads();
-    // rounds of LOADS x PT_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
+    // rounds of LOADS x PS_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
     // round's loads are issued before the current round is binned and flushed
     uint32_t w = j, base = 0;
     uint32_t n = w < nvw ? cnt1[r1(w)] : 0;
@@ -167,14 +168,14 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         const uint32_t *src = buf1 + r1(ww) * cap1;
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
-            const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
+            const uint32_t idx = bb + i * PS_THREADS + threadIdx.x;
             dst[i] = idx < nn ? src[idx] : PT_SENT;
         }
     };
     if (w < nvw) load(v, w, base, n);
     while (w < nvw) {
         // advance to the next round and prefetch it
-        uint32_t w2 = w, base2 = base + LOADS * PT_THREADS, n2 = n;
+        uint32_t w2 = w, base2 = base + LOADS * PS_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
             do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
@@ -275,19 +276,19 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint32_t>::lds_bytes(std::max(pl.b2, pl.b3));
+    const size_t lds = Bins<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3));
     (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
     const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
     if (pl.world > 1)
-        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
                            pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
     else
-        hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+        hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
                            pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
     if (pl.b3)  // third level: bucket (b1, b2), input = the regions written above
-        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PT_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
+        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
                            pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2);
     return 0;
 }

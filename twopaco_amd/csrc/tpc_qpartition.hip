@@ -187,20 +187,21 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 }
 
 // ------------------------------------------------------------------------------------------ B
+constexpr int QS_THREADS = 1024;  // split: 16 waves hide the LDS atomic round trips better than 8
 template <bool SHARDED>
-__global__ void __launch_bounds__(PT_THREADS)
+__global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
           PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
 {   // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
-    constexpr int LOADS = 8;
+    constexpr int LOADS = 4;
     constexpr uint64_t SENT = ~0ull;
-    Bins<uint64_t> bins;
+    Bins<uint64_t, QS_THREADS> bins;
     uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
     bins.init();
-    for (uint32_t i = threadIdx.x; i <= NB2; i += PT_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
+    for (uint32_t i = threadIdx.x; i <= NB2; i += QS_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
     const uint32_t nvw = prev_wpb ? prev_wpb : SHARDED ? nwg1 * sh.world : nwg1;  // source regions: (source rank, workgroup)
@@ -222,13 +223,13 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         const uint64_t *src = buf1 + r1(ww) * cap1;
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
-            const uint32_t idx = bb + i * PT_THREADS + threadIdx.x;
+            const uint32_t idx = bb + i * QS_THREADS + threadIdx.x;
             dst[i] = (i < loads && idx < nn) ? src[idx] : SENT;
         }
     };
     if (w < nvw) load(v, w, base, n);
     while (w < nvw) {
-        uint32_t w2 = w, base2 = base + (uint32_t)loads * PT_THREADS, n2 = n;
+        uint32_t w2 = w, base2 = base + (uint32_t)loads * QS_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
             do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
@@ -572,7 +573,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     // k_q_split entries per thread per round for a level with 2^bits bins (the last level's bins see a 2x skew)
     auto loads_for = [](int bits) {
         const int c = (PT_BIN_BYTES / 8) >> bits;
-        return std::max(1, std::min(8, std::max(1, (1 << bits) * (c - 16) * 5 / 8) * 9 / 8 / PT_THREADS / 2));
+        return std::max(1, std::min(4, std::max(1, (1 << bits) * (c - 16) * 5 / 8) * 9 / 8 / QS_THREADS / 2));
     };
     pl.loads = loads_for(pl.b3 ? pl.b2 : pl.b1);
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
@@ -661,18 +662,18 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     const PtShard sh{pl.rank, pl.world};
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-        const size_t lds = Bins<uint64_t>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
+        const size_t lds = Bins<uint64_t, QS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
         (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
         if (pl.world > 1)
-            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
+            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
                                pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
         else
-            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(PT_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
+            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
                                pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
         if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
-            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PT_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
+            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
                                a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2);
     }
     {
