@@ -12,4 +12,4 @@ for name, calls, total, avg, pct in c.execute("select name,total_calls,total_dur
     short = re.sub(r"\(.*", "", short).replace("void ", "")
     if "rocprim" in short:
         short = "rocprim::" + ("radix_sort_onesweep" if "onesweep_iteration" in name else "radix_sort_histogram")
-    print("%s,%d,%.3f,%.3f,%.3f" % (short, calls, total / 1e3, avg / 1e3, pct))
+    print('"%s",%d,%.3f,%.3f,%.3f' % (short, calls, total / 1e3, avg / 1e3, pct))  # names hold commas: quoted
