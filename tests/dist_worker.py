@@ -74,7 +74,8 @@ def worker(rank, world, port, case, files, use_gpu, result_path):
 def addr_worker(rank, world, port, spec, result_path):
     """Address-sharded filter: `world` ranks (gloo rendezvous, every context on GPU 0).  Each rank
     reports its filter shard after the insert, the merged candidate mask after the query and the
-    final (position, id) list; the test reassembles the shards and compares with the oracle."""
+    final (position, id) list; the test reassembles the shards and compares with the oracle.
+    `spec` is one configuration or a list of them (run one after the other in the same process group)."""
     import pickle
 
     import numpy as np
@@ -88,31 +89,40 @@ def addr_worker(rank, world, port, spec, result_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    if spec.get("files"):
-        text = capi.PackedText.from_fasta(spec["files"])
-    else:
-        recs, _ = synth.workload(spec["workload"], scale=spec["scale"])
-        text = capi.PackedText.from_codes(recs)
-    ctx = capi.Context(0)
-    for opt, val in spec.get("options", {}).items():
-        ctx.set_option(opt, val)
-    ctx.set_params(spec["k"], spec["L"], spec["q"], capi.seed_table(spec["q"], spec["L"], seed=spec["seed"]))
-    ctx.seq_upload(text)
-    sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0))
-    out = {"rounds": []}
-    for lo, hi in spec["ranges"]:
-        geom = sh.insert(lo, hi)
-        shard = ctx.filter_download()
-        qgeom = sh.query(lo, hi)
-        out["rounds"].append({"geom": geom, "qgeom": qgeom, "shard": shard, "mask": ctx.mask_download(False),
-                              "survivors": sh.stats["survivors"]})
-    st = tdist.address_sharded_step(sh, spec["abundance"], fetch=True)
-    out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], moved=sh.comm.bytes_moved)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, out)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    code_of = np.zeros(256, dtype=np.uint8)
+    code_of[letters] = np.arange(5, dtype=np.uint8)
+    results = []
+    for sp in (spec if isinstance(spec, list) else [spec]):
+        if sp.get("files"):
+            text = capi.PackedText.from_fasta(sp["files"])
+        elif sp.get("records"):
+            text = capi.PackedText.from_codes([code_of[np.frombuffer(r, dtype=np.uint8)] for r in sp["records"]])
+        else:
+            recs, _ = synth.workload(sp["workload"], scale=sp["scale"])
+            text = capi.PackedText.from_codes(recs)
+        ctx = capi.Context(0)
+        for opt, val in sp.get("options", {}).items():
+            ctx.set_option(opt, val)
+        ctx.set_params(sp["k"], sp["L"], sp["q"], capi.seed_table(sp["q"], sp["L"], seed=sp["seed"]))
+        ctx.seq_upload(text)
+        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0))
+        out = {"rounds": []}
+        for lo, hi in sp["ranges"]:
+            geom = sh.insert(lo, hi)
+            shard = ctx.filter_download()
+            qgeom = sh.query(lo, hi)
+            out["rounds"].append({"geom": geom, "qgeom": qgeom, "shard": shard, "mask": ctx.mask_download(False),
+                                  "survivors": sh.stats["survivors"]})
+        st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True)
+        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], moved=sh.comm.bytes_moved)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        results.append(gathered)
+        ctx.close()
     if rank == 0:
         with open(result_path, "wb") as f:
-            pickle.dump(gathered, f)
+            pickle.dump(results if isinstance(spec, list) else results[0], f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -95,3 +95,39 @@ def test_address_sharded_synthetic_batches(world, budget, tmp_path):
     tr = gathered[0]["rounds"][0]["survivors"][0]
     assert len(tr) == 3 and tr[2] <= tr[1] <= tr[0]
     check(spec, o, gathered, world)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_address_sharded_randomized(world, tmp_path):
+    """Random texts (N runs, skew) x random k, L, q, slice size, tile batches and gated ranges, all in one process group."""
+    rng = np.random.default_rng(99 + world)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    specs = []
+    for trial in range(10):
+        k = int(rng.choice([5, 9, 15, 25, 31, 33]))
+        L = int(rng.integers(14, 24))
+        q = int(rng.integers(1, 8))
+        slice_bits = int(rng.integers(6, min(12, L - 6) + 1))
+        base = alphabet[rng.integers(0, 4, int(rng.integers(3000, 50000)))].copy()
+        recs = []
+        for r in range(int(rng.integers(1, 5))):
+            s = base.copy()
+            hits = rng.random(s.size) < 0.02
+            s[hits] = alphabet[rng.integers(0, 4, int(hits.sum()))]
+            if rng.random() < 0.5:
+                a = int(rng.integers(0, s.size)); s[a:a + int(rng.integers(1, 60))] = ord("N")
+            if rng.random() < 0.2:
+                s[:int(rng.integers(1, s.size // 4))] = ord("A")
+            recs.append(s.tobytes())
+        size = 1 << L
+        cut = sorted(int(x) for x in rng.integers(0, size, 2))
+        specs.append({"records": recs, "k": k, "L": L, "q": q, "seed": int(rng.integers(1, 1 << 40)), "ranges": [(0, size), (cut[0], cut[1])],
+                      "abundance": (1 << 64) - 1,
+                      "options": {"slice_bits": slice_bits, "part_min_tiles": 1, "part_budget_bytes": int(rng.choice([40 << 30, 1 << 20]))}})
+    results = run(specs, world, tmp_path)
+    for sp, gathered in zip(specs, results):
+        o = O.Oracle(sp["k"], sp["L"], sp["q"], O.seed_table(sp["seed"], sp["q"], sp["L"]))
+        for r in sp["records"]:
+            o.add_record(r)
+        check(sp, o, gathered, world)
+        o.close()
