@@ -174,7 +174,7 @@ void tpc_host_free(void *ptr);
  *   tpc_shard_hash     level 1 of the pass over this rank's tiles of `batch` into send_regions /
  *                      send_counts (block d = entries for rank d); the query also marks the
  *                      N-adjacent vertices of those tiles; *n_overflow = entries that did not fit
- *                      a region (>= 2^63: the overflow list itself overflowed -> unsupported skew)
+ *                      a region (>= 2^62: the overflow list itself overflowed -> unsupported skew)
  *   tpc_shard_overflow_get / _set   the overflow list of the pass (full addresses, any owner):
  *                      ranks all-gather their lists and set the concatenation before _apply
  *   tpc_shard_apply    levels 2-3 over the received blocks: insert ORs the owned slices; query

@@ -1008,7 +1008,7 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's collective runs on another stream
-    if (n_overflow) *n_overflow = ov[1] ? (1ull << 63) : (uint64_t)ov[0];
+    if (n_overflow) *n_overflow = ov[1] ? (1ull << 62) : (uint64_t)ov[0];
     return 0;
 }
 

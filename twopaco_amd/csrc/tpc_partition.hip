@@ -45,7 +45,7 @@ struct Overflow {
 
 // ------------------------------------------------------------------------------------------ level 1
 struct HashEmit {
-    Bins<uint32_t> *bins;
+    Bins<uint32_t, 1024> *bins;  // k_part_hash's bins (PH_THREADS)
     const Overflow *ovf;
     int shift;          // L - B1
     uint32_t remmask;   // 2^(L-B1) - 1
@@ -68,8 +68,9 @@ struct HashEmit {
     }
 };
 
+constexpr int PH_THREADS = 1024;  // two 512-word tiles per workgroup round: 16 waves hide the LDS latencies that 8 left exposed
 template <int Q, bool GATED, bool SHARDED>
-__global__ void __launch_bounds__(PT_THREADS)
+__global__ void __launch_bounds__(PH_THREADS)
 k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
             const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
             uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers)
@@ -77,14 +78,16 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
-    Bins<uint32_t> bins;
-    uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
-    uint64_t *s_h = s_b + TW;
+    Bins<uint32_t, PH_THREADS> bins;
+    uint64_t *s_b2 = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));  // [2][TW]
+    uint64_t *s_h = s_b2 + 2 * TW;
     uint64_t *s_hk = s_h + Q * 5;
-    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + Q * 5);
-    uint32_t *s_w = s_n + TW;  // 8 words
+    uint32_t *s_n2 = reinterpret_cast<uint32_t *>(s_hk + Q * 5);              // [2][TW]
+    uint32_t *s_w = s_n2 + 2 * TW;  // 16 words
     bins.init();
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, half = tid >> 9, lt = tid & (PT_THREADS - 1);
+    const uint64_t *s_b = s_b2 + half * TW;
+    const uint32_t *s_n = s_n2 + half * TW;
     if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
     const int shift = P.L - LOG_NB;
     HashEmit emit{&bins, &ovf, shift, (uint32_t)((1ull << shift) - 1ull), perm};
@@ -95,18 +98,21 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
     const int xw = (P.k + 1) / 32 + 2;
     unsigned hashed = 0;
-    for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
-        __syncthreads();  // previous tile's staging is no longer read
+    for (uint64_t pair = tile0 + 2 * (uint64_t)blockIdx.x; pair < tile0 + n_tiles; pair += 2 * (uint64_t)gridDim.x) {
+        __syncthreads();  // previous tiles' staging is no longer read
+        const uint64_t tile = pair + half;
+        const bool have = tile < tile0 + n_tiles;
         const uint64_t wfirst = tile * PT_THREADS;
         const uint64_t wbase = wfirst - 1;
-        for (int i = tid; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
-            const int64_t w = (int64_t)wfirst - 1 + i;
-            s_b[i] = w >= 0 ? bases[w] : 0ull;
-            s_n[i] = w >= 0 ? nmask[w] : 0xFFFFFFFFu;
-        }
+        if (have)
+            for (int i = lt; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
+                const int64_t w = (int64_t)wfirst - 1 + i;
+                s_b2[half * TW + i] = w >= 0 ? bases[w] : 0ull;
+                s_n2[half * TW + i] = w >= 0 ? nmask[w] : 0xFFFFFFFFu;
+            }
         __syncthreads();
-        const uint64_t g0 = (wfirst + tid) * TPC_RUN;
-        const bool active = g0 < n_text;
+        const uint64_t g0 = (wfirst + lt) * TPC_RUN;
+        const bool active = have && g0 < n_text;
         TpcRoll<Q> r;
         if (active) tpc_roll_init<Q>(r, P, s_h, s_b, s_n, g0, wbase);
         for (int s0 = 0; s0 < TPC_RUN; s0 += pos_per_round) {
@@ -124,7 +130,7 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
         __syncthreads();
         if (tid == 0) {
             unsigned t = 0;
-            for (int i = 0; i < PT_THREADS / 64; i++) t += s_w[i];
+            for (int i = 0; i < PH_THREADS / 64; i++) t += s_w[i];
             if (t) atomicAdd(n_kmers, (unsigned long long)t);
         }
     }
@@ -259,11 +265,11 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint32_t>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
+    const size_t lds = Bins<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 5 * 16 + 64;
 #define TPC_HASH_GO(G, S)                                                                                                                   \
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_part_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL((k_part_hash<Q, G, S>), dim3(pl.nwg1), dim3(PT_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
+        hipLaunchKernelGGL((k_part_hash<Q, G, S>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers);            \
     } while (0)
     if (pl.world > 1) { if (gated) TPC_HASH_GO(true, true); else TPC_HASH_GO(false, true); }
@@ -328,7 +334,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     if (world == 0 || (world & (world - 1)) || world > (1u << pl.b1)) return false;  // ranks own whole buckets
     pl.n_tiles = n_tiles;
     pl.tile0 = 0;
-    pl.nwg1 = (uint32_t)std::min<uint64_t>(256, pl.n_tiles);
+    pl.nwg1 = (uint32_t)std::min<uint64_t>(256, (pl.n_tiles + 1) / 2);  // k_part_hash takes two tiles per workgroup round
     // level-2 workgroups per bucket: one per bucket is fastest once the buckets alone fill the chip (measured 1 / 2 / 4 / 8 on M2:
     // 45.9 / 46.3 / 47.9 / 51.3 ms per step); fewer local buckets (small filters, sharded filters) are split further
     pl.wpb = std::max<uint32_t>(1, std::min<uint32_t>(8, (256u * world) >> pl.b1));
@@ -337,7 +343,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     int budget = (1 << pl.b1) * (cap - 32) * 5 / 8;  // entries per round
     // frac: expected share of positions that emit (a gated round only inserts edges touching its
     // vertex-hash range), so a round can cover more positions before the rings fill
-    int ppr = (int)(budget / (PT_THREADS * q * std::max(frac, 1.0 / 64)));
+    int ppr = (int)(budget / (1024 * q * std::max(frac, 1.0 / 64)));  // k_part_hash: 1024 threads (two tiles) x pos_per_round
     pl.pos_per_round = ppr >= 32 ? 32 : ppr >= 16 ? 16 : ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));

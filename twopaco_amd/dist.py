@@ -262,7 +262,7 @@ class AddressSharded:
         t0 = self._tick(tag + "_all_to_all", t0)
         # skew path: entries that did not fit their level-1 region, for any owner
         m = self.comm.max_ints([n_ovf])[0]
-        if m >= (1 << 63):
+        if m >= (1 << 62):
             raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
         if m > 0:
             eb = geom["overflow_entry_bytes"]
