@@ -593,49 +593,64 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
     int rc = compact_mask(c, c->rmask);
     if (rc) return rc;
     c->marks_valid = true;
-    // table: power of two >= 2 x marks
-    uint64_t cap = 1024;
-    while (cap < 2 * c->n_marks + 2) cap <<= 1;
+    // Exact-filter table, a power of two.  Sized first for the usual case -- on many-genome inputs a key is marked dozens
+    // of times, so marks / 4 slots hold the distinct keys several times over and the table (and TrueBifurcations' scan of it)
+    // stays cache sized; a probe sequence longer than TPC_FILTER2_PROBE_LIMIT flags a table that is too full and the pass
+    // is repeated with 2 x marks slots, which always suffices.
     const size_t sb = tpc_table_slot_bytes(c->C);
-    if (cap > c->table_alloc) {
-        if (c->table) (void)hipFree(c->table);
-        c->table = nullptr;
-        HIPCHK(c, hipMalloc(&c->table, cap * sb));
-        c->table_alloc = cap;
-    }
-    c->table_cap = cap;
     TpcLaunch a = make_launch(c);
     const bool counted = abundance < c->n_marks;  // otherwise no key can exceed the abundance cut
     if (!c->scan_blocks) HIPCHK(c, hipMalloc((void **)&c->scan_blocks, 2 * TPC_SCAN2_BLOCKS * sizeof(uint64_t)));
-    {
-        Timed t(c, TPC_K_FILTER2);
-        // key = EMPTY (all ones), meta = 0
-        tpc_launch_table_init(c->stream, c->table, cap);
-        if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap, counted)) return fail(c, -1, "filter2 launch failed");
-    }
+    uint64_t full = 1024;
+    while (full < 2 * c->n_marks + 2) full <<= 1;
+    uint64_t cap = 1024;
+    while (cap < c->n_marks / 4 + 2) cap <<= 1;
     uint64_t tp = 0, used = 0;
-    {
-        Timed t(c, TPC_K_SCAN2);
-        if (tpc_launch_scan2_count(a, c->table, cap, abundance, counted, c->scan_blocks, c->scan_blocks + TPC_SCAN2_BLOCKS, c->counters + 4))
-            return fail(c, -1, "scan2 launch failed");
-        if ((rc = read_counter(c, 4, &tp))) return rc;
-        if ((rc = read_counter(c, 5, &used))) return rc;
-        if (tp) {
-            const uint64_t need = c->n_keys + tp;
-            if (need > c->keys_cap) {
-                uint64_t *nk = nullptr;
-                const uint64_t ncap = need + need / 4 + 1024;
-                HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
-                if (c->n_keys) HIPCHK(c, hipMemcpyAsync(nk, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (c->keys) (void)hipFree(c->keys);
-                c->keys = nk;
-                c->keys_cap = ncap;
-            }
-            if (tpc_launch_scan2_write(a, c->C, c->marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
-                return fail(c, -1, "scan2 launch failed");
-            c->n_keys += tp;
+    for (;;) {
+        if (cap > c->table_alloc) {
+            if (c->table) (void)hipFree(c->table);
+            c->table = nullptr;
+            c->table_alloc = 0;
+            HIPCHK(c, hipMalloc(&c->table, cap * sb));
+            c->table_alloc = cap;
         }
+        c->table_cap = cap;
+        HIPCHK(c, hipMemsetAsync(c->counters + 6, 0, sizeof(unsigned long long), c->stream));
+        {
+            Timed t(c, TPC_K_FILTER2);
+            // key = EMPTY (all ones), meta = 0
+            tpc_launch_table_init(c->stream, c->table, cap);
+            if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
+        }
+        uint64_t too_full = 0;
+        {
+            Timed t(c, TPC_K_SCAN2);
+            if (tpc_launch_scan2_count(a, c->table, cap, abundance, counted, c->scan_blocks, c->scan_blocks + TPC_SCAN2_BLOCKS, c->counters + 4))
+                return fail(c, -1, "scan2 launch failed");
+            unsigned long long three[3] = {0, 0, 0};
+            HIPCHK(c, hipMemcpyAsync(three, c->counters + 4, sizeof three, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            tp = three[0]; used = three[1]; too_full = three[2];
+            if (!too_full && tp) {
+                const uint64_t need = c->n_keys + tp;
+                if (need > c->keys_cap) {
+                    uint64_t *nk = nullptr;
+                    const uint64_t ncap = need + need / 4 + 1024;
+                    HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
+                    if (c->n_keys) HIPCHK(c, hipMemcpyAsync(nk, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    if (c->keys) (void)hipFree(c->keys);
+                    c->keys = nk;
+                    c->keys_cap = ncap;
+                }
+                if (tpc_launch_scan2_write(a, c->C, c->marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
+                    return fail(c, -1, "scan2 launch failed");
+                c->n_keys += tp;
+            }
+        }
+        if (!too_full) break;
+        if (cap >= full) return fail(c, -1, "exact-filter table overflow at full size");
+        cap = full;
     }
     // MergeOr into the run-wide mask (VE.h:909-913)
     if (c->rounds_done == 0) {

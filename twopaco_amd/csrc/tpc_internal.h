@@ -116,7 +116,11 @@ int tpc_launch_mask_or(hipStream_t s, uint32_t *dst, const uint32_t *src, uint64
 size_t tpc_table_slot_bytes(int C);
 int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
 // counted: keep exact occurrence counts (needed only when the abundance cut can apply)
-int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted);
+// *overflow (device) is set when a probe sequence exceeds TPC_FILTER2_PROBE_LIMIT slots: the table is too small for the
+// number of distinct keys and the pass must be repeated with a larger one
+#define TPC_FILTER2_PROBE_LIMIT 512u
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
+                       unsigned long long *overflow);
 // TrueBifurcations in two atomic-free passes over TPC_SCAN2_BLOCKS chunks of the table.
 // count: block_tp / block_used (TPC_SCAN2_BLOCKS uint64 each) become exclusive offsets; totals[0] =
 // true junctions, totals[1] = table size.  write: junction keys at block_tp offsets.

@@ -215,7 +215,8 @@ __global__ void k_table_init(Slot *table, uint64_t cap)
 template <int C, bool COUNTED>
 __global__ void __launch_bounds__(256)
 k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-          const uint32_t *__restrict__ nmask, const uint64_t *__restrict__ marks, uint64_t n_marks, Slot *table, uint64_t cap)
+          const uint32_t *__restrict__ nmask, const uint64_t *__restrict__ marks, uint64_t n_marks, Slot *table, uint64_t cap,
+          unsigned long long *overflow)
 {
     __shared__ uint64_t s_h0[4];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
@@ -241,7 +242,10 @@ k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
     uint64_t slot = key_hash<C>(ck) & mask;
     bool claimed = false;    // this thread put the key into the slot
     uint64_t seen_meta = 0;  // meta bits known to be set already
-    for (;;) {
+    // The table is first sized for the usual ratio of marks to distinct keys (tpc_pass2_filter); a probe sequence this long
+    // means it is too full: flag it and let the host repeat the pass with the table sized for all marks being distinct.
+    for (uint32_t probes = 0;; probes++) {
+        if (probes >= TPC_FILTER2_PROBE_LIMIT) { *overflow = 1ull; return; }
         const uint4 raw = *reinterpret_cast<const uint4 *>(&table[slot]);
         uint64_t cur = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
         seen_meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
@@ -465,14 +469,15 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap)
     return 0;
 }
 
-int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted)
+int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
+                       unsigned long long *overflow)
 {
     if (n_marks == 0) return 0;
 #define CALL(C_)                                                                                                                         \
     if (counted) hipLaunchKernelGGL((k_filter2<C_, true>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, \
-                                    marks, n_marks, (Slot *)table, cap);                                                                 \
+                                    marks, n_marks, (Slot *)table, cap, overflow);                                                       \
     else hipLaunchKernelGGL((k_filter2<C_, false>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, \
-                            n_marks, (Slot *)table, cap)
+                            n_marks, (Slot *)table, cap, overflow)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
