@@ -228,7 +228,8 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
- * "insert_batches" / "query_batches" = tile batches.  -1: unknown name. */
+ * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
+ * with the full-size table by the last tpc_pass2_filter.  -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);
 
 #ifdef __cplusplus

@@ -396,6 +396,33 @@ def test_cli_pipeline_twopaco_then_graphdump(tmp_path):
         assert "".join(spelled) == letters[rec].tobytes().decode()
 
 
+def test_exact_filter_table_retry(capi):
+    """Two genomes differing by SNPs: every junction key is marked about twice, so the first, optimistic table
+    (marks / 4 slots) is too small; the pass flags it, repeats with 2 x marks slots and gives the oracle's result."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.02)
+    recs = recs[:2]
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    o = O.Oracle(25, 24, 5, O.seed_table(3, 5, 24))
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    o.enumerate(rounds=1)
+    ctx = capi.Context(0)
+    ctx.set_params(25, 24, 5, capi.seed_table(5, 24, seed=3))
+    ctx.seq_upload(capi.PackedText.from_codes(recs))
+    ctx.run_begin()
+    ctx.filter_reset()
+    ctx.pass1_insert()
+    marks = ctx.pass1_query()
+    st = ctx.pass2_filter()
+    assert ctx.stat("filter2_retries") == 1 and marks > 2048
+    rs = o.round_stats(0)
+    assert (st["true"], st["false"], st["table"]) == (rs["true"], rs["false"], rs["table"])
+    assert ctx.junctions_finalize() == len(o.keys)
+    assert (ctx.junction_keys() == o.keys).all()
+    ctx.close()
+
+
 def test_filter_checkpoint_restore(capi, tmp_path):
     """tpc_filter_download / tpc_filter_upload: a second context that restores the first one's Bloom filter (and
     one that restores the ORACLE's bitmap) continues with the query and ends with the same output."""

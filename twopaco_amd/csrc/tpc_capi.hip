@@ -69,6 +69,7 @@ struct tpc_ctx {
     // what the last insert / query actually ran (tpc_get_stat)
     int stat_path[2] = {0, 0};       // 1 direct kernel, 2 / 3 partitioned with that many levels (+10: partitioned, then completed by the direct kernel)
     int64_t stat_batches[2] = {0, 0};
+    int64_t stat_filter2_retries = 0;  // exact-filter passes repeated with the full-size table (last tpc_pass2_filter)
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = 0;  // bytes of partition buffers per batch; 0 = automatic (part_budget())
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
@@ -292,6 +293,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "query_path")) return c->stat_path[1];
     if (!strcmp(name, "insert_batches")) return c->stat_batches[0];
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
+    if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
     return -1;
 }
 
@@ -606,6 +608,7 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
     uint64_t cap = 1024;
     while (cap < c->n_marks / 4 + 2) cap <<= 1;
     uint64_t tp = 0, used = 0;
+    c->stat_filter2_retries = 0;
     for (;;) {
         if (cap > c->table_alloc) {
             if (c->table) (void)hipFree(c->table);
@@ -651,6 +654,7 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
         if (!too_full) break;
         if (cap >= full) return fail(c, -1, "exact-filter table overflow at full size");
         cap = full;
+        c->stat_filter2_retries++;
     }
     // MergeOr into the run-wide mask (VE.h:909-913)
     if (c->rounds_done == 0) {
