@@ -47,6 +47,8 @@ struct tpc_ctx {
     std::vector<uint64_t> keys_host;
     uint32_t *idtab = nullptr;
     uint64_t idtab_cap = 0;
+    void *sort_scratch = nullptr;
+    size_t sort_scratch_bytes = 0;
     // emit
     int64_t *emit_id = nullptr;
     uint64_t emit_cap = 0, n_emit = 0;
@@ -263,7 +265,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks };
+                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -679,7 +681,7 @@ int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
     HIPCHK(c, hipSetDevice(c->device));
     {
         Timed t(c, TPC_K_SORT);
-        int rc = tpc_launch_sort_keys(c->stream, c->C, c->P.k, c->keys, c->n_keys);
+        int rc = tpc_launch_sort_keys(c->stream, c->C, c->P.k, c->keys, c->n_keys, &c->sort_scratch, &c->sort_scratch_bytes);
         if (rc) return fail(c, rc, "key sort failed (%d)", rc);
         uint64_t cap = 1024;
         while (cap < 2 * c->n_keys + 2) cap <<= 1;

@@ -130,9 +130,9 @@ int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, 
 int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
                            const uint64_t *block_off, uint64_t *keys_out);
 
-// Sort junction keys (J x C, in place) in CompressedString::Less order (rocPRIM radix sort; scratch is
-// allocated inside: J is small).
-int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J);
+// Sort junction keys (J x C, in place) in CompressedString::Less order (rocPRIM radix sort).  *scratch / *scratch_bytes:
+// a device buffer owned by the caller that the one-word path grows as needed (multi-word keys allocate inside).
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void **scratch, size_t *scratch_bytes);
 
 // id index over sorted keys + output-pass lookup
 int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap);

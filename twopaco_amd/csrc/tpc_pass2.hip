@@ -506,24 +506,30 @@ int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, con
     return 0;
 }
 
-int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J)
+int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void **scratch, size_t *scratch_bytes)
 {
     if (J < 2) return 0;
     hipError_t e;
     if (C == 1) {
-        uint64_t *out = nullptr;
-        void *tmp = nullptr;
+        // one-word keys (k <= 28): radix sort on the 2k significant bits; output + temporary storage live in the caller's
+        // scratch buffer, which only grows (no allocation in the steady state)
         size_t tmp_bytes = 0;
         int end_bit = 2 * k;
         if (end_bit > 64) end_bit = 64;
+        uint64_t *out = nullptr;
         if ((e = rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, out, J, 0, end_bit, s)) != hipSuccess) return -2;
-        if (hipMalloc(&out, J * sizeof(uint64_t)) != hipSuccess) return -3;
-        if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8) != hipSuccess) { (void)hipFree(out); return -3; }
+        const size_t out_bytes = (J * sizeof(uint64_t) + 255) & ~(size_t)255;
+        const size_t need = out_bytes + (tmp_bytes ? tmp_bytes : 8);
+        if (need > *scratch_bytes) {
+            if (*scratch) (void)hipFree(*scratch);
+            *scratch = nullptr; *scratch_bytes = 0;
+            if (hipMalloc(scratch, need + need / 4) != hipSuccess) return -3;
+            *scratch_bytes = need + need / 4;
+        }
+        out = (uint64_t *)*scratch;
+        void *tmp = (char *)*scratch + out_bytes;
         e = rocprim::radix_sort_keys(tmp, tmp_bytes, keys, out, J, 0, end_bit, s);
         if (e == hipSuccess) e = hipMemcpyAsync(keys, out, J * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(out);
-        (void)hipFree(tmp);
         return e == hipSuccess ? 0 : -2;
     }
     // C > 1: CompressedString::Less compares word 0 first (compressedstring.h:93-104), so an LSD
