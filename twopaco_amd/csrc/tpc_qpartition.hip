@@ -365,48 +365,83 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
         const int e = (int)(sid & 7);
         const uint64_t g = gbase + (sid >> 3);
         if ((rmask[g >> 5] >> ((uint32_t)g & 31u)) & 1u) continue;  // already marked by another edge
-        // vertex hashes of the N-free window at g, from the text (VertexRollingHash ctor, vertexrollinghash.h:79-102)
-        uint64_t pos[Q], neg[Q];
-#pragma unroll
-        for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
-        for (int t0 = 0; t0 < P.k; t0 += 32) {
-            uint64_t w = tpc_text_word(bases, g + t0);
-            const int m = min(32, P.k - t0);
-            for (int t = 0; t < m; t++) {
-                const int c = (int)(w & 3);
-                w >>= 2;
-#pragma unroll
-                for (int i = 0; i < Q; i++) pos[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
-            }
-        }
-        for (int t1 = P.k; t1 > 0; t1 -= 32) {  // reverse complement: last base first
-            const int m = min(32, t1);
-            uint64_t w = tpc_text_word(bases, g + t1 - m);
-            for (int t = m - 1; t >= 0; t--) {
-                const int c = 3 - (int)((w >> (2 * t)) & 3);
-#pragma unroll
-                for (int i = 0; i < Q; i++) neg[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + c];
-            }
-        }
         const int c = e & 3;
-        uint64_t p[Q], nn[Q];
+        uint64_t addr[Q];  // Bloom addresses of the edge, functions 1..Q-1 (function 0 passed in k_q_lookup)
+        bool have = false;
+        if (P.k <= 32) {
+            // The strand is decided by function 0 unless its two values tie (vertexrollinghash.h:170-200): roll function 0
+            // on both strands, then functions 1..Q-1 on the chosen strand only (same instruction stream for both choices:
+            // a lane on the negative strand reads the window backwards and complemented) -- 2 + (Q-1) rolls instead of 2Q.
+            const uint64_t w = tpc_text_word(bases, g);
+            uint64_t pos0 = 0, neg0 = 0;
+            for (int t = 0; t < P.k; t++) {
+                pos0 = tpc_rotl1(pos0, P.L, P.lmask) ^ s_h[(int)((w >> (2 * t)) & 3)];
+                neg0 = tpc_rotl1(neg0, P.L, P.lmask) ^ s_h[3 - (int)((w >> (2 * (P.k - 1 - t))) & 3)];
+            }
+            const uint64_t p0 = e < 4 ? (s_hk[c] ^ pos0) : (tpc_rotl1(pos0, P.L, P.lmask) ^ s_h[c]);
+            const uint64_t n0 = e < 4 ? (tpc_rotl1(neg0, P.L, P.lmask) ^ s_h[3 - c]) : (neg0 ^ s_hk[3 - c]);
+            if (p0 != n0) {
+                const bool ng = n0 < p0;
+                uint64_t h[Q];
 #pragma unroll
-        for (int i = 0; i < Q; i++) {
-            if (e < 4) {  // in-edge c + v
-                p[i] = s_hk[i * 5 + c] ^ pos[i];
-                nn[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c];
-            } else {      // out-edge v + c
-                p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
-                nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c];
+                for (int i = 0; i < Q; i++) h[i] = 0;
+                for (int t = 0; t < P.k; t++) {
+                    const int ch = ng ? 3 - (int)((w >> (2 * (P.k - 1 - t))) & 3) : (int)((w >> (2 * t)) & 3);
+#pragma unroll
+                    for (int i = 1; i < Q; i++) h[i] = tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                }
+#pragma unroll
+                for (int i = 1; i < Q; i++) {
+                    if (e < 4) addr[i] = ng ? (tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c]) : (s_hk[i * 5 + c] ^ h[i]);          // in-edge c + v
+                    else addr[i] = ng ? (h[i] ^ s_hk[i * 5 + 3 - c]) : (tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + c]);               // out-edge v + c
+                }
+                have = true;
             }
         }
-        const bool ng = tpc_pick_neg<Q>(p, nn);
+        if (!have) {  // long k-mers, or a function-0 tie: all 2Q vertex hashes (VertexRollingHash ctor, vertexrollinghash.h:79-102)
+            uint64_t pos[Q], neg[Q];
+#pragma unroll
+            for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
+            for (int t0 = 0; t0 < P.k; t0 += 32) {
+                uint64_t w = tpc_text_word(bases, g + t0);
+                const int m = min(32, P.k - t0);
+                for (int t = 0; t < m; t++) {
+                    const int ch = (int)(w & 3);
+                    w >>= 2;
+#pragma unroll
+                    for (int i = 0; i < Q; i++) pos[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                }
+            }
+            for (int t1 = P.k; t1 > 0; t1 -= 32) {  // reverse complement: last base first
+                const int m = min(32, t1);
+                const uint64_t w = tpc_text_word(bases, g + t1 - m);
+                for (int t = m - 1; t >= 0; t--) {
+                    const int ch = 3 - (int)((w >> (2 * t)) & 3);
+#pragma unroll
+                    for (int i = 0; i < Q; i++) neg[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                }
+            }
+            uint64_t p[Q], nn[Q];
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                if (e < 4) {  // in-edge c + v
+                    p[i] = s_hk[i * 5 + c] ^ pos[i];
+                    nn[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c];
+                } else {      // out-edge v + c
+                    p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
+                    nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c];
+                }
+            }
+            const bool ng = tpc_pick_neg<Q>(p, nn);
+#pragma unroll
+            for (int i = 1; i < Q; i++) addr[i] = ng ? nn[i] : p[i];
+        }
         bool present = true;  // function 0 passed in k_q_lookup; the other probes are independent loads
         uint32_t wv[Q];
 #pragma unroll
-        for (int i = 1; i < Q; i++) { const uint64_t a = ng ? nn[i] : p[i]; wv[i] = filter[a >> 5]; }
+        for (int i = 1; i < Q; i++) wv[i] = filter[addr[i] >> 5];
 #pragma unroll
-        for (int i = 1; i < Q; i++) { const uint64_t a = ng ? nn[i] : p[i]; present = present && ((wv[i] >> ((uint32_t)a & 31u)) & 1u); }
+        for (int i = 1; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
