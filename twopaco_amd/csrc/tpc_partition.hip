@@ -141,12 +141,12 @@ constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips be
 template <bool SHARDED>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
-             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
+             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads)
 {   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
     // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
-    constexpr int LOADS = 8;
+    constexpr int LOADS = 16;  // upper bound; `loads` of them are used
     Bins<uint32_t, PS_THREADS> bins;
     bins.carve(smem, LOG_NB2);
     bins.init();
@@ -175,13 +175,13 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
             const uint32_t idx = bb + i * PS_THREADS + threadIdx.x;
-            dst[i] = idx < nn ? src[idx] : PT_SENT;
+            dst[i] = (i < loads && idx < nn) ? src[idx] : PT_SENT;
         }
     };
     if (w < nvw) load(v, w, base, n);
     while (w < nvw) {
         // advance to the next round and prefetch it
-        uint32_t w2 = w, base2 = base + LOADS * PS_THREADS, n2 = n;
+        uint32_t w2 = w, base2 = base + (uint32_t)loads * PS_THREADS, n2 = n;
         if (base2 >= n2) {
             base2 = 0;
             do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
@@ -278,6 +278,13 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     return 0;
 }
 
+// entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the < 32 leftovers per bin
+int split_loads(int bits)
+{
+    const int cap = (PT_BIN_BYTES / 4) >> bits;
+    return std::max(1, std::min(14, (1 << bits) * std::max(cap - 32, 4) * 5 / 8 / PS_THREADS));
+}
+
 int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
@@ -289,13 +296,13 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
     const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
     if (pl.world > 1)
         hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, split_loads(pl.b2));
     else
         hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, split_loads(pl.b2));
     if (pl.b3)  // third level: bucket (b1, b2), input = the regions written above
         hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
-                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2);
+                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, split_loads(pl.b3));
     return 0;
 }
 
