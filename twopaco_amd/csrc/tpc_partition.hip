@@ -117,7 +117,7 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
         if (active) tpc_roll_init<Q>(r, P, s_h, s_b, s_n, g0, wbase);
         for (int s0 = 0; s0 < TPC_RUN; s0 += pos_per_round) {
             if (active)
-                for (int s = s0; s < s0 + pos_per_round; s++)
+                for (int s = s0; s < min(s0 + pos_per_round, TPC_RUN); s++)  // any round length: the last round of a run may be short
                     hashed += tpc_insert_step<Q, GATED>(r, P, s_h, s_hk, s_b, s_n, g0 + s, wbase, lo, hi, emit);
             bins.flush(false, reg, lost);
         }
@@ -351,7 +351,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // frac: expected share of positions that emit (a gated round only inserts edges touching its
     // vertex-hash range), so a round can cover more positions before the rings fill
     int ppr = (int)(budget / (1024 * q * std::max(frac, 1.0 / 64)));  // k_part_hash: 1024 threads (two tiles) x pos_per_round
-    pl.pos_per_round = ppr >= 32 ? 32 : ppr >= 16 ? 16 : ppr >= 8 ? 8 : ppr >= 4 ? 4 : ppr >= 2 ? 2 : 1;
+    pl.pos_per_round = std::max(1, std::min(32, ppr));
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
