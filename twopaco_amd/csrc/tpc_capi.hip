@@ -47,6 +47,7 @@ struct tpc_ctx {
     std::vector<uint64_t> keys_host;
     uint32_t *idtab = nullptr;
     uint64_t idtab_cap = 0;
+    size_t idtab_bytes = 0;
     void *sort_scratch = nullptr;
     size_t sort_scratch_bytes = 0;
     // emit
@@ -685,13 +686,16 @@ int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
         if (rc) return fail(c, rc, "key sort failed (%d)", rc);
         uint64_t cap = 1024;
         while (cap < 2 * c->n_keys + 2) cap <<= 1;
-        if (cap > c->idtab_cap) {
+        const size_t slot_bytes = c->C == 1 ? 16 : 4;  // one-word keys sit in the slot next to their rank (tpc_pass2.hip:k_idtab_build)
+        if (cap * slot_bytes > c->idtab_bytes) {
             if (c->idtab) (void)hipFree(c->idtab);
             c->idtab = nullptr;
-            HIPCHK(c, hipMalloc((void **)&c->idtab, cap * sizeof(uint32_t)));
+            c->idtab_bytes = 0;
+            HIPCHK(c, hipMalloc((void **)&c->idtab, cap * slot_bytes));
+            c->idtab_bytes = cap * slot_bytes;
         }
         c->idtab_cap = cap;
-        HIPCHK(c, hipMemsetAsync(c->idtab, 0, cap * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->idtab, 0, cap * slot_bytes, c->stream));
         if (c->n_keys >= 0xFFFFFFFFull) return fail(c, -1, "too many junctions for the 32-bit id index");
         tpc_launch_idtab_build(c->stream, c->C, c->keys, c->n_keys, c->idtab, cap);
     }

@@ -351,6 +351,9 @@ k_scan2_write(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t 
 }
 
 // ---------------------------------------------------------------- id index + output lookup
+// One-word keys: 16-byte slots {key, rank} (rank word first claimed by CAS, then the key stored: readers run in a later
+// kernel), so that the output pass needs one scattered load per probe.  Multi-word keys: 4-byte rank slots, keys compared
+// through the sorted key array.
 template <int C>
 __global__ void __launch_bounds__(256) k_idtab_build(const uint64_t *__restrict__ keys, uint64_t J, uint32_t *idtab, uint64_t cap)
 {
@@ -361,6 +364,12 @@ __global__ void __launch_bounds__(256) k_idtab_build(const uint64_t *__restrict_
     for (int w = 0; w < C; w++) key[w] = keys[i * C + w];
     const uint64_t mask = cap - 1;
     uint64_t slot = key_hash<C>(key) & mask;
+    if (C == 1) {
+        while (atomicCAS(&idtab[slot * 4 + 2], 0u, (uint32_t)(i + 1)) != 0u) slot = (slot + 1) & mask;
+        idtab[slot * 4 + 0] = (uint32_t)key[0];
+        idtab[slot * 4 + 1] = (uint32_t)(key[0] >> 32);
+        return;
+    }
     while (atomicCAS(&idtab[slot], 0u, (uint32_t)(i + 1)) != 0u) slot = (slot + 1) & mask;
 }
 
@@ -391,11 +400,19 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
             const uint64_t mask = cap - 1;
             uint64_t slot = key_hash<C>(ck) & mask;
             for (;;) {
-                const uint32_t r = idtab[slot];
-                if (r == 0) break;
+                uint32_t r;
                 uint64_t sk[C];
+                if (C == 1) {
+                    const uint4 sl = reinterpret_cast<const uint4 *>(idtab)[slot];
+                    r = sl.z;
+                    if (r == 0) break;
+                    sk[0] = (uint64_t)sl.x | ((uint64_t)sl.y << 32);
+                } else {
+                    r = idtab[slot];
+                    if (r == 0) break;
 #pragma unroll
-                for (int w = 0; w < C; w++) sk[w] = keys[(uint64_t)(r - 1) * C + w];
+                    for (int w = 0; w < C; w++) sk[w] = keys[(uint64_t)(r - 1) * C + w];
+                }
                 if (keys_equal<C>(sk, ck)) {
                     id = keys_equal<C>(ck, fw) ? (int64_t)r : -(int64_t)r;
                     valid++;
