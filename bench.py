@@ -137,7 +137,7 @@ def main():
     # measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
     # MI355X_MICROARCH.md prescribes) -- only valid for the workload they were collected on
     traffic_ins = traffic_qry = None
-    pmc = os.path.join(ROOT, "profiles", "r01s_pmc_traffic.json")  # tools/profile_round.sh + tools/pmc_traffic.py
+    pmc = os.path.join(ROOT, "profiles", "r01t_pmc_traffic.json")  # tools/profile_round.sh + tools/pmc_traffic.py
     if os.path.exists(pmc) and args.workload == "m2" and args.scale == 1.0:
         with open(pmc) as f:
             t = json.load(f)
