@@ -118,10 +118,13 @@ namespace TwoPaCo
 				{
 					try
 					{
+						PhaseTimer setupTimer;
 						if (tpc_ctx_create(options.device, &ctx_) != 0)
 						{
 							throw std::runtime_error("Can't create a GPU context (no MI355X visible?)");
 						}
+
+						setupTimer.Lap("  setup thread: HIP start-up + context");
 
 						Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
 						// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
@@ -130,6 +133,7 @@ namespace TwoPaCo
 						const double budget = gb ? std::atof(gb) : 20.0;
 						Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(budget * double(1ull << 30))), "set_option");
 						Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
+						setupTimer.Lap("  setup thread: parameters + filter allocation");
 					}
 					catch (std::exception & e)
 					{
