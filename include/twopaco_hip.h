@@ -62,6 +62,11 @@ int tpc_ctx_create(int device, tpc_ctx **out);
 void tpc_ctx_destroy(tpc_ctx *ctx);
 const char *tpc_last_error(const tpc_ctx *ctx);
 
+/* Optional: make the runtime load every kernel code object now (one trivial launch per translation unit) instead of
+ * at the first real launch.  Touches no context state, so a one-shot caller can run it on a second host thread
+ * while it uploads the text. */
+int tpc_warmup(tpc_ctx *ctx);
+
 /* Hash parameters: vertex length k, filter bits L (filter has 2^L bits), q functions and
  * their character tables seed_table[q][5] (A,C,G,T,N) -- the only entries of
  * CharacterHash::hashvalues the path ever reads (characterhash.h:41-59).  Replaces

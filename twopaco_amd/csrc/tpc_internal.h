@@ -145,3 +145,10 @@ int tpc_launch_stream_plan(hipStream_t s, const uint64_t *d_rec_start, const uin
                            const int64_t *ids, uint64_t n_marks, uint64_t *vscan, void *rec, uint32_t r_last, uint64_t *totals_host);
 int tpc_launch_stream_write(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
                             const int64_t *ids, uint64_t n_marks, const uint64_t *vscan, const void *rec, uint32_t r_last, uint64_t first_stub, uint32_t *out);
+
+// code-object warm-up (one trivial launch per translation unit), used by tpc_warmup
+void tpc_warm_pass1(hipStream_t s);
+void tpc_warm_partition(hipStream_t s);
+void tpc_warm_qpartition(hipStream_t s);
+void tpc_warm_pass2(hipStream_t s);
+void tpc_warm_stream(hipStream_t s);

@@ -416,3 +416,7 @@ int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl0, ui
     if (rc) return rc;
     return tpc_launch_insert_part_apply(a, pl, fresh);
 }
+
+// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+__global__ void k_warm_partition() {}
+void tpc_warm_partition(hipStream_t s) { hipLaunchKernelGGL(k_warm_partition, dim3(1), dim3(64), 0, s); }

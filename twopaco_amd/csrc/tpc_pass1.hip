@@ -377,3 +377,7 @@ int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *
     hipLaunchKernelGGL(k_hash_dump, dim3(blocks), dim3(128), 0, a.stream, a.P, a.tab, a.bases, a.nmask, g0, n, out);
     return 0;
 }
+
+// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+__global__ void k_warm_pass1() {}
+void tpc_warm_pass1(hipStream_t s) { hipLaunchKernelGGL(k_warm_pass1, dim3(1), dim3(64), 0, s); }

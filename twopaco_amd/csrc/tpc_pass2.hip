@@ -16,6 +16,19 @@
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 
+// This file is compiled twice (csrc/Makefile): part 0 holds everything for keys of one or two words (k <= 60, what nearly
+// every run uses); part 1 (-DTPC_PASS2_PART=1 -> tpc_pass2_long.o) only the kernels templated on C = 3..19 words.  The
+// runtime loads a code object at the first launch from it, so a run with short keys never loads the 5 MB of long-key
+// code (18 -> 3 ms of start-up).
+#ifndef TPC_PASS2_PART
+#define TPC_PASS2_PART 0
+#endif
+#if TPC_PASS2_PART == 0
+#define TPC_PASS2_FN(name) name
+#else
+#define TPC_PASS2_FN(name) name##_long
+#endif
+
 namespace {
 
 constexpr uint64_t EMPTY = ~0ull;
@@ -448,16 +461,34 @@ inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b
 
 }  // namespace
 
+#if TPC_PASS2_PART == 0
 #define TPC_DISPATCH_C(C_, CALL)                                                                  \
     switch (C_) {                                                                                 \
-    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;       \
+    case 1: CALL(1); break; case 2: CALL(2); break;                                               \
+    default: return -1;                                                                           \
+    }
+#else
+#define TPC_DISPATCH_C(C_, CALL)                                                                  \
+    switch (C_) {                                                                                 \
+    case 3: CALL(3); break; case 4: CALL(4); break;                                               \
     case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;       \
     case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
     case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
     case 17: CALL(17); break; case 18: CALL(18); break; case 19: CALL(19); break;                 \
     default: return -1;                                                                           \
     }
+#endif
+// the long-key halves of the four dispatching launchers (tpc_pass2_long.o)
+int tpc_launch_filter2_long(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
+                            unsigned long long *overflow);
+int tpc_launch_scan2_write_long(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                                const uint64_t *block_off, uint64_t *keys_out);
+int tpc_launch_idtab_build_long(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap);
+int tpc_launch_sort_keys_long(hipStream_t s, int C, uint64_t *keys, uint64_t J);  // multi-word keys (C >= 2)
+int tpc_launch_emit_long(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
+                         const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid);
 
+#if TPC_PASS2_PART == 0
 int tpc_launch_mask_count(hipStream_t s, const uint32_t *mask, uint64_t n_words, uint64_t *block_sums, unsigned long long *n_out)
 {
     const unsigned nb = nblk(n_words, 256);
@@ -486,10 +517,15 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap)
     return 0;
 }
 
-int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
+#endif  // part 0 only
+
+int TPC_PASS2_FN(tpc_launch_filter2)(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
                        unsigned long long *overflow)
 {
     if (n_marks == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_filter2_long(a, C, marks, n_marks, table, cap, counted, overflow);
+#endif
 #define CALL(C_)                                                                                                                         \
     if (counted) hipLaunchKernelGGL((k_filter2<C_, true>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, \
                                     marks, n_marks, (Slot *)table, cap, overflow);                                                       \
@@ -500,8 +536,9 @@ int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_
     return 0;
 }
 
-uint64_t tpc_scan2_chunk(uint64_t cap) { return ((cap + TPC_SCAN2_BLOCKS - 1) / TPC_SCAN2_BLOCKS + 255) / 256 * 256; }
+uint64_t TPC_PASS2_FN(tpc_scan2_chunk)(uint64_t cap) { return ((cap + TPC_SCAN2_BLOCKS - 1) / TPC_SCAN2_BLOCKS + 255) / 256 * 256; }
 
+#if TPC_PASS2_PART == 0
 int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, uint64_t abundance, bool counted, uint64_t *block_tp,
                            uint64_t *block_used, unsigned long long *totals)
 {
@@ -513,16 +550,22 @@ int tpc_launch_scan2_count(const TpcLaunch &a, const void *table, uint64_t cap, 
     return 0;
 }
 
-int tpc_launch_scan2_write(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+#endif  // part 0 only
+
+int TPC_PASS2_FN(tpc_launch_scan2_write)(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, uint64_t abundance, bool counted,
                            const uint64_t *block_off, uint64_t *keys_out)
 {
-    const uint64_t chunk = tpc_scan2_chunk(cap);
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_scan2_write_long(a, C, marks, table, cap, abundance, counted, block_off, keys_out);
+#endif
+    const uint64_t chunk = TPC_PASS2_FN(tpc_scan2_chunk)(cap);
 #define CALL(C_) hipLaunchKernelGGL((k_scan2_write<C_>), dim3(TPC_SCAN2_BLOCKS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, chunk, abundance, counted ? 1 : 0, block_off, keys_out)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
 }
 
+#if TPC_PASS2_PART == 0
 int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J, void **scratch, size_t *scratch_bytes)
 {
     if (J < 2) return 0;
@@ -549,6 +592,13 @@ int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J
         if (e == hipSuccess) e = hipMemcpyAsync(keys, out, J * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
         return e == hipSuccess ? 0 : -2;
     }
+    return tpc_launch_sort_keys_long(s, C, keys, J);
+}
+#endif  // part 0 only
+
+#if TPC_PASS2_PART == 1
+int tpc_launch_sort_keys_long(hipStream_t s, int C, uint64_t *keys, uint64_t J)
+{
     // C > 1: CompressedString::Less compares word 0 first (compressedstring.h:93-104), so an LSD
     // pass sequence sorts by word C-1 first and word 0 last, each pass stable.
     uint64_t *kw = nullptr, *kw2 = nullptr, *out = nullptr;
@@ -576,23 +626,35 @@ int tpc_launch_sort_keys(hipStream_t s, int C, int k, uint64_t *keys, uint64_t J
     (void)hipFree(kw); (void)hipFree(kw2); (void)hipFree(out); (void)hipFree(perm); (void)hipFree(perm2); (void)hipFree(tmp);
     return rc;
 }
+#endif  // part 1 only
 
-
-int tpc_launch_idtab_build(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap)
+int TPC_PASS2_FN(tpc_launch_idtab_build)(hipStream_t s, int C, const uint64_t *keys, uint64_t J, uint32_t *idtab, uint64_t cap)
 {
     if (J == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_idtab_build_long(s, C, keys, J, idtab, cap);
+#endif
 #define CALL(C_) hipLaunchKernelGGL((k_idtab_build<C_>), dim3(nblk(J, 256)), dim3(256), 0, s, keys, J, idtab, cap)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
 }
 
-int tpc_launch_emit(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
+int TPC_PASS2_FN(tpc_launch_emit)(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, const uint64_t *keys, uint64_t J,
                     const uint32_t *idtab, uint64_t cap, int64_t *ids, unsigned long long *n_valid)
 {
     if (n_marks == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_emit_long(a, C, marks, n_marks, keys, J, idtab, cap, ids, n_valid);
+#endif
 #define CALL(C_) hipLaunchKernelGGL((k_emit<C_>), dim3(std::min<unsigned>(nblk(n_marks, 256), 16384u)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, keys, J, idtab, cap, ids, n_valid)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;
 }
+
+#if TPC_PASS2_PART == 0
+// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+__global__ void k_warm_pass2() {}
+void tpc_warm_pass2(hipStream_t s) { hipLaunchKernelGGL(k_warm_pass2, dim3(1), dim3(64), 0, s); }
+#endif

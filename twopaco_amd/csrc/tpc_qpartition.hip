@@ -788,3 +788,7 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
     hipLaunchKernelGGL(k_surv_gather, dim3(64, QS_LISTS), dim3(256), 0, a.stream, pl.surv, pl.surv_cur, pl.surv_cap, out);
     return 0;
 }
+
+// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+__global__ void k_warm_qpartition() {}
+void tpc_warm_qpartition(hipStream_t s) { hipLaunchKernelGGL(k_warm_qpartition, dim3(1), dim3(64), 0, s); }

@@ -114,6 +114,7 @@ namespace TwoPaCo
 				// the device context and the filter allocation (HIP start-up, 2^L/8 bytes of hipMalloc) do not depend
 				// on the input: they are set up by a second thread while this one parses and packs the FASTA files
 				std::string setupError;
+				std::thread warm;
 				std::thread setup([&]()
 				{
 					try
@@ -125,6 +126,8 @@ namespace TwoPaCo
 						}
 
 						setupTimer.Lap("  setup thread: HIP start-up + context");
+						// the kernels' code objects load on a third thread while the filter is allocated and the text goes up
+						warm = std::thread([this]() { PhaseTimer warmTimer; tpc_warmup(ctx_); warmTimer.Lap("  warm-up thread: code objects"); });
 
 						Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
 						// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
@@ -149,6 +152,7 @@ namespace TwoPaCo
 				catch (...)
 				{
 					setup.join();
+					if (warm.joinable()) warm.join();
 					throw;
 				}
 
@@ -156,10 +160,15 @@ namespace TwoPaCo
 				setup.join();
 				if (!setupError.empty())
 				{
+					if (warm.joinable()) warm.join();
 					throw std::runtime_error(setupError);
 				}
 
-				Check(tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
+				{
+					const int rcUpload = tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length);
+					if (warm.joinable()) warm.join();
+					Check(rcUpload, "seq_upload");
+				}
 				timer.Lap("context + upload");
 
 				Check(tpc_run_begin(ctx_), "run_begin");
