@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- junction-enumeration hot path on MI355X, BASELINE.json's metric.
+"""bench.py -- junction-enumeration hot path on MI355X, BASELINE.json's metric
+("k-mers hashed/sec + end-to-end junctions/sec, 62 E. coli k=25 f=36, 1/2/4/8 GPU").
 
 A "step" is one full pass of the hot path over the synthetic workload, input already packed and
 resident in HBM: Bloom filter reset, first-pass insert, first-pass query, candidate compaction,
 second-pass exact filter, junction key sort + id index, output-pass id lookup (junction records
 left in HBM).  value = vertex k-mers through the whole path per second, whole job.
+The second half of the metric -- end-to-end junction occurrences per second, process start to file
+close -- is measured at N = 1 by running the `twopaco` CLI as a child process on the same workload
+written out as FASTA files (`e2e` in the JSON line).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload m2|m1] [--scale S]
+                  [--decomposition ranges|address] [--cpu-baseline sample|full|none] [--e2e-runs R]
 
-N > 1 is launched by torch.distributed.run (one process per GPU, RCCL); see twopaco_amd/dist.py.
-Rank 0 prints ONE JSON line.
+--gpus N > 1 without a launcher (no WORLD_SIZE in the environment) starts
+`python -m torch.distributed.run --nproc-per-node N` on this file as a CHILD process (before anything
+touches the GPU) and passes its output and exit code through; under a launcher every rank runs
+twopaco_amd/dist.py:bench_main (one process per GPU, RCCL).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import re
+import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -23,13 +33,44 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from twopaco_amd import capi, synth  # noqa: E402
-
-G_BYTES = 64          # HBM access granule of a scattered 4-byte access (SURVEY 8d planning value)
+G_BYTES = 64           # HBM access granule of a scattered 4-byte access (SURVEY 8d planning value)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
+GOLDEN_SEED = 20240229  # tests/golden/make_golden.py: the seed the reference goldens were made with
+PMC_PROFILE = "r02_pmc_traffic.json"
+
+
+def launch_ranks(args):
+    """bench.py --gpus N, N > 1, no launcher: become the parent of torch.distributed.run (child process)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def csrc_signature():
+    """sha256 over the kernel sources: PMC byte counts collected on other kernels must not be reported as this run's."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "twopaco_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def golden_case(workload, scale):
+    name = {("m2", 1.0): "m2_full", ("m1", 1.0): "m1_full"}.get((workload, scale))
+    path = os.path.join(ROOT, "tests", "golden", "cases.json")
+    if not name or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for c in json.load(f):
+            if c["name"] == name:
+                return c
+    return None
 
 
 def one_step(ctx, abundance=(1 << 64) - 1):
@@ -43,38 +84,104 @@ def one_step(ctx, abundance=(1 << 64) - 1):
     return marks, st, J, n_valid
 
 
-def cpu_baseline(recs, p, n_genomes=6, timeout=240):
-    """The REAL reference binary (oracle/_ref/twopaco_ref, built from /root/reference) on a bounded
-    sample of the same workload, on this host's cores.  Falls back to the C oracle (kind 'port')."""
+def write_fasta_files(recs, tmp, n=None):
+    from twopaco_amd import synth
+    files = []
+    for i, r in enumerate(recs[:n]):
+        path = os.path.join(tmp, "g%d.fa" % i)
+        synth.write_fasta(path, [r], first_id=i)
+        files.append(path)
+    return files
+
+
+def sha256_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def e2e_cli(files, p, golden, runs, tmp):
+    """End-to-end junction occurrences per second (SURVEY 8d metric 2; reference path constructor.cpp:161-176 -> VE ctor ->
+    junctionapi.h:118-132): the `twopaco` CLI as a fresh child process, wall clock from process start to exit (output
+    file closed), FASTA files in the page cache, output sha256 checked against the reference golden."""
+    exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
+    threads = str(min(64, os.cpu_count() or 1))
+    walls, occ, sha_ok = [], None, None
+    for rep in range(runs):
+        out = os.path.join(tmp, "e2e_%d.bin" % rep)  # a fresh file each time
+        cmd = [exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", str(GOLDEN_SEED), "--tmpdir", tmp, "-o", out] + files
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        if res.returncode != 0:
+            return {"error": res.stderr.decode()[-400:]}
+        walls.append(wall)
+        occ = int(re.search(r"True marks count: (\d+)", res.stdout.decode()).group(1))
+        if rep == 0 and golden:
+            sha_ok = sha256_file(out) == golden["bin_sha256"] and occ == golden["true_marks"]
+            if not sha_ok:
+                return {"error": "e2e output differs from the reference golden %s" % golden["name"]}
+        os.unlink(out)
+        time.sleep(1.0)  # the driver releases the previous process's device memory asynchronously
+    walls.sort()
+    med = walls[len(walls) // 2]
+    return {"e2e_wall_s": med, "e2e_wall_s_min": walls[0], "e2e_wall_s_all": walls, "e2e_junction_occurrences_per_sec": occ / med,
+            "junction_occurrences": occ, "runs": runs, "host_threads": int(threads),
+            "output_sha256_equals_reference": sha_ok,
+            "what": "twopaco CLI child process, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (len(files), runs)}
+
+
+def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
+    """The REAL reference binary (oracle/_ref/twopaco_ref, built from /root/reference) on this host's cores.
+    sample: the first 6 genomes (bounded: ~1 min); full: the whole workload (several minutes; also times the fixed
+    cost -- the serial filter zeroing of concurrentbitvector.cpp:11-24 -- with a one-record input).
+    Falls back to the C oracle (kind 'port') when the reference build is absent."""
+    from twopaco_amd import synth
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "twopaco_ref")
-    sample = recs[:n_genomes]
+    sample = recs if mode == "full" else recs[:6]
     kmers = synth.n_kmers(sample, p["k"])
-    tmp = tempfile.mkdtemp()
     if os.path.exists(ref):
-        files = []
-        for i, r in enumerate(sample):
-            path = os.path.join(tmp, "s%d.fa" % i)
-            synth.write_fasta(path, [r], first_id=i)
-            files.append(path)
-        for L in (p["L"], 32):
-            cmd = [ref, "-k", str(p["k"]), "-f", str(L), "-q", str(p["q"]), "-t", str(cores), "--tmpdir", tmp, "-o", os.path.join(tmp, "ref.bin")] + files
+        files = write_fasta_files(sample, tmp)
+
+        def run(fs, L, to):
+            cmd = [ref, "-k", str(p["k"]), "-f", str(L), "-q", str(p["q"]), "-t", str(cores), "--tmpdir", tmp, "-o", os.path.join(tmp, "ref.bin")] + fs
             t0 = time.time()
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=to)
+            return time.time() - t0, res
+
+        fixed = None
+        if mode == "full":
+            tiny = os.path.join(tmp, "tiny.fa")
+            synth.write_fasta(tiny, [recs[0][:2000]])
             try:
-                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+                fixed, _ = run([tiny], p["L"], 1200)
+            except subprocess.TimeoutExpired:
+                fixed = None
+        for L in (p["L"], 32):
+            try:
+                wall, res = run(files, L, 3600 if mode == "full" else timeout)
             except subprocess.TimeoutExpired:
                 continue
-            wall = time.time() - t0
             if res.returncode != 0:
                 continue
             log = res.stdout.decode()
             m = re.search(r"\n1\t(\d+)\t(\d+)\t", log)
             occ = int(re.search(r"True marks count: (\d+)", log).group(1))
-            return {"value": kmers / wall, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-                    "sample": "first %d genomes of the workload (%d k-mers), k=%d q=%d f=%d, reference binary -t %d, wall %.1f s "
-                              "(its log: fill %s s incl. serial filter zeroing, query %s s); %d junction occurrences"
-                              % (n_genomes, kmers, p["k"], p["q"], L, cores, wall, m.group(1) if m else "?", m.group(2) if m else "?", occ),
-                    "junction_occurrences_per_sec": occ / wall}
+            out = {"value": kmers / wall, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+                   "sample": "%s of the workload (%d genomes, %d k-mers), k=%d q=%d f=%d, reference binary -t %d, wall %.1f s "
+                             "(its log: fill %s s incl. serial filter zeroing, query %s s); %d junction occurrences"
+                             % ("all" if mode == "full" else "first 6 genomes", len(sample), kmers, p["k"], p["q"], L, cores, wall,
+                                m.group(1) if m else "?", m.group(2) if m else "?", occ),
+                   "junction_occurrences_per_sec": occ / wall, "wall_s": wall}
+            if fixed is not None:
+                out["fixed_cost_s"] = fixed
+                out["value_without_fixed_cost"] = kmers / max(wall - fixed, 1e-9)
+                out["sample"] += "; a 2 kbp input takes %.1f s (filter allocation + serial zeroing, concurrentbitvector.cpp:11-24)" % fixed
+            return out
+    import numpy as np
     from oracle import oracle as O
     o = O.Oracle(p["k"], min(p["L"], 32), p["q"], O.seed_table(1, p["q"], min(p["L"], 32)))
     letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
@@ -91,15 +198,20 @@ def cpu_baseline(recs, p, n_genomes=6, timeout=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="m2")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
+    ap.add_argument("--e2e-runs", type=int, default=3, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
     ap.add_argument("--decomposition", default="ranges", choices=["ranges", "address"],
                     help="multi-GPU: vertex-hash ranges (default) or the address-sharded filter (power-of-two N)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,13 +220,17 @@ def main():
         from twopaco_amd import dist as tdist
         return tdist.bench_main(args, rank, world, local_rank)
 
+    import torch
+    from twopaco_amd import capi, synth
+
     torch.cuda.set_device(0)
     recs, p = synth.workload(args.workload, scale=args.scale)
     n_kmers = synth.n_kmers(recs, p["k"])
+    golden = golden_case(args.workload, args.scale)
     text = capi.PackedText.from_codes(recs)
     ctx = capi.Context(0)
     ctx.set_option("insert_test_first", args.test_first)
-    ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=12345))
+    ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=GOLDEN_SEED))
     t0 = time.time()
     ctx.seq_upload(text)
     torch.cuda.synchronize()
@@ -133,48 +249,82 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms = {n: v / args.steps for n, v in kms.items()}
+    result = {"candidate_marks": marks, "junctions": J, "junction_occurrences": n_valid, **st}
+    result_ok = None
+    if golden:  # the reference's own counters for this workload (VE.h:384-388), tests/golden/cases.json
+        r = golden["rounds"][0]
+        result_ok = (marks, J, st["true"], st["false"], st["table"]) == (r["marks"], golden["distinct"], r["true"], r["false"], r["table"])
+        if not result_ok:
+            print("bench: result %r differs from the reference golden %r" % (result, r), file=sys.stderr)
+            sys.exit(3)
+    ctx.close()
 
-    # measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
-    # MI355X_MICROARCH.md prescribes) -- only valid for the workload they were collected on
+    # HBM bytes per launch: (1) what the write-combining design has to move by construction (DESIGN.md section 3:
+    # every Bloom address is written once and read once per partition level, read once more where it is applied,
+    # plus one pass over the filter and the packed text) -- the figure `achieved` is priced with, <= measured bytes
+    # by construction so frac <= 1; (2) the PMC counters of a rocprofv3 run of this same command (profiles/), only
+    # reported when the kernel sources have not changed since.  SURVEY 8d's scattered-atomic model (2 x 64 B per
+    # probe) describes the direct kernels; it is printed as `survey_model_GBs` for reference, never as a fraction.
+    q = p["q"]
+    filter_bytes = (1 << p["L"]) // 8
+    ins_addr, qry_addr = q * n_kmers, 6 * n_kmers
+    design_ins = 0.375 * n_kmers + ins_addr * 4 * 4 + filter_bytes          # W l1, R+W l2, R apply; filter written once
+    design_qry = 0.375 * n_kmers + qry_addr * 8 * 4 + filter_bytes          # uint64 entries; filter read once
     traffic_ins = traffic_qry = None
-    pmc = os.path.join(ROOT, "profiles", "r01t_pmc_traffic.json")  # tools/profile_round.sh + tools/pmc_traffic.py
+    pmc_tag = None
+    pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
     if os.path.exists(pmc) and args.workload == "m2" and args.scale == 1.0:
         with open(pmc) as f:
             t = json.load(f)
-        traffic_ins, traffic_qry = t["groups"]["insert"], t["groups"]["query"]
-    b_ins = 0.25 + p["q"] * 2 * G_BYTES     # RFO + write-back of one granule per probe
-    b_chk = 0.375 + 6 * G_BYTES            # ~6 absent-edge probes per k-mer
-    ach_ins = n_kmers * b_ins / (kms["insert"] * 1e-3) / 1e9
-    ach_chk = n_kmers * b_chk / (kms["query"] * 1e-3) / 1e9
+        if t.get("csrc_signature") == csrc_signature():
+            traffic_ins, traffic_qry = t["groups"]["insert"], t["groups"]["query"]
+            pmc_tag = PMC_PROFILE
+        else:
+            pmc_tag = "stale: %s was collected on other kernel sources" % PMC_PROFILE
+
+    def roof(kernel, ms, design, traffic, survey_bytes):
+        ach = design / (ms * 1e-3) / 1e9
+        d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": traffic, "traffic_source": pmc_tag, "launch_ms": ms, "algorithmic_bytes_per_launch": design,
+             "algorithmic_bytes_per_kmer": design / n_kmers,
+             "measured_hbm_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
+             "measured_hbm_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+             "survey_model_GBs": n_kmers * survey_bytes / (ms * 1e-3) / 1e9}
+        return d
+
     out = {
         "metric": "kmers_hashed_per_sec", "value": n_kmers * args.steps / dt, "unit": "k-mers/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d, 1 round"
                                % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
-                   "kmers": n_kmers, "filter_bytes": (1 << p["L"]) // 8, "insert_test_first": args.test_first},
+                   "kmers": n_kmers, "filter_bytes": filter_bytes, "insert_test_first": args.test_first, "decomposition": "single GPU"},
         "junction_occurrences_per_sec": n_valid * args.steps / dt,
         "insert_kmers_per_sec": n_kmers / (kms["insert"] * 1e-3),
         "query_kmers_per_sec": n_kmers / (kms["query"] * 1e-3),
         "kernel_ms": kms,
-        "result": {"candidate_marks": marks, "junctions": J, "junction_occurrences": n_valid, **st},
+        "result": result,
+        "result_equals_reference_golden": result_ok,
         "upload_s_pcie": upload_s,
         # the dominant kernel group of a step is the first-pass query (k_q_hash + k_q_split + k_q_lookup + k_q_verify)
-        "roofline": {"bound": "hbm", "kernel": "first-pass query (k_q_hash, k_q_split, k_q_lookup, k_q_verify)", "achieved": ach_chk,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_chk / HBM_PEAK_GBS, "traffic": traffic_qry,
-                     "algorithmic_bytes_per_kmer": b_chk, "launch_ms": kms["query"],
-                     # the same launch priced with the bytes the PMC counters saw instead of the model's
-                     "measured_hbm_GBs": (traffic_qry / (kms["query"] * 1e-3) / 1e9) if traffic_qry else None,
-                     "measured_hbm_frac": (traffic_qry / (kms["query"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_qry else None},
+        "roofline": roof("first-pass query (k_q_hash, k_q_split, k_q_lookup, k_q_verify)", kms["query"], design_qry, traffic_qry, 0.375 + 6 * G_BYTES),
         # the north star's roofline kernel: first-pass Bloom insert
-        "roofline_insert": {"bound": "hbm", "kernel": "first-pass insert (k_part_hash, k_part_split, k_part_apply)", "achieved": ach_ins,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_ins / HBM_PEAK_GBS, "traffic": traffic_ins,
-                            "algorithmic_bytes_per_kmer": b_ins, "word_level_bytes_per_kmer": 0.25 + 8 * p["q"], "launch_ms": kms["insert"],
-                            "measured_hbm_GBs": (traffic_ins / (kms["insert"] * 1e-3) / 1e9) if traffic_ins else None,
-                            "measured_hbm_frac": (traffic_ins / (kms["insert"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_ins else None},
+        "roofline_insert": roof("first-pass insert (k_part_hash, k_part_split, k_part_apply)", kms["insert"], design_ins, traffic_ins, 0.25 + q * 2 * G_BYTES),
     }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(recs, p)
+    tmp = tempfile.mkdtemp(prefix="tpc_bench_")
+    try:
+        if args.e2e_runs > 0:
+            files = write_fasta_files(recs, tmp)
+            out["e2e"] = e2e_cli(files, p, golden, args.e2e_runs, tmp)
+            if "error" in out["e2e"]:
+                print("bench: " + out["e2e"]["error"], file=sys.stderr)
+                sys.exit(4)
+            out["e2e_junction_occurrences_per_sec"] = out["e2e"]["e2e_junction_occurrences_per_sec"]
+            out["e2e_wall_s"] = out["e2e"]["e2e_wall_s"]
+        if not args.no_cpu_baseline and args.cpu_baseline != "none":
+            out["cpu_baseline"] = cpu_baseline(recs, p, tmp, args.cpu_baseline)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     print(json.dumps(out))
 
 

@@ -21,11 +21,13 @@
  * text  T = N rec0 N rec1 N ... recS-1 N  (codes A0 C1 G2 T3 N4) indexed by a
  * global position g; seq coordinate = g - rec_start[r].
  */
+#define _GNU_SOURCE /* MAP_ANONYMOUS / MAP_NORESERVE under -std=c11 */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <sys/mman.h>
 
 #define ORC_N 4
 #define ORC_INVALID_VERTEX INT64_MAX /* graphconstructor/common.cpp:5 */
@@ -240,6 +242,23 @@ static inline int bit_get(const uint32_t *f, uint64_t i) { return (f[i >> 5] >> 
 static inline void bit_set(uint32_t *f, uint64_t i) { f[i >> 5] |= 1u << (i & 31); }           /* :31-37 */
 
 /* ------------------------------------------------------------------ lifecycle */
+static uint64_t filter_words(const orc_run *R);
+/* A zeroed filter (ConcurrentBitVector ctor, concurrentbitvector.cpp:11-24).  calloc, not malloc + memset: the
+ * pages of a 2^38..2^40-bit filter that a small test text never touches then cost nothing. */
+static void filter_free(orc_run *R)
+{
+    if (R->filter) munmap(R->filter, filter_words(R) * sizeof(uint32_t));
+    R->filter = NULL;
+}
+static int filter_zero(orc_run *R)
+{   /* anonymous zero pages, not reserved: a 128 GiB filter that a test text touches in a few thousand places is fine */
+    filter_free(R);
+    void *p = mmap(NULL, filter_words(R) * sizeof(uint32_t), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) { snprintf(R->err, sizeof R->err, "cannot map a %d-bit filter", R->L); return -1; }
+    R->filter = (uint32_t *)p;
+    return 0;
+}
+
 orc_run *orc_create(int k, int L, int q, const uint64_t *table)
 {
     if (q < 1 || q > 16 || L < 2 || L > 62 || k < 1) return NULL;
@@ -262,7 +281,7 @@ orc_run *orc_create(int k, int L, int q, const uint64_t *table)
 void orc_destroy(orc_run *R)
 {
     if (!R) return;
-    free(R->txt); free(R->rec_start); free(R->rec_len); free(R->filter); free(R->mask); free(R->rmask);
+    free(R->txt); free(R->rec_start); free(R->rec_len); filter_free(R); free(R->mask); free(R->rmask);
     free(R->keys); free(R->out_seq); free(R->out_pos); free(R->out_id);
     free(R);
 }
@@ -492,7 +511,8 @@ static uint32_t *build_run_lengths(const orc_run *R)
 static void split_pass(orc_run *R, uint32_t *bins, uint64_t bin_size)
 {
     uint64_t nw = filter_words(R);
-    uint32_t *f = (uint32_t *)calloc(nw, sizeof(uint32_t));
+    uint32_t *f = (uint32_t *)mmap(NULL, nw * sizeof(uint32_t), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (f == MAP_FAILED) abort();
     uint64_t addr[16];
     orc_vhash v;
     for (uint32_t r = 0; r < R->nrec; r++) {
@@ -520,7 +540,7 @@ static void split_pass(orc_run *R, uint32_t *bins, uint64_t bin_size)
             }
         }
     }
-    free(f);
+    munmap(f, nw * sizeof(uint32_t));
 }
 
 /* FilterFillerWorker VE.h:995-1105 over the global text. */
@@ -678,10 +698,10 @@ int orc_enumerate(orc_run *R, int rounds, uint64_t abundance)
     }
     uint32_t *run = build_run_lengths(R);
     uint64_t mw = (R->ntxt >> 5) + 1;
-    free(R->mask); free(R->rmask); free(R->filter); free(R->keys);
+    free(R->mask); free(R->rmask); filter_free(R); free(R->keys);
     R->mask = (uint32_t *)calloc(mw, sizeof(uint32_t));
     R->rmask = (uint32_t *)calloc(mw, sizeof(uint32_t));
-    R->filter = (uint32_t *)malloc(filter_words(R) * sizeof(uint32_t));
+    R->filter = NULL;
     R->keys = NULL; R->nkeys = 0; R->nout = 0; R->rounds = rounds;
     uint64_t low = 0, high = real_size, low_boundary = 0;
     for (int round = 0; round < rounds; round++) {
@@ -694,7 +714,7 @@ int orc_enumerate(orc_run *R, int rounds, uint64_t abundance)
             high = low_boundary * bin_size;
         } else high = real_size;
         R->r_low[round] = low; R->r_high[round] = high;
-        memset(R->filter, 0, filter_words(R) * sizeof(uint32_t));
+        if (filter_zero(R)) { free(run); free(bins); return -1; }
         memset(R->rmask, 0, mw * sizeof(uint32_t));
         fill_pass(R, run, low, high);
         R->r_marks[round] = check_pass(R, run, low, high);
@@ -775,10 +795,10 @@ void orc_hash_dump(const orc_run *R, uint64_t g, uint64_t *posneg, int c, uint64
 int orc_dist_begin(orc_run *R)
 {
     uint64_t mw = (R->ntxt >> 5) + 1;
-    free(R->mask); free(R->rmask); free(R->filter); free(R->keys);
+    free(R->mask); free(R->rmask); filter_free(R); free(R->keys);
     R->mask = (uint32_t *)calloc(mw, sizeof(uint32_t));
     R->rmask = (uint32_t *)calloc(mw, sizeof(uint32_t));
-    R->filter = (uint32_t *)malloc(filter_words(R) * sizeof(uint32_t));
+    R->filter = NULL;
     R->keys = NULL; R->nkeys = 0; R->nout = 0;
     return 0;
 }
@@ -788,7 +808,7 @@ int orc_dist_round(orc_run *R, uint64_t low, uint64_t high, uint64_t abundance, 
 {
     uint32_t *run = build_run_lengths(R);
     uint64_t mw = (R->ntxt >> 5) + 1;
-    memset(R->filter, 0, filter_words(R) * sizeof(uint32_t));
+    if (filter_zero(R)) { free(run); return -1; }
     memset(R->rmask, 0, mw * sizeof(uint32_t));
     fill_pass(R, run, low, high);
     uint64_t marks = check_pass(R, run, low, high);
@@ -837,8 +857,7 @@ int orc_split_bins(orc_run *R, uint32_t *bins)
 int orc_fill_only(orc_run *R, uint64_t low, uint64_t high)
 {
     uint32_t *run = build_run_lengths(R);
-    free(R->filter);
-    R->filter = (uint32_t *)calloc(filter_words(R), sizeof(uint32_t));
+    if (filter_zero(R)) { free(run); return -1; }
     fill_pass(R, run, low, high);
     free(run);
     return 0;

@@ -161,3 +161,18 @@ def comm_worker(rank, world, port, result_path):
             pickle.dump(gathered, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def bench_backend(args, rank, world):
+    """TPC_BENCH_BACKEND hook for tests/test_dist_cpu.py::test_bench_gpus_flag_launches_ranks: the oracle as the rank
+    backend of `bench.py --gpus N` (TEST ONLY -- exercises the launcher, the rendezvous, the timed loop and the JSON
+    line on a machine without GPUs; the product path never loads the oracle)."""
+    from helpers import GOLDEN, golden_cases
+    from oracle import oracle as O
+
+    case = [c for c in golden_cases() if c["name"] == "rand6_k9_fp"][0]
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    o.add_fasta(os.path.join(GOLDEN, case["fasta"]))
+    p = {"k": case["k"], "L": case["L"], "q": case["q"]}
+    n_kmers = int((o.text != 4).sum())
+    return OracleBackend(o), n_kmers, p, "rand6.fa k=9 f=14 (test input)"

@@ -81,6 +81,22 @@ def write_rand_fa(path, n, nchr, seed, n_rate=1 / 500.0, change=0.05, indel_frac
     synth.write_fasta(path, recs, width=60)
 
 
+def write_longk_fa(path, seed=13):
+    """Records with long shared stretches, so that keys of 10-19 words (k = 301 / 603) have real junctions: chr0 random,
+    chr1 = chr0 with a substitution every ~1500 bases, chr2 = chr0 rotated (one breakpoint), chr3 = a 1300-base repeat
+    unit three times with one N, chr4 shorter than k = 603."""
+    base = synth.random_genome(6000, seed)
+    c1 = base.copy()
+    for i in range(700, 6000, 1500):
+        c1[i] = (c1[i] + 1) & 3
+    c2 = np.concatenate([base[2500:], base[:2500]])
+    unit = synth.random_genome(1300, seed + 1)
+    c3 = np.concatenate([unit, unit, unit])
+    c3[2000] = 4
+    c4 = base[100:500]
+    synth.write_fasta(path, [base, c1, c2, c3, c4], width=70)
+
+
 def parse_log(log):
     rounds = []
     for m in re.finditer(r"Round (\d+), (\d+):(\d+)", log):
@@ -94,23 +110,36 @@ def parse_log(log):
 
 
 def main():
+    # --only a,b,c : (re)generate just these cases and merge them into cases.json (the big synthetic
+    # cases take minutes to an hour and tens of GiB of filter each)
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     O.build()
-    tmp = tempfile.mkdtemp()
-    shutil.copy("/root/reference/example/example.fa", os.path.join(HERE, "example.fa"))
-    write_edge_fa(os.path.join(HERE, "edge.fa"))
-    write_rand_fa(os.path.join(HERE, "rand6.fa"), 3000, 6, 11)
-    write_rand_fa(os.path.join(HERE, "c2.fa"), 2500, 3, 12, n_rate=1 / 900.0, change=0.03)
+    tmp = tempfile.mkdtemp(dir=os.environ.get("TPC_GOLDEN_TMP"))
+    if only is None:
+        shutil.copy("/root/reference/example/example.fa", os.path.join(HERE, "example.fa"))
+        write_edge_fa(os.path.join(HERE, "edge.fa"))
+        write_rand_fa(os.path.join(HERE, "rand6.fa"), 3000, 6, 11)
+        write_rand_fa(os.path.join(HERE, "c2.fa"), 2500, 3, 12, n_rate=1 / 900.0, change=0.03)
+    if only is None or any(n.startswith("lk_") for n in only):
+        write_longk_fa(os.path.join(HERE, "lk.fa"))
 
     cases = []
 
-    def case(name, fasta, k, L, q=5, rounds=1, debug=False, abundance=None, keep_bin=True, synth_spec=None, files=None):
+    def case(name, fasta, k, L, q=5, rounds=1, debug=False, abundance=None, keep_bin=True, synth_spec=None, files=None, threads=1):
+        if only is not None and name not in only:
+            return
         if files is None:
             files = [os.path.join(HERE, fasta)]
+        elif callable(files):
+            files = files()
         out = os.path.join(tmp, name + ".bin")
-        log, _ = O.run_reference(files, k, L, q=q, rounds=rounds, threads=1, seed=SEED, out=out, tmpdir=tmp, debug=debug,
-                                 abundance=abundance)
+        # threads > 1 only for the big cases: the bytes and counters of a single-round run do not depend on the thread count
+        log, _ = O.run_reference(files, k, L, q=q, rounds=rounds, threads=threads, seed=SEED, out=out, tmpdir=tmp, debug=debug,
+                                 abundance=abundance, timeout=6 * 3600)
         data = open(out, "rb").read()
-        c = {"name": name, "fasta": fasta, "k": k, "L": L, "q": q, "n_rounds": rounds, "seed": SEED, "ref_debug_build": debug,
+        c = {"name": name, "fasta": fasta, "k": k, "L": L, "q": q, "n_rounds": rounds, "seed": SEED, "ref_debug_build": debug, "ref_threads": threads,
              "abundance": abundance, "bin_sha256": hashlib.sha256(data).hexdigest(), "bin_bytes": len(data)}
         if synth_spec:
             c["synth"] = synth_spec
@@ -145,19 +174,42 @@ def main():
     case("c2_k51_r2", "c2.fa", 51, 22, rounds=2)
     case("c2_k61", "c2.fa", 61, 22)
     case("c2_k125", "c2.fa", 125, 22)
+    # long keys (C = 10 and C = 19 words: the reference's MAX_CAPACITY, vertexenumerator.cpp:17-70) and q beyond 8
+    case("lk_k301", "lk.fa", 301, 22)
+    case("lk_k603", "lk.fa", 603, 22)
+    case("lk_k603_r2", "lk.fa", 603, 24, rounds=2)
+    case("lk_k159", "lk.fa", 159, 20)
+    case("rand6_k9_q12", "rand6.fa", 9, 20, q=12)
+    # collision-free multi-round runs: "first seen" in the split pass (VE.h:559-570) is then order independent,
+    # so the round ranges (VE.h:206-254) below are what ANY correct implementation must print
+    case("rand6_k9_L24_r4", "rand6.fa", 9, 24, rounds=4)
+    case("c2_k29_L26_r3", "c2.fa", 29, 26, rounds=3)
 
     # synthetic workloads of BASELINE.json's configs (FASTA regenerated from twopaco_amd/synth.py)
-    for name, wl, scale in [("m1_small", "m1", 0.02), ("m1_full", "m1", 1.0), ("m2_small", "m2", 0.004)]:
-        recs, p = synth.workload(wl, seed=12345, scale=scale)
-        L = p["L"] if scale == 1.0 else 26
-        files = []
-        for i, r in enumerate(recs):
-            path = os.path.join(tmp, "%s_%d.fa" % (name, i))
-            synth.write_fasta(path, [r], first_id=i)
-            files.append(path)
-        case(name, None, p["k"], L, q=p["q"], keep_bin=False, synth_spec={"workload": wl, "seed": 12345, "scale": scale}, files=files)
+    # m2_full = the bench workload (BASELINE configs[2]); m2_s05_f38 = the f = 38 geometry (512 bins per level) on a text the
+    # reference finishes in minutes; m2x8_f38 = configs[3]'s shape (multi-Gbp text, 32 GiB filter, several query batches)
+    for name, wl, scale, L, thr in [("m1_small", "m1", 0.02, 26, 1), ("m1_full", "m1", 1.0, None, 1), ("m2_small", "m2", 0.004, 26, 1),
+                                    ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m2x8_f38", "m2", 8.0, 38, 4)]:
+        if only is not None and name not in only:
+            continue
 
-    with open(os.path.join(HERE, "cases.json"), "w") as f:
+        def files(name=name, wl=wl, scale=scale):
+            recs, _ = synth.workload(wl, seed=12345, scale=scale)
+            out = []
+            for i, r in enumerate(recs):
+                path = os.path.join(tmp, "%s_%d.fa" % (name, i))
+                synth.write_fasta(path, [r], first_id=i)
+                out.append(path)
+            return out
+        p = synth.workload(wl, seed=12345, scale=0.0001)[1]
+        case(name, None, p["k"], L or p["L"], q=p["q"], keep_bin=False, synth_spec={"workload": wl, "seed": 12345, "scale": scale}, files=files, threads=thr)
+
+    path = os.path.join(HERE, "cases.json")
+    if only is not None:
+        old = json.load(open(path))
+        new = {c["name"] for c in cases}
+        cases = [c for c in old if c["name"] not in new] + cases
+    with open(path, "w") as f:
         json.dump(cases, f, indent=1)
     shutil.rmtree(tmp)
 

@@ -9,6 +9,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 
 
+# full-size synthetic workloads: minutes of work and GiBs of filter each -- dedicated tests, not the parametrised sweeps
+BIG = ("m1_full", "m2_full", "m2_s05_f38", "m2x8_f38")
+
+
 def golden_cases():
     with open(os.path.join(GOLDEN, "cases.json")) as f:
         return json.load(f)

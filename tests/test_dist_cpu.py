@@ -101,3 +101,27 @@ def test_address_sharded_collectives(world, tmp_path):
         assert got[r]["back"] == ([d + 1 for d in range(world) for _ in range(counts[d])], counts)
         assert got[r]["gather"] == [[10 * s + i for i in range(3)] for s in range(world)]
         assert got[r]["max"] == [world - 1, 7]
+
+
+def test_bench_gpus_flag_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks by itself (torch.distributed.run as
+    a child process) and rank 0 prints one JSON line with n_gpus = ranks = 2.  The ranks run the oracle backend over
+    gloo (TPC_BENCH_BACKEND, test only): what is under test is the launch path the driver's scaling run depends on."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TPC_DIST_BACKEND="gloo", TPC_BENCH_BACKEND="dist_worker:bench_backend",
+               PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2 and out["backend"] == "injected"
+    assert out["config"]["decomposition"] == "ranges"
+    case = CASES["rand6_k9_fp"]
+    assert out["result"]["junctions"] == case["distinct"] and out["result"]["junction_occurrences"] > 0

@@ -162,3 +162,33 @@ def test_junction_api_header_roundtrip(built, tmp_path):
         n = subprocess.check_output([exe, os.path.join(GOLDEN, case["bin"]), out]).decode().strip()
         assert int(n) == case["true_marks"]
         assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="build container only: needs the reference sources where they lie")
+def test_reference_main_and_selftest_compile_against_host_headers(built, tmp_path):
+    """INTEGRATION.md Option A: the reference's own constructor.cpp (its main) and test.cpp (its --test) compile
+    UNCHANGED against twopaco_amd/host/vertexenumerator.h and link against libtwopaco_host.so.  The two files are
+    copied to a temporary directory only (a quoted include resolves next to the including file first); nothing of
+    the reference enters the repository."""
+    import shutil
+    for f in ("constructor.cpp", "test.cpp", "test.h"):
+        shutil.copy(os.path.join(REF_SRC, "graphconstructor", f), str(tmp_path / f))
+    host = os.path.join(ROOT, "twopaco_amd", "host")
+    lib = os.path.join(ROOT, "twopaco_amd", "lib")
+    objs = []
+    for f in ("constructor.cpp", "test.cpp"):
+        obj = str(tmp_path / (f[:-4] + ".o"))
+        # -I host first: vertexenumerator.h, junctionapi.h, dnachar.h are ours; src/common only supplies the header-only TCLAP
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-w", "-c", str(tmp_path / f), "-I", host, "-I", os.path.join(REF_SRC, "common"), "-o", obj])
+        objs.append(obj)
+    exe = str(tmp_path / "twopaco_dropin")
+    subprocess.check_call(["g++", "-o", exe] + objs + ["-L", lib, "-ltwopaco_host", "-ltwopaco_hip", "-lpthread", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert "--filtersize" in r.stdout and "--kvalue" in r.stdout  # the reference's own TCLAP usage text
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "-k", "11", "-f", "20", os.path.join(GOLDEN, "example.fa"), "-o", str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 1 and "GPU" in r.stderr  # the reference's main reports our runtime_error; no CPU path

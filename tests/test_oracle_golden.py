@@ -6,11 +6,11 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, case_files, golden_cases, sha256_file
+from helpers import BIG, GOLDEN, case_files, golden_cases, sha256_file
 from oracle import oracle as O
 
 CASES = golden_cases()
-FAST = [c for c in CASES if c["name"] != "m1_full"]
+FAST = [c for c in CASES if c["name"] not in BIG]
 
 
 @pytest.mark.parametrize("case", FAST, ids=[c["name"] for c in FAST])

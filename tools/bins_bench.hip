@@ -1,0 +1,151 @@
+// bins_bench.hip -- the LDS write-combining bins on their own: synthetic entries (random bins), no hashing.
+// Compares tpc_bins.h:Bins (barrier flush per round) with tpc_rbins.h:RBins (barrier-free rings) at the
+// entry counts of the M2 workload and verifies that every entry reaches its region exactly once.
+//   hipcc --offload-arch=gfx950 -O3 -Itwopaco_amd/csrc -Iinclude tools/bins_bench.hip -o tools/bins_bench
+#include "tpc_rbins.h"
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__device__ __forceinline__ uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s; }
+
+template <class T> __device__ __forceinline__ T make_val(uint32_t r, uint32_t id);
+template <> __device__ __forceinline__ uint32_t make_val<uint32_t>(uint32_t r, uint32_t) { return r & 0x0FFFFFFFu; }
+template <> __device__ __forceinline__ uint64_t make_val<uint64_t>(uint32_t r, uint32_t id) { return ((uint64_t)id << 31) | (r & 0x0FFFFFFFu); }
+
+// V2 = false: Bins with a flush every `ppr` steps; true: RBins.  N entries per thread per step.
+template <class T, int N, bool V2, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr, int filler, T *buf, uint32_t *cnt, uint64_t cap,
+                                                   unsigned long long *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    const uint32_t wg = blockIdx.x;
+    auto reg = [buf, cap, wg, NB](uint32_t b) { return PtRegion<T>{buf + ((uint64_t)wg * NB + b) * cap, cap}; };
+    unsigned long long *lostc = sums + 2;
+    auto lost = [lostc](uint32_t, T) { atomicAdd(lostc, 1ull); };
+    uint32_t rng = (blockIdx.x * THREADS + threadIdx.x) * 2654435761u + 12345u;
+    unsigned long long sum = 0;
+    uint32_t acc = 0;
+    if constexpr (V2) {
+        RBins<T, THREADS> bins;
+        bins.carve(smem, LOG_NB);
+        bins.init();
+        __syncthreads();
+        for (int s = 0; s < steps; s++) {
+            uint32_t b[N];
+            T val[N];
+            bool ok[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                uint32_t r = lcg(rng);
+                for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);  // stands in for the hashing
+                b[i] = (r >> 8) & (uint32_t)(NB - 1);
+                val[i] = make_val<T>(r, (uint32_t)s);
+                ok[i] = true;
+                sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
+            }
+            bins.template push_batch<N>(b, val, ok, reg, lost);
+        }
+        bins.flush(true, reg, lost);
+        bins.store_counts(cnt + (uint64_t)wg * NB, reg, [](uint32_t b) { return b; });
+    } else {
+        Bins<T, THREADS> bins;
+        bins.carve(smem, LOG_NB);
+        bins.init();
+        __syncthreads();
+        for (int s0 = 0; s0 < steps; s0 += ppr) {
+            for (int s = s0; s < min(steps, s0 + ppr); s++) {
+                uint32_t b[N];
+                T val[N];
+                bool ok[N];
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    uint32_t r = lcg(rng);
+                    for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);
+                    b[i] = (r >> 8) & (uint32_t)(NB - 1);
+                    val[i] = make_val<T>(r, (uint32_t)s);
+                    ok[i] = true;
+                    sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
+                }
+                bins.template push_batch<N>(b, val, ok, lost);
+            }
+            bins.flush(false, reg, lost);
+        }
+        bins.flush(true, reg, lost);
+        bins.store_counts(cnt + (uint64_t)wg * NB, reg, [](uint32_t b) { return b; });
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
+    if (acc == 0x12345) sums[3] = 1;
+}
+
+template <class T>
+__global__ void k_check(const T *buf, const uint32_t *cnt, uint64_t cap, int NB, unsigned long long *sums)
+{   // one workgroup per region
+    const uint64_t r = blockIdx.x;
+    const uint32_t b = (uint32_t)(r % NB);
+    const uint32_t n = cnt[r];
+    unsigned long long sum = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const T v = buf[r * cap + i];
+        if (v != (T)~(T)0) { sum += (unsigned long long)v ^ ((unsigned long long)b << 40); c++; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); c += __shfl_down(c, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[1], sum); atomicAdd(&sums[4], c); }
+}
+
+template <class T, int N, bool V2>
+int run(const char *name, int log_nb, int steps, int ppr, int filler)
+{
+    constexpr int THREADS = 1024;
+    const int nwg = 256, NB = 1 << log_nb;
+    const uint64_t per_bin = (uint64_t)steps * THREADS * N / NB;
+    const uint64_t cap = ((uint64_t)(per_bin * 1.2) + 256 + 31) & ~31ull;
+    T *buf;
+    uint32_t *cnt;
+    unsigned long long *sums;
+    CK(hipMalloc(&buf, (size_t)nwg * NB * cap * sizeof(T)));
+    CK(hipMalloc(&cnt, (size_t)nwg * NB * 4));
+    CK(hipMalloc(&sums, 64));
+    const size_t lds = V2 ? RBins<T, THREADS>::lds_bytes(log_nb) : Bins<T, THREADS>::lds_bytes(log_nb);
+    CK(hipFuncSetAttribute((const void *)k_bins<T, N, V2, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemset(sums, 0, 64));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_bins<T, N, V2, THREADS>), dim3(nwg), dim3(THREADS), lds, 0, log_nb, steps, ppr, filler, buf, cnt, cap, sums);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    hipLaunchKernelGGL((k_check<T>), dim3(nwg * NB), dim3(256), 0, 0, buf, cnt, cap, NB, sums);
+    unsigned long long h[8];
+    CK(hipMemcpy(h, sums, 64, hipMemcpyDeviceToHost));
+    const double n = (double)nwg * THREADS * steps * N;
+    printf("%-28s NB %3d N %d filler %2d: %8.3f ms %8.1f G entries/s %6.2f TB/s written   %s (entries %.0f, found %llu, lost %llu)\n", name, NB, N, filler, ms,
+           n / ms / 1e6, n * sizeof(T) / ms / 1e9, (h[0] == h[1] && h[4] + h[2] == (unsigned long long)n && h[2] == 0) ? "OK" : "MISMATCH", n, h[4], h[2]);
+    CK(hipFree(buf)); CK(hipFree(cnt)); CK(hipFree(sums));
+    return 0;
+}
+
+int main()
+{
+    // M2: query 1.86 G uint64 entries (6 per position), insert 1.55 G uint32 entries (5 per position)
+    for (int filler : {0, 40}) {
+        run<uint64_t, 6, false>("Bins  u64 (flush/round)", 8, 1184, 1, filler);
+        run<uint64_t, 6, true>("RBins u64 (barrier-free)", 8, 1184, 1, filler);
+        run<uint32_t, 5, false>("Bins  u32 (flush/3 steps)", 8, 1184, 3, filler);
+        run<uint32_t, 5, true>("RBins u32 (barrier-free)", 8, 1184, 3, filler);
+    }
+    run<uint64_t, 4, false>("Bins  u64 split-like", 8, 1776, 1, 0);
+    run<uint64_t, 4, true>("RBins u64 split-like", 8, 1776, 1, 0);
+    run<uint64_t, 6, false>("Bins  u64 512 bins", 9, 1184, 1, 0);
+    run<uint64_t, 6, true>("RBins u64 512 bins", 9, 1184, 1, 0);
+    run<uint32_t, 5, true>("RBins u32 512 bins", 9, 1184, 1, 0);
+    run<uint32_t, 5, true>("RBins u32 64 bins", 6, 1184, 1, 0);
+    return 0;
+}

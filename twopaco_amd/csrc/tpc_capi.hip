@@ -206,6 +206,7 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
 {
     const uint64_t tiles = text_tiles512(c);
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
+    if (c->P.q > 8) return false;  // the partitioned kernels are instantiated for q <= 8
     const int64_t budget = part_budget(c);
     for (uint64_t batches = 1;; batches *= 2) {
         const uint64_t per = (tiles + batches - 1) / batches;
@@ -364,7 +365,9 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     if (!((nmask[0] & 1u) && ((nmask[(n_text - 1) >> 5] >> ((n_text - 1) & 31)) & 1u)))
         return fail(c, -1, "text must start and end with the N separator");
     const uint64_t tiles = (nw + TPC_TILE_THREADS - 1) / TPC_TILE_THREADS;
-    const uint64_t alloc = ((nw + 511) / 512) * 512 + TPC_XW_MAX + 2;  // covers the 256- and 512-word tilings
+    // whole 512-word tiles of text_tiles512() (one more than nw needs when n_text is a multiple of 16384: the kernels of the
+    // partitioned passes stage words [tile * 512 - 1, tile * 512 + 512 + xw) and k_q_hash stores a tile's rmask unguarded)
+    const uint64_t alloc = ((n_text / TPC_RUN + 512) / 512) * 512 + TPC_XW_MAX + 2;
     for (void *p : { (void *)c->bases, (void *)c->nmask, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
         if (p) (void)hipFree(p);
     c->bases = nullptr; c->nmask = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
@@ -419,6 +422,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     const uint64_t tiles = text_tiles512(c);
     uint64_t batches = 1;
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
+    if (c->P.q > 8) part = false;  // the partitioned kernels are instantiated for q <= 8
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);

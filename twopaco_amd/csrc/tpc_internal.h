@@ -3,8 +3,8 @@
 #include "tpc_device.h"
 #include <vector>
 
-#define TPC_TAB_MAXQ 8
-#define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[8][5] then hk[8][5]
+#define TPC_TAB_MAXQ 16
+#define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[16][5] then hk[16][5]
 #define TPC_TAB_WORDS (2 * TPC_TAB_MAXQ * 5)
 
 struct TpcLaunch {
@@ -21,7 +21,7 @@ struct TpcLaunch {
 // pass 1 (tpc_pass1.hip)
 int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);
 int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks);
-int tpc_launch_split(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, uint64_t bin_size);
+int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size);  // emask is consumed (occurrences still to be counted)
 int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *out);
 
 // partitioned insert (tpc_partition.hip)

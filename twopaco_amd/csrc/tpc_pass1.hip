@@ -226,15 +226,24 @@ k_query(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
 
 // ------------------------------------------------------------------------------------------
 // Split pass histogram (rounds > 1).  Every (k+1)-mer of 'N'+record+'N' (no N gate) is inserted
-// into the scratch filter; an edge occurrence that flips at least one bit bumps the bins of its
-// two endpoint vertex hashes (VE.h:538-571).  The reference's "first seen" is evaluated in
-// arrival order of its worker threads; here arrival order is the hardware's (atomicOr returns the
-// old word), which differs from the -t 1 order only for edges whose q bits are all covered by
-// other edges -- the bins feed only the round boundaries, never the output.
+// into the scratch filter; the FIRST-SEEN occurrence of an edge bumps the bins of its two endpoint
+// vertex hashes (VE.h:538-571: "wasSet" is false when some bit of the edge was still unset).
+// The reference evaluates "first seen" in the arrival order of its worker threads (text order at -t 1).
+// Here an edge is counted once, by ballot over its own bits, whatever the arrival order:
+//   phase i (one launch each, i = 0 .. phases-1): every occurrence that has not won yet does one
+//   atomicOr on bit a_i of its edge; the occurrence that flips it wins: it is counted, sets the edge's
+//   other q-1 bits and leaves the game.  All occurrences of one edge share their q addresses, so exactly
+//   one of them can flip a_i; an edge whose a_0 was taken by a DIFFERENT edge gets its chance on a_1 in
+//   the next launch (by then every winner's bits are visible), and so on.
+// An edge therefore counts once unless its first `phases` bits are all covered by other edges -- the
+// sequential rule is "unless all q bits are covered by earlier edges".  With a scratch filter large
+// enough that no such coverage happens both give the number of distinct edges, bin for bin
+// (tests/test_gpu_parity.py::test_split_histogram_exact_when_collision_free); on a crowded filter the
+// two differ by (fill/q)^phases of the edges, far inside the reference's own -t dependence.
 template <int Q>
 __global__ void __launch_bounds__(TPC_TILE_THREADS)
 k_split(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-        const uint32_t *__restrict__ nmask, const uint32_t *__restrict__ emask, uint64_t n_text,
+        const uint32_t *__restrict__ nmask, const uint32_t *__restrict__ todo_in, uint32_t *__restrict__ todo_out, int phase, uint64_t n_text,
         uint32_t *__restrict__ filter, uint32_t *__restrict__ bins, uint64_t bin_size)
 {
     __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
@@ -248,8 +257,8 @@ k_split(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
     __syncthreads();
     const uint64_t g0 = (wfirst + tid) * TPC_RUN;
     if (g0 >= n_text) return;
-    const uint32_t em = emask[wfirst + tid];  // bit s: a dispatched record's (k+1)-mer starts at g0+s
-    if (em == 0) return;
+    uint32_t em = todo_in[wfirst + tid];  // bit s: an edge occurrence that has not won yet starts at g0+s
+    if (em == 0) { if (todo_out != todo_in) todo_out[wfirst + tid] = 0; return; }
     TpcVHash<Q> v;
     tpc_vhash_init<Q>(v, P, s_h, s_b, s_n, g0, wbase);
     int c_first = tpc_tile_char(s_b, s_n, g0, wbase);
@@ -267,26 +276,31 @@ k_split(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
         }
         if ((em >> s) & 1u) {
             const bool neg = tpc_pick_neg<Q>(ep, en);
-            bool was_set = true;
+            uint64_t a[Q];
 #pragma unroll
-            for (int i = 0; i < Q; i++) {
-                const uint64_t a = neg ? en[i] : ep[i];
-                const uint32_t bit = 1u << ((uint32_t)a & 31u);
-                const uint32_t old = atomicOr(&filter[a >> 5], bit);
-                if (!(old & bit)) was_set = false;
-            }
-            if (!was_set) {
+            for (int i = 0; i < Q; i++) a[i] = neg ? en[i] : ep[i];
+            uint64_t mine = a[0];
+#pragma unroll
+            for (int i = 1; i < Q; i++) if (i == phase) mine = a[i];
+            const uint32_t bit = 1u << ((uint32_t)mine & 31u);
+            const uint32_t old = atomicOr(&filter[mine >> 5], bit);
+            if (!(old & bit)) {  // this occurrence is the edge's first-seen one
+#pragma unroll
+                for (int i = 0; i < Q; i++)
+                    if (i != phase) atomicOr(&filter[a[i] >> 5], 1u << ((uint32_t)a[i] & 31u));
                 const uint64_t b0 = tpc_min(v.pos[0], v.neg[0]) / bin_size;
                 const uint64_t b1 = tpc_min(npos[0], nneg[0]) / bin_size;
                 // MAX_COUNTER saturation (common.cpp:6): counts beyond 2^31-1 are not reachable per bin here
                 if (bins[b0] < 0x7FFFFFFFu) atomicAdd(&bins[b0], 1u);
                 if (bins[b1] < 0x7FFFFFFFu) atomicAdd(&bins[b1], 1u);
+                em &= ~(1u << s);
             }
         }
 #pragma unroll
         for (int i = 0; i < Q; i++) { v.pos[i] = npos[i]; v.neg[i] = nneg[i]; }
         c_first = c_first_nx;
     }
+    todo_out[wfirst + tid] = em;
 }
 
 // Vertex hashes of a range of windows (parity tap).
@@ -326,10 +340,12 @@ void launch_query_q(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t h
 }
 
 template <int Q>
-void launch_split_q(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, uint64_t bin_size)
+void launch_split_q(const TpcLaunch &a, uint32_t *todo, uint32_t *bins, uint64_t bin_size)
 {
     dim3 grid((unsigned)a.n_tiles), block(TPC_TILE_THREADS);
-    hipLaunchKernelGGL((k_split<Q>), grid, block, 0, a.stream, a.P, a.tab, a.bases, a.nmask, emask, a.n_text, a.filter, bins, bin_size);
+    const int phases = Q < 3 ? Q : 3;  // see k_split
+    for (int phase = 0; phase < phases; phase++)
+        hipLaunchKernelGGL((k_split<Q>), grid, block, 0, a.stream, a.P, a.tab, a.bases, a.nmask, todo, todo, phase, a.n_text, a.filter, bins, bin_size);
 }
 
 }  // namespace
@@ -344,6 +360,14 @@ void launch_split_q(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, u
     case 6: CALL(6); break;                    \
     case 7: CALL(7); break;                    \
     case 8: CALL(8); break;                    \
+    case 9: CALL(9); break;                    \
+    case 10: CALL(10); break;                  \
+    case 11: CALL(11); break;                  \
+    case 12: CALL(12); break;                  \
+    case 13: CALL(13); break;                  \
+    case 14: CALL(14); break;                  \
+    case 15: CALL(15); break;                  \
+    case 16: CALL(16); break;                  \
     default: return -1;                        \
     }
 
@@ -363,7 +387,7 @@ int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t 
     return 0;
 }
 
-int tpc_launch_split(const TpcLaunch &a, const uint32_t *emask, uint32_t *bins, uint64_t bin_size)
+int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size)
 {
 #define CALL(Q) launch_split_q<Q>(a, emask, bins, bin_size)
     TPC_DISPATCH_Q(a.P.q, CALL)

@@ -396,45 +396,67 @@ def merge_records(parts, rec_start, rec_length, k, n_junctions):
 
 
 def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload."""
+    """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload.
+
+    TPC_BENCH_BACKEND=module:function (TEST ONLY, tests/test_dist_cpu.py): the rank backend comes from
+    function(args, rank, world) -> (backend, n_kmers, params, description) instead of the HIP library, so that the
+    launch / rendezvous / timing / reporting path of `bench.py --gpus N` can run under gloo on a machine without
+    GPUs.  Such a line says "backend": "injected" and is not a measurement."""
+    import importlib
+
     import torch
     import torch.distributed as dist
 
     from . import capi, synth
 
     backend = os.environ.get("TPC_DIST_BACKEND", "nccl")  # "gloo": several ranks on one GPU (testing only)
-    ngpu = torch.cuda.device_count()
-    device = local_rank % max(ngpu, 1)
-    torch.cuda.set_device(device)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-    else:
-        dist.init_process_group(backend)
-    recs, p = synth.workload(args.workload, scale=args.scale)
-    n_kmers = synth.n_kmers(recs, p["k"])
-    text = capi.PackedText.from_codes(recs)
-    ctx = capi.Context(device)
-    ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=12345))
-    ctx.seq_upload(text)
+    injected = os.environ.get("TPC_BENCH_BACKEND")
     address = getattr(args, "decomposition", "ranges") == "address"
-    if address:
-        sh = AddressSharded(ctx, dist, torch.device("cuda", device))
-        step = lambda: address_sharded_step(sh)
-    else:
-        be = HipBackend(ctx)
+    ctx = None
+    if injected:
+        mod, fn = injected.split(":")
+        be, n_kmers, p, workload_desc = getattr(importlib.import_module(mod), fn)(args, rank, world)
+        dist.init_process_group(backend)
+        if address:
+            raise RuntimeError("the injected test backend only drives the ranges decomposition")
         step = lambda: sharded_step(be, dist, p["L"])
+    else:
+        ngpu = torch.cuda.device_count()
+        device = local_rank % max(ngpu, 1)
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+        recs, p = synth.workload(args.workload, scale=args.scale)
+        n_kmers = synth.n_kmers(recs, p["k"])
+        workload_desc = "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d" % (
+            args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"])
+        text = capi.PackedText.from_codes(recs)
+        ctx = capi.Context(device)
+        ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=20240229))
+        ctx.seq_upload(text)
+        if address:
+            sh = AddressSharded(ctx, dist, torch.device("cuda", device))
+            step = lambda: address_sharded_step(sh)
+        else:
+            be = HipBackend(ctx)
+            step = lambda: sharded_step(be, dist, p["L"])
     for _ in range(args.warmup):
         step()
     names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit"] + (["shard_hash", "shard_apply"] if address else [])
     kms = {n: 0.0 for n in names}
     dist.barrier()
-    torch.cuda.synchronize()
+    if ctx is not None:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = step()
         for n in names:
-            kms[n] += max(ctx.kernel_ms(n), 0.0) / args.steps
-    torch.cuda.synchronize()
+            if ctx is not None:
+                kms[n] += max(ctx.kernel_ms(n), 0.0) / args.steps
+    if ctx is not None:
+        torch.cuda.synchronize()
     dist.barrier()
     dev = _dev(dist)
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -444,28 +466,30 @@ def bench_main(args, rank, world, local_rank):
         dist.all_reduce(tot)
     dt = float(dt.item())
     if rank == 0:
+        qms = max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9)
+        # bytes rank 0's first-pass query moves by construction (bench.py: 6 uint64 entries per k-mer x 4 transfers, the
+        # packed text, one pass over the filter): ranges -> whole text hashed, 1/world of the entries, whole filter;
+        # address -> 1/world of the text, of the entries and of the filter
+        fb = (1 << p["L"]) // 8
+        design = (0.375 * n_kmers / world + 6 * n_kmers / world * 32 + fb / world) if address else (0.375 * n_kmers + 6 * n_kmers / world * 32 + fb)
         out = {
             "metric": "kmers_hashed_per_sec", "value": n_kmers * args.steps / dt, "unit": "k-mers/s", "n_gpus": world,
+            "ranks": dist.get_world_size(), "backend": "injected" if injected else ("rccl" if backend == "nccl" else backend),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d"
-                                   % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
-                       "kmers": n_kmers, "filter_bytes": (1 << p["L"]) // 8,
+            "config": {"workload": workload_desc,
+                       "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
                        "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of level-1 regions per pass, per-function survivor probes, all_gather of the mask" % world)
                        if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
             "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
             "kernel_ms_rank0": kms,
-            # dominant kernel group on rank 0, priced like the single-GPU line (0.375 + 6 x 64 B per queried k-mer);
-            # a rank queries the vertices of its range / its tiles = 1/world of the k-mers
-            "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0 (its 1/%d of the k-mers)" % world,
-                         "achieved": (n_kmers / world) * 384.375 / (max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9) * 1e-3) / 1e9,
-                         "peak": 8000.0, "unit": "GB/s",
-                         "frac": (n_kmers / world) * 384.375 / (max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9) * 1e-3) / 1e9 / 8000.0,
-                         "traffic": None},
+            "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0", "achieved": design / (qms * 1e-3) / 1e9,
+                         "peak": 8000.0, "unit": "GB/s", "frac": design / (qms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": design, "launch_ms": qms} if ctx is not None else None,
             "exchange_bytes_rank0_per_step": (sh.comm.bytes_moved // (args.steps + args.warmup)) if address else None,
             "phase_ms_rank0_per_step": {k: v * 1e3 / (args.steps + args.warmup) for k, v in sh.t.items()} if address else None,
             "survivors_rank0": sh.stats.get("survivors") if address else None,
             "result": {"candidate_marks": int(tot[1].item()), "junctions": st["junctions"], "junction_occurrences": int(tot[0].item())},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.destroy_process_group()

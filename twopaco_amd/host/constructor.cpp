@@ -54,7 +54,8 @@ namespace
 	{
 		std::cout << "USAGE: twopaco {-f <integer>|--filtermemory <float>} [-k <oddc>] [-q <integer>] [-r <integer>]" << std::endl
 			<< "               [-t <integer>] [-a <integer>] [--tmpdir <directory name>] [-o <file name>] [--test]" << std::endl
-			<< "               [--seed <integer>] [--device <integer>] [--test-first] <fasta files with genomes> ..." << std::endl;
+			<< "               [--seed <integer>] [--device <integer>] [--test-first] <fasta files with genomes> ..." << std::endl
+			<< "       -q: 1..16 hash functions (the reference takes any number; 9..16 run on the direct kernels)" << std::endl;
 	}
 }
 

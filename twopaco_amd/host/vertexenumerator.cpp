@@ -52,7 +52,7 @@ namespace TwoPaCo
 			size_t GetVerticesCount() const { return vertices_; }
 			int64_t GetId(const std::string & vertex) const
 			{
-				if (vertex.size() < seed_.VertexLength()) return INVALID_VERTEX;
+				if (vertex.size() < seed_.VertexLength() || vertices_ == 0) return INVALID_VERTEX;
 				return tpc_get_id(ctx_, vertex.c_str());
 			}
 
@@ -164,15 +164,6 @@ namespace TwoPaCo
 					throw std::runtime_error(setupError);
 				}
 
-				{
-					const int rcUpload = tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length);
-					if (warm.joinable()) warm.join();
-					Check(rcUpload, "seq_upload");
-				}
-				timer.Lap("context + upload");
-
-				Check(tpc_run_begin(ctx_), "run_begin");
-
 				// records the reference dispatches: at least k bases (vertexenumerator.h:1177)
 				std::vector<uint64_t> dispStart, dispLength;
 				for (size_t r = 0; r < text.recStart.size(); r++)
@@ -184,15 +175,27 @@ namespace TwoPaCo
 					}
 				}
 
+				// Nothing to enumerate (only headers, or every record shorter than k): the reference runs its passes over an
+				// empty task stream, prints zero counters and leaves an empty output file.  Same here, without device work.
+				const bool nothing = dispStart.empty();
+				{
+					const int rcUpload = nothing ? 0 : tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length);
+					if (warm.joinable()) warm.join();
+					Check(rcUpload, "seq_upload");
+				}
+				timer.Lap("context + upload");
+
+				if (!nothing) Check(tpc_run_begin(ctx_), "run_begin");
+
 				const uint64_t BIN_SIZE = std::max(uint64_t(1), realSize / BINS_COUNT);
 				std::vector<uint32_t> binCounter;
 				double roundSize = 0;
 				if (rounds > 1)
 				{
 					logStream << "Splitting the input kmers set..." << std::endl;
-					binCounter.resize(BINS_COUNT);
-					Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
-					roundSize = double(std::accumulate(binCounter.begin(), binCounter.end(), size_t(0))) / rounds;
+					binCounter.resize(BINS_COUNT + 1);
+					if (!nothing) Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
+					roundSize = double(std::accumulate(binCounter.begin(), binCounter.begin() + BINS_COUNT, size_t(0))) / rounds;
 				}
 
 				logStream << std::string(80, '-') << std::endl;
@@ -207,7 +210,7 @@ namespace TwoPaCo
 					if (rounds > 1)
 					{
 						// reference vertexenumerator.h:234-250
-						uint64_t accumulated = binCounter[lowBoundary];
+						uint64_t accumulated = binCounter[std::min<uint64_t>(lowBoundary, BINS_COUNT)];
 						for (++lowBoundary; lowBoundary < BINS_COUNT; ++lowBoundary)
 						{
 							if (accumulated <= roundSize || round + 1 == rounds)
@@ -230,21 +233,21 @@ namespace TwoPaCo
 					logStream << "Round " << round << ", " << low << ":" << high << std::endl;
 					logStream << "Pass\tFilling\tFiltering" << std::endl << "1\t";
 					PhaseTimer sub;
-					Check(tpc_filter_reset(ctx_), "filter_reset");
+					if (!nothing) Check(tpc_filter_reset(ctx_), "filter_reset");
 					uint64_t kmers = 0;
-					Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+					if (!nothing) Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
 					sub.Lap("  round: insert");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
 					uint64_t marks = 0;
-					Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
+					if (!nothing) Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
 					sub.Lap("  round: query");
 					logStream << time(0) - mark << "\t" << std::endl;
 
 					mark = time(0);
 					logStream << "2\t";
 					uint64_t truePositives = 0, falsePositives = 0, hashTableSize = 0;
-					Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
+					if (!nothing) Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
 					sub.Lap("  round: exact filter");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
@@ -261,13 +264,13 @@ namespace TwoPaCo
 				timer.Lap("rounds (insert, query, exact filter)");
 				mark = time(0);
 				uint64_t junctions = 0;
-				Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
+				if (!nothing) Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
 				vertices_ = junctions;
 				logStream << "Reallocating bifurcations time: " << time(0) - mark << std::endl;
 
 				mark = time(0);
 				uint64_t marked = 0, valid = 0;
-				Check(tpc_emit(ctx_, &marked, &valid), "emit");
+				if (!nothing) Check(tpc_emit(ctx_, &marked, &valid), "emit");
 				// EdgeConstructionWorker + FlushEdgeResults + JunctionPositionWriter (reference vertexenumerator.h:837-854,
 				// 927-958, junctionapi.h:118-132): the device formats the whole junction stream -- records in
 				// (sequence, position) order, stub ids for sequence ends, one separator per sequence-id step
@@ -278,7 +281,7 @@ namespace TwoPaCo
 					throw std::runtime_error("Too many sequences");
 				}
 
-				Check(tpc_emit_stream(ctx_, text.recStart.data(), text.recLength.data(), uint32_t(text.recStart.size()), &streamBytes, &occurence), "emit_stream");
+				if (!nothing) Check(tpc_emit_stream(ctx_, text.recStart.data(), text.recLength.data(), uint32_t(text.recStart.size()), &streamBytes, &occurence), "emit_stream");
 				timer.Lap("sort + id lookup + junction stream");
 				{
 					const int fd = ::open(outFileName.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);

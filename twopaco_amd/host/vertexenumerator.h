@@ -7,14 +7,27 @@
 #ifndef _VERTEX_ENUMERATOR_H_
 #define _VERTEX_ENUMERATOR_H_
 
+// What the reference's own translation units rely on their vertexenumerator.h to pull in (constructor.cpp uses log2,
+// test.cpp uses CHAR_MAX, UINT32_MAX, DnaChar, std::thread-era headers): kept here so that both compile UNCHANGED
+// against this header (tests/test_host_cpu.py::test_reference_main_and_selftest_compile_against_host_headers).
+#include <climits>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <deque>
 #include <memory>
+#include <numeric>
 #include <ostream>
+#include <sstream>
 #include <string>
+#include <thread>
+#include <unordered_set>
 #include <vector>
 
+#include "dnachar.h"
 #include "junctionapi.h"
 #include "seed.h"
+#include "streamfastaparser.h"
 
 namespace TwoPaCo
 {
