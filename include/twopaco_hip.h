@@ -190,8 +190,17 @@ void tpc_host_free(void *ptr);
  *                             address of every survivor id in sid_dev (entry i*fn_count + j)
  *   tpc_shard_probe           answer probes against this rank's shard (hit_dev[i] = 0/1)
  *   tpc_shard_mark            set the candidate mark of every id in sid_dev (all q probes hit)
+ *   tpc_shard_route           owner-major send order for `n` probes: perm_dev[i] = slot of item i, counts_host[r] =
+ *                             items for rank r (the grouping a host language would do with a sort; world <= 64)
+ *   tpc_shard_permute64       dst[perm[i]] = src[i] (the addresses into send order)
+ *   tpc_shard_select          the ids of sid_dev whose fn_count answers are all 1; hit_dev holds the answers in SEND
+ *                             order (owners answer in the order they were asked), sid_out_dev / *n_out the kept ids
  *   tpc_mask_export / tpc_mask_merge   round mask to / OR of `count` masks from a device buffer:
- *                             the union over ranks is the mask tpc_pass1_query would produce */
+ *                             the union over ranks is the mask tpc_pass1_query would produce
+ *   tpc_mask_export_padded / tpc_mask_or_blocks / tpc_mask_import   the same union as an OR all-reduce by word
+ *                             ranges: export padded to world x chunk words, all_to_all of the chunks, fold the
+ *                             `count` received chunks, all_gather the folded chunks, import (2 (W-1)/W mask sizes
+ *                             per rank on the wire instead of W) */
 #define TPC_SHARD_INSERT 0
 #define TPC_SHARD_QUERY 1
 int tpc_shard_config(tpc_ctx *ctx, uint32_t rank, uint32_t world);
@@ -205,8 +214,15 @@ int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
 int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
 int tpc_shard_probe(tpc_ctx *ctx, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev);
 int tpc_shard_mark(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n);
+int tpc_shard_route(tpc_ctx *ctx, const int32_t *owner_dev, uint64_t n, uint32_t *perm_dev, uint64_t *counts_host);
+int tpc_shard_permute64(tpc_ctx *ctx, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, uint64_t *dst_dev);
+int tpc_shard_select(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n, int fn_count, const uint8_t *hit_dev, const uint32_t *perm_dev,
+                     uint64_t *sid_out_dev, uint64_t *n_out);
 int tpc_mask_export(tpc_ctx *ctx, uint32_t *dst_dev);
 int tpc_mask_merge(tpc_ctx *ctx, const uint32_t *src_dev, uint32_t count);
+int tpc_mask_export_padded(tpc_ctx *ctx, uint32_t *dst_dev, uint64_t total_words);
+int tpc_mask_or_blocks(tpc_ctx *ctx, const uint32_t *blocks_dev, uint32_t count, uint64_t words, uint32_t *out_dev);
+int tpc_mask_import(tpc_ctx *ctx, const uint32_t *src_dev);
 
 /* ---- parity taps (debug; used by tests/) ---------------------------------------------- */
 uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 (sharded: 2^L/32/world) */
@@ -234,7 +250,9 @@ int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
- * with the full-size table by the last tpc_pass2_filter.  -1: unknown name. */
+ * with the full-size table by the last tpc_pass2_filter; "round_marks" = candidate marks of the round the last
+ * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does).
+ * -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);
 
 #ifdef __cplusplus

@@ -187,9 +187,9 @@ def main():
 
     # synthetic workloads of BASELINE.json's configs (FASTA regenerated from twopaco_amd/synth.py)
     # m2_full = the bench workload (BASELINE configs[2]); m2_s05_f38 = the f = 38 geometry (512 bins per level) on a text the
-    # reference finishes in minutes; m2x8_f38 = configs[3]'s shape (multi-Gbp text, 32 GiB filter, several query batches)
+    # reference finishes in minutes; m3_f38 = configs[3]'s shape (7 genomes, 1.12 Gbp of text, 32 GiB filter, several query batches)
     for name, wl, scale, L, thr in [("m1_small", "m1", 0.02, 26, 1), ("m1_full", "m1", 1.0, None, 1), ("m2_small", "m2", 0.004, 26, 1),
-                                    ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m2x8_f38", "m2", 8.0, 38, 4)]:
+                                    ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m3_f38", "m3", 1.0, None, 4)]:
         if only is not None and name not in only:
             continue
 

@@ -1,0 +1,85 @@
+"""GPU (-m gpu): the C++ multi-GPU host (twopaco_amd/host/multigpu.cpp) -- Bloom filter sharded by bit address, one rank
+(thread + device context) per GPU.  One device is all a test box has, so the ranks are emulated on it over the loopback
+transport (RCCL refuses duplicate devices); the RCCL transport itself is exercised with its single possible rank.  Every
+run must write the reference's bytes."""
+import os
+import subprocess
+
+import pytest
+
+from helpers import GOLDEN, case_files, golden_cases, parse_log, sha256_file
+
+pytestmark = pytest.mark.gpu
+CASES = {c["name"]: c for c in golden_cases()}
+MAXU = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from twopaco_amd import capi as m
+    m.hip()
+    m.host()
+    return m
+
+
+def _check(case, e, out):
+    assert os.path.getsize(out) == case["bin_bytes"]
+    assert sha256_file(out) == case["bin_sha256"]
+    assert e.vertices_count() == case["distinct"]
+    log = parse_log(e.log)
+    assert log["true_marks"] == case["true_marks"]
+    return log
+
+
+@pytest.mark.parametrize("name,ranks", [("rand6_k9_fp", 2), ("rand6_k9_L33", 4), ("c2_k51_r2", 2), ("edge_k5", 2), ("rand6_k25_q3", 8),
+                                        ("rand6_k9_a3", 4), ("c2_k125", 2), ("m1_small", 4), ("m2_small", 8)])
+def test_emulated_ranks_write_reference_bytes(capi, tmp_path, name, ranks):
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    log = _check(case, e, out)
+    assert "GPUs = %d" % ranks in e.log and "loopback" in e.log
+    if case["n_rounds"] == 1:
+        assert log["rounds"] == case["rounds"]  # marks, true / false junctions, table size of the one round
+    else:
+        assert sum(r["true"] for r in log["rounds"]) == case["distinct"]
+    e.close()
+
+
+def test_rccl_transport_single_rank(capi, tmp_path):
+    """The sharded path over the RCCL transport with the one rank a single-GPU box allows: librccl is loaded, the
+    communicator created, and every collective of the pass (send/recv groups to self, all-gather) runs through it."""
+    case = CASES["rand6_k25_q3"]  # (not a saturated filter: a sharded filter has no direct-kernel fallback when every probe survives)
+    out = str(tmp_path / "rccl.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], tmpdir=str(tmp_path), out=out, seed=case["seed"],
+                        gpus=1, force_sharded=True, rccl=True)
+    log = _check(case, e, out)
+    assert "RCCL" in e.log and log["rounds"] == case["rounds"]
+    e.close()
+
+
+def test_m1_full_four_emulated_ranks(capi, tmp_path):
+    """BASELINE configs[1] at full size with the filter cut over four ranks: sha256 == the real reference's."""
+    case = CASES["m1_full"]
+    out = str(tmp_path / "m1mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], tmpdir=str(tmp_path), out=out, seed=case["seed"],
+                        threads=8, gpus=4, emulate_ranks=True)
+    log = _check(case, e, out)
+    assert log["rounds"] == case["rounds"]
+    e.close()
+
+
+def test_cli_gpus_flag(tmp_path):
+    case = CASES["rand6_k9_fp_r4"]
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    out = str(tmp_path / "cli.bin")
+    r = subprocess.run([exe, "-k", str(case["k"]), "-f", str(case["L"]), "-q", str(case["q"]), "-r", "2", "-t", "2", "--gpus", "2", "--emulate-ranks",
+                        "--seed", str(case["seed"]), "--tmpdir", str(tmp_path), "-o", out, os.path.join(GOLDEN, case["fasta"])],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()
+    assert "GPUs = 2" in r.stdout and "Distinct junctions = %d" % case["distinct"] in r.stdout
+    bad = subprocess.run([exe, "-k", "9", "-f", "14", "--gpus", "3", os.path.join(GOLDEN, case["fasta"])], capture_output=True, text=True)
+    assert bad.returncode == 1 and "power of two" in bad.stderr

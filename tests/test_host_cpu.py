@@ -192,3 +192,17 @@ def test_reference_main_and_selftest_compile_against_host_headers(built, tmp_pat
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "-k", "11", "-f", "20", os.path.join(GOLDEN, "example.fa"), "-o", str(tmp_path / "o.bin")], capture_output=True, text=True)
         assert r.returncode == 1 and "GPU" in r.stderr  # the reference's main reports our runtime_error; no CPU path
+
+
+def test_native_synth_equals_numpy(built, monkeypatch):
+    """host/synthgen.cpp generates the workloads of twopaco_amd/synth.py bit for bit (the goldens were made from the numpy code)."""
+    from twopaco_amd import synth
+    sizes = (("m1", 0.01), ("m2", 0.1), ("m3", 0.002))
+    fast = {w: synth.workload(w, scale=s)[0] for w, s in sizes}
+    monkeypatch.setenv("TPC_SYNTH_NUMPY", "1")
+    for (w, s) in sizes:
+        slow = synth.workload(w, scale=s)[0]
+        assert len(slow) == len(fast[w])
+        for a, b in zip(slow, fast[w]):
+            assert a.dtype == b.dtype == np.uint8 and (a == b).all()
+    assert sum(int((r == 4).sum()) for r in fast["m2"]) > 0

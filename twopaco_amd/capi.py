@@ -20,6 +20,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
+               "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup"]
 
@@ -87,6 +88,12 @@ def hip():
         L.tpc_shard_mark.argtypes = [p, p, u64]
         L.tpc_mask_export.argtypes = [p, p]
         L.tpc_mask_merge.argtypes = [p, p, u32]
+        L.tpc_shard_route.argtypes = [p, p, u64, p, p]
+        L.tpc_shard_permute64.argtypes = [p, p, p, u64, p]
+        L.tpc_shard_select.argtypes = [p, p, u64, ci, p, p, p, p]
+        L.tpc_mask_export_padded.argtypes = [p, p, u64]
+        L.tpc_mask_or_blocks.argtypes = [p, p, u32, u64, p]
+        L.tpc_mask_import.argtypes = [p, p]
         L.tpc_emit_stream.argtypes = [p, p, p, u32, p, p]
         L.tpc_emit_stream_fetch.argtypes = [p, u64, u64, p]
         L.tpc_host_alloc.argtypes = [ctypes.POINTER(p), u64]
@@ -117,12 +124,18 @@ def host():
         L.tpch_create_enumerator.restype = p
         L.tpch_create_enumerator.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, u64, u64, u64, u64, u64, u64, ctypes.c_char_p,
                                              ctypes.c_char_p, ci, u64, ci, ci, ctypes.POINTER(p)]
+        L.tpch_create_enumerator_mgpu.restype = p
+        L.tpch_create_enumerator_mgpu.argtypes = [ctypes.POINTER(ctypes.c_char_p), ci, u64, u64, u64, u64, u64, u64, ctypes.c_char_p,
+                                                  ctypes.c_char_p, ci, u64, ci, ci, ci, ci, ci, ctypes.POINTER(p)]
         L.tpch_enumerator_free.argtypes = [p]
         L.tpch_vertices_count.restype = u64
         L.tpch_vertices_count.argtypes = [p]
         L.tpch_get_id.restype = i64
         L.tpch_get_id.argtypes = [p, ctypes.c_char_p]
         L.tpch_hash_seed.argtypes = [p, p]
+        L.tpch_synth_genome.argtypes = [u64, u64, p]
+        L.tpch_synth_substitute.argtypes = [p, u64, u64, u64, p]
+        L.tpch_synth_n_runs.argtypes = [p, u64, u64, u64, u64]
         _host = L
     return _host
 
@@ -398,17 +411,44 @@ class Context:
     def mask_words(self):
         return int(hip().tpc_mask_words(self._h))
 
+    def shard_route(self, owner_ptr, n, perm_ptr, world):
+        counts = np.zeros(64, dtype=np.uint64)
+        self._ck(hip().tpc_shard_route(self._h, owner_ptr, n, perm_ptr, counts.ctypes.data))
+        return [int(x) for x in counts[:world]]
+
+    def shard_permute64(self, src_ptr, perm_ptr, n, dst_ptr):
+        self._ck(hip().tpc_shard_permute64(self._h, src_ptr, perm_ptr, n, dst_ptr))
+
+    def shard_select(self, sid_ptr, n, fn_count, hit_ptr, perm_ptr, out_ptr):
+        m = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_select(self._h, sid_ptr, n, fn_count, hit_ptr, perm_ptr, out_ptr, ctypes.byref(m)))
+        return m.value
+
+    def mask_export_padded(self, dst_ptr, total_words):
+        self._ck(hip().tpc_mask_export_padded(self._h, dst_ptr, total_words))
+
+    def mask_or_blocks(self, blocks_ptr, count, words, out_ptr):
+        self._ck(hip().tpc_mask_or_blocks(self._h, blocks_ptr, count, words, out_ptr))
+
+    def mask_import(self, src_ptr):
+        self._ck(hip().tpc_mask_import(self._h, src_ptr))
+
 
 class Enumerator:
     """TwoPaCo::CreateEnumerator through the C++ host layer (host/vertexenumerator.h)."""
 
     def __init__(self, files, k, filter_bits, q=5, rounds=1, threads=1, abundance=(1 << 64) - 1, tmpdir=".",
-                 out="de_bruijn.bin", seed=None, device=0, test_first=False):
+                 out="de_bruijn.bin", seed=None, device=0, test_first=False, gpus=1, rccl=True, emulate_ranks=False, force_sharded=False):
         arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
         log = ctypes.c_void_p()
-        self._h = host().tpch_create_enumerator(arr, len(files), k, filter_bits, q, rounds, threads, abundance, tmpdir.encode(),
-                                                out.encode(), 0 if seed is None else 1, 0 if seed is None else seed, device,
-                                                1 if test_first else 0, ctypes.byref(log))
+        if gpus > 1 or force_sharded:  # host/multigpu.h: the filter sharded by bit address over `gpus` ranks
+            self._h = host().tpch_create_enumerator_mgpu(arr, len(files), k, filter_bits, q, rounds, threads, abundance, tmpdir.encode(),
+                                                         out.encode(), 0 if seed is None else 1, 0 if seed is None else seed, device,
+                                                         gpus, 1 if rccl else 0, 1 if emulate_ranks else 0, 1 if force_sharded else 0, ctypes.byref(log))
+        else:
+            self._h = host().tpch_create_enumerator(arr, len(files), k, filter_bits, q, rounds, threads, abundance, tmpdir.encode(),
+                                                    out.encode(), 0 if seed is None else 1, 0 if seed is None else seed, device,
+                                                    1 if test_first else 0, ctypes.byref(log))
         self.log = ctypes.string_at(log.value).decode() if log.value else ""
         if log.value:
             host().tpch_free(log)

@@ -17,9 +17,10 @@ struct PtPerm {
     int slice_bits, F;
     uint32_t mult, inv;
     __host__ __device__ __forceinline__ uint64_t fwd(uint64_t a) const
-    {
-        const uint64_t smask = ((uint64_t)1 << slice_bits) - 1, fmask = ((uint64_t)1 << F) - 1;
-        return ((((a >> slice_bits) * mult) & fmask) << slice_bits) | (a & smask);
+    {   // F < 32 for every accepted geometry (three levels of at most 9 bits): one 32-bit multiply
+        const uint64_t smask = ((uint64_t)1 << slice_bits) - 1;
+        const uint32_t sp = ((uint32_t)(a >> slice_bits) * mult) & (uint32_t)(((uint64_t)1 << F) - 1);
+        return ((uint64_t)sp << slice_bits) | (a & smask);
     }
     __host__ __device__ __forceinline__ uint64_t back(uint64_t a) const
     {

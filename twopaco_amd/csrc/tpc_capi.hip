@@ -320,6 +320,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "insert_batches")) return c->stat_batches[0];
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
+    if (!strcmp(name, "round_marks")) return c->marks_valid ? (int64_t)c->n_marks : -1;  // set bits of the round mask (after tpc_pass2_filter)
     return -1;
 }
 
@@ -1188,6 +1189,84 @@ int tpc_mask_merge(tpc_ctx *c, const uint32_t *src_dev, uint32_t count)
     for (uint32_t i = 0; i < count; i++) tpc_launch_mask_or(c->stream, c->rmask, src_dev + (uint64_t)i * c->n_words, c->n_words);
     c->marks_valid = false;
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_route(tpc_ctx *c, const int32_t *owner_dev, uint64_t n, uint32_t *perm_dev, uint64_t *counts_host)
+{
+    if (!c || !counts_host || (n && (!owner_dev || !perm_dev))) return fail(c, -1, "bad arguments");
+    if (c->sh_world > 64) return fail(c, -1, "routing supports at most 64 ranks");
+    if (n > 0xFFFFFFFFull) return fail(c, -1, "too many items to route at once");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *d = nullptr;  // [0..63] counts, [64..127] cursors
+    HIPCHK(c, hipMalloc((void **)&d, 128 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(d, 0, 128 * sizeof(unsigned long long), c->stream));
+    tpc_launch_route(c->stream, owner_dev, n, d, d + 64, perm_dev, 0);
+    unsigned long long h[64], cur[64];
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long acc = 0;
+    for (int i = 0; i < 64; i++) { cur[i] = acc; acc += h[i]; if ((uint32_t)i < c->sh_world) counts_host[i] = h[i]; }
+    HIPCHK(c, hipMemcpyAsync(d + 64, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));
+    tpc_launch_route(c->stream, owner_dev, n, d, d + 64, perm_dev, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    return 0;
+}
+
+int tpc_shard_permute64(tpc_ctx *c, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, uint64_t *dst_dev)
+{
+    if (!c || (n && (!src_dev || !perm_dev || !dst_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    tpc_launch_permute64(c->stream, src_dev, perm_dev, n, dst_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_select(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n, int fn_count, const uint8_t *hit_dev, const uint32_t *perm_dev, uint64_t *sid_out_dev,
+                     uint64_t *n_out)
+{
+    if (!c || !n_out || fn_count < 1 || (n && (!sid_dev || !hit_dev || !perm_dev || !sid_out_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, sizeof(unsigned long long), c->stream));
+    tpc_launch_select(c->stream, sid_dev, n, fn_count, hit_dev, perm_dev, sid_out_dev, c->counters + 3);
+    HIPCHK(c, hipGetLastError());
+    return read_counter(c, 3, n_out);
+}
+
+// Candidate-mask union by word ranges (an OR all-reduce built from an all_to_all and an all_gather, because RCCL has no
+// bitwise reduction): every rank exports its mask padded to world x chunk words, the chunks are exchanged (rank r
+// receives chunk r of everyone), tpc_mask_or_blocks folds them, the folded chunks are all-gathered and imported.
+int tpc_mask_export_padded(tpc_ctx *c, uint32_t *dst_dev, uint64_t total_words)
+{
+    if (!c || !c->rmask || !dst_dev || total_words < c->n_words) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst_dev, c->rmask, c->n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (total_words > c->n_words) HIPCHK(c, hipMemsetAsync(dst_dev + c->n_words, 0, (total_words - c->n_words) * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_mask_or_blocks(tpc_ctx *c, const uint32_t *blocks_dev, uint32_t count, uint64_t words, uint32_t *out_dev)
+{
+    if (!c || !blocks_dev || !out_dev || count < 1) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out_dev, blocks_dev, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    for (uint32_t i = 1; i < count; i++) tpc_launch_mask_or(c->stream, out_dev, blocks_dev + (uint64_t)i * words, words);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_mask_import(tpc_ctx *c, const uint32_t *src_dev)
+{
+    if (!c || !c->rmask || !src_dev) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->rmask, src_dev, c->n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    c->marks_valid = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

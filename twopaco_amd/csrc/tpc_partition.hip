@@ -353,7 +353,10 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     int ppr = (int)(budget / (1024 * q * std::max(frac, 1.0 / 64)));  // k_part_hash: 1024 threads (two tiles) x pos_per_round
     pl.pos_per_round = std::max(1, std::min(32, ppr));
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
-    const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
+    // a workgroup takes ceil(pairs / nwg1) tile pairs: with few tiles per workgroup the busiest one holds well over the mean
+    const uint64_t pairs = (pl.n_tiles + 1) / 2, pairs_wg = (pairs + pl.nwg1 - 1) / pl.nwg1;
+    const double share1 = std::min(1.0, (double)(2 * pairs_wg) / (double)std::max<uint64_t>(pl.n_tiles, 1));
+    const double avg1 = a_max * share1 / (double)(1 << pl.b1);
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
     const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;

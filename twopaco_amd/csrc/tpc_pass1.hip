@@ -236,10 +236,15 @@ k_query(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
 //   one of them can flip a_i; an edge whose a_0 was taken by a DIFFERENT edge gets its chance on a_1 in
 //   the next launch (by then every winner's bits are visible), and so on.
 // An edge therefore counts once unless its first `phases` bits are all covered by other edges -- the
-// sequential rule is "unless all q bits are covered by earlier edges".  With a scratch filter large
-// enough that no such coverage happens both give the number of distinct edges, bin for bin
-// (tests/test_gpu_parity.py::test_split_histogram_exact_when_collision_free); on a crowded filter the
-// two differ by (fill/q)^phases of the edges, far inside the reference's own -t dependence.
+// sequential rule is "unless all q bits are covered by earlier edges".  phases = min(q, 3) while the filter
+// is sparse (the two rules then differ by (fill/q)^3 of the edges), q when it is crowded.  With a scratch
+// filter large enough that no such coverage happens both give the number of distinct edges, bin for bin
+// (tests/test_gpu_parity.py::test_split_histogram_exact_when_collision_free).
+// One order dependence survives even then, in the reference as here: for k + 1 > L the cyclic polynomial
+// hash rotates characters L positions apart by the same amount (cyclichash.h:29-35), so two DIFFERENT
+// (k+1)-mers with the same letters in every rotation class (typically windows over the edge of an N run)
+// share all q addresses; only one of them is ever "first seen", and which one (text order at -t 1, arrival
+// order otherwise) decides whose endpoint bins are bumped.  The total and all other bins are unaffected.
 template <int Q>
 __global__ void __launch_bounds__(TPC_TILE_THREADS)
 k_split(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
@@ -343,7 +348,8 @@ template <int Q>
 void launch_split_q(const TpcLaunch &a, uint32_t *todo, uint32_t *bins, uint64_t bin_size)
 {
     dim3 grid((unsigned)a.n_tiles), block(TPC_TILE_THREADS);
-    const int phases = Q < 3 ? Q : 3;  // see k_split
+    const bool crowded = (double)Q * (double)a.n_text > (double)(a.P.lmask >> 3);  // more than 1/8 of the bits could be set
+    const int phases = (Q < 3 || crowded) ? Q : 3;  // see k_split
     for (int phase = 0; phase < phases; phase++)
         hipLaunchKernelGGL((k_split<Q>), grid, block, 0, a.stream, a.P, a.tab, a.bases, a.nmask, todo, todo, phase, a.n_text, a.filter, bins, bin_size);
 }

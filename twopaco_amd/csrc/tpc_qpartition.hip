@@ -536,6 +536,78 @@ __global__ void k_v_mark(const uint64_t *__restrict__ sid_list, uint64_t n, uint
     }
 }
 
+// ---- owner routing of the survivor probes (the host layer only moves the buffers) -------------------------
+// perm[i] = slot of item i in the owner-major send order.  Each workgroup ranks a chunk of items in LDS (one LDS
+// atomic per item) and reserves its share of every owner's range with one global atomic per owner and chunk.
+constexpr int RT_CHUNK = 4096, RT_MAXW = 64;
+__global__ void __launch_bounds__(256)
+k_route_count(const int32_t *__restrict__ owner, uint64_t n, unsigned long long *counts)
+{
+    __shared__ uint32_t h[RT_MAXW];
+    if (threadIdx.x < RT_MAXW) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[owner[i] & (RT_MAXW - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < RT_MAXW && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+k_route_scatter(const int32_t *__restrict__ owner, uint64_t n, unsigned long long *cursor, uint32_t *__restrict__ perm)
+{
+    __shared__ uint32_t h[RT_MAXW];
+    __shared__ unsigned long long base[RT_MAXW];
+    for (uint64_t c0 = (uint64_t)blockIdx.x * RT_CHUNK; c0 < n; c0 += (uint64_t)gridDim.x * RT_CHUNK) {
+        if (threadIdx.x < RT_MAXW) h[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t rank[RT_CHUNK / 256];
+        int own[RT_CHUNK / 256];
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 256; u++) {
+            const uint64_t i = c0 + (uint64_t)u * 256 + threadIdx.x;
+            own[u] = i < n ? (owner[i] & (RT_MAXW - 1)) : -1;
+            rank[u] = own[u] >= 0 ? atomicAdd(&h[own[u]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x < RT_MAXW && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 256; u++) {
+            const uint64_t i = c0 + (uint64_t)u * 256 + threadIdx.x;
+            if (own[u] >= 0) perm[i] = (uint32_t)(base[own[u]] + rank[u]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_permute64(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n, uint64_t *__restrict__ dst)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[perm[i]] = src[i];
+}
+
+// survivors whose fn_count answers (in send order: hit[perm[...]]) are all 1; order of the output is not significant
+__global__ void __launch_bounds__(256)
+k_select(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8_t *__restrict__ hit, const uint32_t *__restrict__ perm,
+         uint64_t *__restrict__ out, unsigned long long *n_out)
+{
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_base;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < n; c0 += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint64_t i = c0 + threadIdx.x;
+        bool keep = i < n;
+        for (int t = 0; keep && t < fn_count; t++) keep = hit[perm[i * fn_count + t]] != 0;
+        const uint32_t r = keep ? atomicAdd(&s_cnt, 1u) : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_out, (unsigned long long)s_cnt);
+        __syncthreads();
+        if (keep) out[s_base + r] = sid[i];
+        __syncthreads();
+    }
+}
+
 template <int Q>
 void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
 {
@@ -612,7 +684,10 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     };
     pl.loads = loads_for(pl.b3 ? pl.b2 : pl.b1);
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
-    const double avg1 = a_max / ((double)pl.nwg1 * (1 << pl.b1));
+    // a workgroup takes ceil(n_tiles / nwg1) tiles: with few tiles per workgroup the busiest one holds well over the mean
+    const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
+    const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
+    const double avg1 = a_max * share1 / (double)(1 << pl.b1);
     pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
     pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
@@ -780,6 +855,26 @@ int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t
 {
     if (n) hipLaunchKernelGGL(k_v_mark, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, a.stream, sid, n,
                               pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+    return 0;
+}
+
+int tpc_launch_route(hipStream_t s, const int32_t *owner, uint64_t n, unsigned long long *counts, unsigned long long *cursor, uint32_t *perm, int phase)
+{   // phase 0: counts[64] += items per owner; phase 1: perm from the cursors (exclusive prefix of the counts, set by the caller)
+    if (n == 0) return 0;
+    if (phase == 0) hipLaunchKernelGGL(k_route_count, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, owner, n, counts);
+    else hipLaunchKernelGGL(k_route_scatter, dim3((unsigned)std::min<uint64_t>((n + RT_CHUNK - 1) / RT_CHUNK, 4096)), dim3(256), 0, s, owner, n, cursor, perm);
+    return 0;
+}
+
+int tpc_launch_permute64(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, uint64_t *dst)
+{
+    if (n) hipLaunchKernelGGL(k_permute64, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, src, perm, n, dst);
+    return 0;
+}
+
+int tpc_launch_select(hipStream_t s, const uint64_t *sid, uint64_t n, int fn_count, const uint8_t *hit, const uint32_t *perm, uint64_t *out, unsigned long long *n_out)
+{
+    if (n) hipLaunchKernelGGL(k_select, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, sid, n, fn_count, hit, perm, out, n_out);
     return 0;
 }
 

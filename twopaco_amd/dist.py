@@ -220,9 +220,10 @@ class AddressSharded:
     Query only: the survivors of the first probe (edge ids) are checked against hash functions
     1..q-1 -- addresses to their owners (variable all_to_all), one byte back per address; function 1
     alone first, which rejects most Bloom false positives, then the rest in one exchange -- and the
-    survivors of all q functions are the candidate marks.  Finally the per-rank masks are OR-ed (all_gather: RCCL has no bitwise-OR
-    reduction), after which every rank holds the mask tpc_pass1_query would have produced and the
-    second pass runs as on one GPU.
+    survivors of all q functions are the candidate marks.  The grouping of the probes by owner is done by the library
+    (tpc_shard_route / _permute64 / _select).  Finally the per-rank masks are OR-ed (an all_to_all of word ranges, a fold,
+    an all_gather: RCCL has no bitwise-OR reduction), after which every rank holds the mask tpc_pass1_query would have
+    produced and the second pass runs as on one GPU.
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
     list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
 
@@ -308,29 +309,40 @@ class AddressSharded:
                 addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
                 owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
                 ctx.shard_verify_addrs(fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
-                owner = owner.to(torch.int64)
-                order = torch.argsort(owner, stable=True)
-                counts = torch.bincount(owner, minlength=W).cpu().tolist()
-                req, rcounts = self.comm.a2a_var(addr[order].contiguous(), counts)
+                # owner-major send order from the library (tpc_shard_route), answers come back in that order
+                perm = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
+                counts = ctx.shard_route(owner.data_ptr(), n * cnt, perm.data_ptr(), W)
+                send = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
+                ctx.shard_permute64(addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
+                req, rcounts = self.comm.a2a_var(send, counts)
                 hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
                 self.comm.sync()
                 ctx.shard_probe(req.data_ptr(), req.numel(), hit.data_ptr())
                 back, _ = self.comm.a2a_var(hit, rcounts)
-                ok = torch.empty(n * cnt, dtype=torch.bool, device=self.device)
-                ok[order] = back.to(torch.bool)
-                sid = sid[ok.view(n, cnt).all(dim=1)].contiguous()
+                back = back.contiguous()
+                kept = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+                self.comm.sync()
+                m = ctx.shard_select(sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
+                sid = kept[:m].contiguous()
                 trace.append(sid.numel())
             self.comm.sync()
             ctx.shard_mark(sid.data_ptr(), sid.numel())
             self._tick("query_verify", t0)
             survivors.append(trace)
         t0 = time.perf_counter()
+        # OR all-reduce of the candidate masks by word ranges: rank r folds chunk r of every rank's mask, the folded
+        # chunks are all-gathered (RCCL has no bitwise reduction; an all_gather of whole masks moved W mask sizes per rank)
         words = ctx.mask_words()
-        m = torch.empty(words, dtype=torch.int32, device=self.device)
-        ctx.mask_export(m.data_ptr())
-        allm = self.comm.all_gather(m).contiguous()
+        chunk = (words + W - 1) // W
+        mine = torch.empty(W * chunk, dtype=torch.int32, device=self.device)
+        ctx.mask_export_padded(mine.data_ptr(), W * chunk)
+        parts = self.comm.a2a_equal(mine).contiguous()
+        folded = torch.empty(chunk, dtype=torch.int32, device=self.device)
         self.comm.sync()
-        ctx.mask_merge(allm.data_ptr(), W)
+        ctx.mask_or_blocks(parts.data_ptr(), W, chunk, folded.data_ptr())
+        allm = self.comm.all_gather(folded).contiguous()
+        self.comm.sync()
+        ctx.mask_import(allm.data_ptr())
         self._tick("mask_union", t0)
         self.stats["survivors"] = survivors
         return geom

@@ -4,7 +4,8 @@
 // (5), -r/--rounds (1), -t/--threads (1), -a/--abundance (UINT64_MAX), --tmpdir ("."),
 // -o/--outfile ("de_bruijn.bin"), --test, and the FASTA file names.  Extra flags that do not
 // exist in the reference: --seed S (pin the hash tables, see seed.h), --device N,
-// --test-first (test-then-set insert).  Errors go to stderr as "\nError: <what>\n", exit code 1
+// --test-first (test-then-set insert), --gpus N (Bloom filter sharded by bit address over N GPUs of the node,
+// RCCL between them; --no-rccl: device-to-device copies; --emulate-ranks: N ranks on one device, for testing).  Errors go to stderr as "\nError: <what>\n", exit code 1
 // (reference constructor.cpp:179-188).
 #include <cmath>
 #include <cstdint>
@@ -54,7 +55,8 @@ namespace
 	{
 		std::cout << "USAGE: twopaco {-f <integer>|--filtermemory <float>} [-k <oddc>] [-q <integer>] [-r <integer>]" << std::endl
 			<< "               [-t <integer>] [-a <integer>] [--tmpdir <directory name>] [-o <file name>] [--test]" << std::endl
-			<< "               [--seed <integer>] [--device <integer>] [--test-first] <fasta files with genomes> ..." << std::endl
+			<< "               [--seed <integer>] [--device <integer>] [--test-first] [--gpus <power of two>] [--no-rccl]" << std::endl
+			<< "               <fasta files with genomes> ..." << std::endl
 			<< "       -q: 1..16 hash functions (the reference takes any number; 9..16 run on the direct kernels)" << std::endl;
 	}
 }
@@ -123,6 +125,9 @@ int main(int argc, char * argv[])
 			else if (Match(a, 0, "seed")) { options.pinnedSeed = true; options.seed = Parse<uint64_t>(value("(--seed)"), "(--seed)"); optionsSet = true; }
 			else if (Match(a, 0, "device")) { options.device = int(Parse<unsigned int>(value("(--device)"), "(--device)")); optionsSet = true; }
 			else if (Match(a, 0, "test-first")) { options.insertTestFirst = true; optionsSet = true; }
+			else if (Match(a, 0, "gpus")) { options.gpus = int(Parse<unsigned int>(value("(--gpus)"), "(--gpus)")); optionsSet = true; }
+			else if (Match(a, 0, "no-rccl")) { options.rccl = false; optionsSet = true; }
+			else if (Match(a, 0, "emulate-ranks")) { options.emulateRanks = true; optionsSet = true; }
 			else if (Match(a, "h", "help")) { Usage(); return 0; }
 			else if (a == "--version") { std::cout << argv[0] << "  version: 1.1.0" << std::endl; return 0; }
 			else if (a.size() > 1 && a[0] == '-') throw ArgError("Couldn't find match for argument", "(" + a + ")");

@@ -100,6 +100,36 @@ extern "C"
 		}
 	}
 
+	// the same with the multi-GPU knobs: gpus ranks, transport (rccl != 0: RCCL), emulate != 0: all ranks on `device`,
+	// forceSharded != 0: the sharded path even for one GPU
+	void * tpch_create_enumerator_mgpu(const char ** files, int nfiles, uint64_t k, uint64_t filterBits, uint64_t q, uint64_t rounds,
+		uint64_t threads, uint64_t abundance, const char * tmpDir, const char * outFile, int pinned, uint64_t seed, int device,
+		int gpus, int rccl, int emulate, int forceSharded, char ** log)
+	{
+		std::stringstream ss;
+		try
+		{
+			std::vector<std::string> names(files, files + nfiles);
+			TwoPaCo::EnumeratorOptions opt;
+			opt.pinnedSeed = pinned != 0;
+			opt.seed = seed;
+			opt.device = device;
+			opt.gpus = gpus;
+			opt.rccl = rccl != 0;
+			opt.emulateRanks = emulate != 0;
+			opt.forceSharded = forceSharded != 0;
+			std::unique_ptr<TwoPaCo::VertexEnumerator> e = TwoPaCo::CreateEnumerator(names, k, filterBits, q, rounds, threads, abundance, tmpDir, outFile, ss, opt);
+			if (log) *log = Dup(ss.str());
+			return e.release();
+		}
+		catch (std::exception & e)
+		{
+			g_error = e.what();
+			if (log) *log = Dup(ss.str());
+			return 0;
+		}
+	}
+
 	void tpch_enumerator_free(void * h) { delete static_cast<TwoPaCo::VertexEnumerator*>(h); }
 	uint64_t tpch_vertices_count(void * h) { return static_cast<TwoPaCo::VertexEnumerator*>(h)->GetVerticesCount(); }
 	int64_t tpch_get_id(void * h, const char * kmer) { return static_cast<TwoPaCo::VertexEnumerator*>(h)->GetId(kmer); }

@@ -1,0 +1,422 @@
+// multigpu.cpp -- see multigpu.h.  Orchestration of the address-sharded first pass (one thread per GPU) and its two
+// transports.  The call sequence per pass is the one documented in include/twopaco_hip.h (tpc_shard_*):
+//   hash (level 1 of the write-combining partition over this rank's tiles, regions grouped by destination rank)
+//   -> all-to-all of the level-1 regions and their fill counts (ncclSend / ncclRecv group)
+//   -> apply (levels 2-3 on the owned filter slices: OR for the insert, first Bloom probe for the query)
+// and for the query: survivors of the first probe -> addresses of hash functions 1..q-1 routed to their owners
+// (tpc_shard_route / _permute64, variable all-to-all), one answer byte back, tpc_shard_select, tpc_shard_mark; finally
+// the candidate masks are OR-reduced by word ranges (all-to-all, fold, all-gather).
+#include "multigpu.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <stdexcept>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "../../include/twopaco_hip.h"
+
+namespace TwoPaCo
+{
+	namespace
+	{
+		void HipCheck(hipError_t e, const char * what)
+		{
+			if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+		}
+
+		void LibCheck(tpc_ctx * ctx, int rc, const char * what)
+		{
+			if (rc != 0) throw std::runtime_error(std::string(what) + ": " + tpc_last_error(ctx));
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------ barrier + host exchange
+	void RankBarrier::Wait()
+	{
+		std::unique_lock<std::mutex> lock(mutex_);
+		if (failed_) throw std::runtime_error("another rank failed: " + error_);
+		const uint64_t gen = generation_;
+		if (++waiting_ == ranks_)
+		{
+			waiting_ = 0;
+			++generation_;
+			cv_.notify_all();
+		}
+		else
+		{
+			cv_.wait(lock, [&]() { return generation_ != gen || failed_; });
+		}
+
+		if (failed_) throw std::runtime_error("another rank failed: " + error_);
+	}
+
+	void RankBarrier::Fail(const std::string & what)
+	{
+		std::unique_lock<std::mutex> lock(mutex_);
+		if (!failed_)
+		{
+			failed_ = true;
+			error_ = what;
+		}
+
+		cv_.notify_all();
+	}
+
+	void Transport::ExchangeHost(int rank, const uint64_t * mine, int n, std::vector<uint64_t> & all)
+	{
+		if (n > 64) throw std::runtime_error("ExchangeHost: too many values");
+		barrier_.Wait();  // the previous exchange has been read by everyone
+		for (int i = 0; i < n; i++) scratch_[size_t(rank) * 64 + i] = mine[i];
+		barrier_.Wait();
+		all.resize(size_t(ranks_) * n);
+		for (int r = 0; r < ranks_; r++)
+		{
+			for (int i = 0; i < n; i++) all[size_t(r) * n + i] = scratch_[size_t(r) * 64 + i];
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------ loopback transport
+	namespace
+	{
+		class LoopbackTransport : public Transport
+		{
+		public:
+			LoopbackTransport(const std::vector<int> & devices) : Transport(int(devices.size())), devices_(devices), send_(devices.size()), counts_(devices.size()) {}
+			const char * Name() const { return "loopback (device-to-device copies inside the process)"; }
+
+			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
+			{
+				send_[rank] = send;
+				barrier_.Wait();
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				for (int s = 0; s < ranks_; s++)
+				{
+					HipCheck(hipMemcpy(static_cast<char*>(recv) + size_t(s) * blockBytes, static_cast<const char*>(send_[s]) + size_t(rank) * blockBytes,
+						blockBytes, hipMemcpyDeviceToDevice), "loopback all-to-all copy");
+				}
+
+				if (rank == 0) bytesMoved_ += uint64_t(ranks_) * blockBytes;
+				barrier_.Wait();  // nobody reuses a send buffer before every peer has copied from it
+			}
+
+			void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes)
+			{
+				send_[rank] = send;
+				counts_[rank].assign(sendCounts, sendCounts + ranks_);
+				barrier_.Wait();
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				uint64_t at = 0;
+				for (int s = 0; s < ranks_; s++)
+				{
+					uint64_t off = 0;
+					for (int d = 0; d < rank; d++) off += counts_[s][d];
+					if (counts_[s][rank] != recvCounts[s]) throw std::runtime_error("loopback all-to-all: count mismatch");
+					if (recvCounts[s])
+					{
+						HipCheck(hipMemcpy(static_cast<char*>(recv) + at * elemBytes, static_cast<const char*>(send_[s]) + off * elemBytes,
+							size_t(recvCounts[s]) * elemBytes, hipMemcpyDeviceToDevice), "loopback all-to-all copy");
+					}
+
+					at += recvCounts[s];
+				}
+
+				barrier_.Wait();
+			}
+
+			void AllGather(int rank, const void * send, void * recv, size_t bytes)
+			{
+				send_[rank] = send;
+				barrier_.Wait();
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				for (int s = 0; s < ranks_; s++)
+				{
+					HipCheck(hipMemcpy(static_cast<char*>(recv) + size_t(s) * bytes, send_[s], bytes, hipMemcpyDeviceToDevice), "loopback all-gather copy");
+				}
+
+				barrier_.Wait();
+			}
+
+		private:
+			std::vector<int> devices_;
+			std::vector<const void*> send_;
+			std::vector<std::vector<uint64_t> > counts_;
+		};
+
+		// -------------------------------------------------------------------------------------- RCCL transport
+		struct RcclApi
+		{
+			void * lib;
+			ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+			ncclResult_t (*CommDestroy)(ncclComm_t);
+			ncclResult_t (*GroupStart)();
+			ncclResult_t (*GroupEnd)();
+			ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+			ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+			ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+			const char * (*GetErrorString)(ncclResult_t);
+			RcclApi() : lib(0) {}
+			bool Load()
+			{
+				lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+				if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+				if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+				if (!lib) return false;
+				CommInitAll = reinterpret_cast<ncclResult_t (*)(ncclComm_t *, int, const int *)>(dlsym(lib, "ncclCommInitAll"));
+				CommDestroy = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(lib, "ncclCommDestroy"));
+				GroupStart = reinterpret_cast<ncclResult_t (*)()>(dlsym(lib, "ncclGroupStart"));
+				GroupEnd = reinterpret_cast<ncclResult_t (*)()>(dlsym(lib, "ncclGroupEnd"));
+				Send = reinterpret_cast<ncclResult_t (*)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>(dlsym(lib, "ncclSend"));
+				Recv = reinterpret_cast<ncclResult_t (*)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>(dlsym(lib, "ncclRecv"));
+				AllGather = reinterpret_cast<ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>(dlsym(lib, "ncclAllGather"));
+				GetErrorString = reinterpret_cast<const char * (*)(ncclResult_t)>(dlsym(lib, "ncclGetErrorString"));
+				return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllGather && GetErrorString;
+			}
+		};
+
+		class RcclTransport : public Transport
+		{
+		public:
+			RcclTransport(const std::vector<int> & devices) : Transport(int(devices.size())), devices_(devices), comms_(devices.size()), streams_(devices.size())
+			{
+				if (!api_.Load()) throw std::runtime_error("Can't load librccl.so");
+				Check(api_.CommInitAll(comms_.data(), ranks_, devices_.data()), "ncclCommInitAll");
+				for (int r = 0; r < ranks_; r++)
+				{
+					HipCheck(hipSetDevice(devices_[r]), "hipSetDevice");
+					HipCheck(hipStreamCreate(&streams_[r]), "hipStreamCreate");
+				}
+			}
+
+			~RcclTransport()
+			{
+				for (int r = 0; r < ranks_; r++)
+				{
+					(void)hipSetDevice(devices_[r]);
+					if (streams_[r]) (void)hipStreamDestroy(streams_[r]);
+					if (comms_[r]) api_.CommDestroy(comms_[r]);
+				}
+			}
+
+			const char * Name() const { return "RCCL (ncclSend/ncclRecv groups over xGMI)"; }
+
+			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
+			{
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				Check(api_.GroupStart(), "ncclGroupStart");
+				for (int p = 0; p < ranks_; p++)
+				{
+					Check(api_.Send(static_cast<const char*>(send) + size_t(p) * blockBytes, blockBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
+					Check(api_.Recv(static_cast<char*>(recv) + size_t(p) * blockBytes, blockBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
+				}
+
+				Check(api_.GroupEnd(), "ncclGroupEnd");
+				HipCheck(hipStreamSynchronize(streams_[rank]), "all-to-all");
+				if (rank == 0) bytesMoved_ += uint64_t(ranks_) * blockBytes;
+			}
+
+			void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes)
+			{
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				Check(api_.GroupStart(), "ncclGroupStart");
+				uint64_t so = 0, ro = 0;
+				for (int p = 0; p < ranks_; p++)
+				{
+					if (sendCounts[p]) Check(api_.Send(static_cast<const char*>(send) + so * elemBytes, size_t(sendCounts[p]) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
+					if (recvCounts[p]) Check(api_.Recv(static_cast<char*>(recv) + ro * elemBytes, size_t(recvCounts[p]) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
+					so += sendCounts[p];
+					ro += recvCounts[p];
+				}
+
+				Check(api_.GroupEnd(), "ncclGroupEnd");
+				HipCheck(hipStreamSynchronize(streams_[rank]), "all-to-all");
+				if (rank == 0) bytesMoved_ += so * elemBytes;
+			}
+
+			void AllGather(int rank, const void * send, void * recv, size_t bytes)
+			{
+				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
+				Check(api_.AllGather(send, recv, bytes, ncclUint8, comms_[rank], streams_[rank]), "ncclAllGather");
+				HipCheck(hipStreamSynchronize(streams_[rank]), "all-gather");
+			}
+
+		private:
+			void Check(ncclResult_t r, const char * what)
+			{
+				if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + api_.GetErrorString(r));
+			}
+
+			RcclApi api_;
+			std::vector<int> devices_;
+			std::vector<ncclComm_t> comms_;
+			std::vector<hipStream_t> streams_;
+		};
+	}
+
+	std::unique_ptr<Transport> MakeTransport(const std::vector<int> & devices, bool rccl)
+	{
+		std::vector<int> sorted(devices);
+		std::sort(sorted.begin(), sorted.end());
+		const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+		if (rccl && distinct) return std::unique_ptr<Transport>(new RcclTransport(devices));
+		return std::unique_ptr<Transport>(new LoopbackTransport(devices));
+	}
+
+	// ------------------------------------------------------------------------------------------ one rank's scratch
+	void * ShardedRank::Ensure(int which, size_t bytes)
+	{
+		if (bytes > cap[which])
+		{
+			HipCheck(hipSetDevice(device), "hipSetDevice");
+			if (buf[which]) (void)hipFree(buf[which]);
+			buf[which] = 0;
+			cap[which] = 0;
+			const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+			HipCheck(hipMalloc(&buf[which], want), "hipMalloc (exchange buffer)");
+			cap[which] = want;
+		}
+
+		return buf[which];
+	}
+
+	void ShardedRank::Release()
+	{
+		(void)hipSetDevice(device);
+		for (int i = 0; i < 12; i++)
+		{
+			if (buf[i]) (void)hipFree(buf[i]);
+			buf[i] = 0;
+			cap[i] = 0;
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------ the pass
+	namespace
+	{
+		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B };
+
+		// hash -> exchange -> (overflow lists) ; returns the receive buffers in r.buf[RECV_R], r.buf[RECV_C]
+		void HashAndExchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, uint64_t batch, uint64_t lo, uint64_t hi)
+		{
+			const int W = net.Ranks();
+			void * sendR = r.Ensure(SEND_R, size_t(W) * geom[2]);
+			void * sendC = r.Ensure(SEND_C, size_t(W) * geom[3]);
+			void * recvR = r.Ensure(RECV_R, size_t(W) * geom[2]);
+			void * recvC = r.Ensure(RECV_C, size_t(W) * geom[3]);
+			uint64_t overflow = 0;
+			LibCheck(r.ctx, tpc_shard_hash(r.ctx, pass, batch, lo, hi, sendR, sendC, &overflow), "shard_hash");
+			net.AllToAll(r.rank, sendC, recvC, geom[3]);
+			net.AllToAll(r.rank, sendR, recvR, geom[2]);
+			// skew path: entries that did not fit their level-1 region travel as one all-gathered list
+			std::vector<uint64_t> all;
+			net.ExchangeHost(r.rank, &overflow, 1, all);
+			const uint64_t most = *std::max_element(all.begin(), all.end());
+			if (most >= (uint64_t(1) << 62))
+			{
+				throw std::runtime_error("address-sharded pass: an overflow list overflowed (adversarial address skew)");
+			}
+
+			if (most > 0)
+			{
+				const size_t eb = geom[6];
+				char * mine = static_cast<char*>(r.Ensure(OVF_MINE, most * eb));
+				char * gathered = static_cast<char*>(r.Ensure(OVF_ALL, size_t(W) * most * eb));
+				LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
+				net.AllGather(r.rank, mine, gathered, most * eb);
+				// compact the blocks (each holds all[s] valid entries) to the front of `gathered`
+				uint64_t total = all[0];
+				for (int s = 1; s < W; s++)
+				{
+					if (all[s]) HipCheck(hipMemcpy(gathered + total * eb, gathered + size_t(s) * most * eb, all[s] * eb, hipMemcpyDeviceToDevice), "overflow compaction");
+					total += all[s];
+				}
+
+				LibCheck(r.ctx, tpc_shard_overflow_set(r.ctx, pass, gathered, total), "shard_overflow_set");
+			}
+		}
+
+		// Survivors of the first probe against functions fn .. fn+count-1; returns the number that passed (ids in r.buf[SID]).
+		uint64_t VerifyStep(ShardedRank & r, Transport & net, uint64_t n, int fn, int count)
+		{
+			const int W = net.Ranks();
+			const uint64_t items = n * uint64_t(count);
+			uint64_t * sid = static_cast<uint64_t*>(r.buf[SID]);
+			uint64_t * addr = static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(items, 1) * 8));
+			int32_t * owner = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(items, 1) * 4));
+			LibCheck(r.ctx, tpc_shard_verify_addrs(r.ctx, fn, count, sid, n, addr, owner), "shard_verify_addrs");
+			uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(items, 1) * 4));
+			uint64_t counts[64];
+			LibCheck(r.ctx, tpc_shard_route(r.ctx, owner, items, perm, counts), "shard_route");
+			uint64_t * sendAddr = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(items, 1) * 8));
+			LibCheck(r.ctx, tpc_shard_permute64(r.ctx, addr, perm, items, sendAddr), "shard_permute64");
+			std::vector<uint64_t> all;
+			net.ExchangeHost(r.rank, counts, W, all);
+			std::vector<uint64_t> recvCounts(W);
+			uint64_t asked = 0;
+			for (int s = 0; s < W; s++)
+			{
+				recvCounts[s] = all[size_t(s) * W + r.rank];
+				asked += recvCounts[s];
+			}
+
+			// requests in (reuse ADDR: the unpermuted addresses are no longer needed), answers out
+			uint64_t * req = static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(std::max(asked, items), 1) * 8));
+			net.AllToAllV(r.rank, sendAddr, counts, req, recvCounts.data(), 8);
+			uint8_t * answers = static_cast<uint8_t*>(r.Ensure(OWNER, std::max<uint64_t>(std::max(asked, items * 4), 1)));
+			LibCheck(r.ctx, tpc_shard_probe(r.ctx, req, asked, answers), "shard_probe");
+			uint8_t * back = static_cast<uint8_t*>(r.Ensure(MISC_B, std::max<uint64_t>(items * 8, 1)));
+			net.AllToAllV(r.rank, answers, recvCounts.data(), back, counts, 1);
+			uint64_t * kept = static_cast<uint64_t*>(r.Ensure(SID2, std::max<uint64_t>(n, 1) * 8));
+			uint64_t m = 0;
+			LibCheck(r.ctx, tpc_shard_select(r.ctx, sid, n, count, back, perm, kept, &m), "shard_select");
+			std::swap(r.buf[SID], r.buf[SID2]);
+			std::swap(r.cap[SID], r.cap[SID2]);
+			return m;
+		}
+	}
+
+	void ShardedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi)
+	{
+		const int W = net.Ranks();
+		uint64_t geom[16];
+		// ---- insert (FilterFillerWorker)
+		LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_INSERT, lo, hi, geom), "shard_plan(insert)");
+		LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
+		for (uint64_t b = 0; b < geom[0]; b++)
+		{
+			HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
+			LibCheck(r.ctx, tpc_shard_apply(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+		}
+
+		net.Barrier().Wait();  // every shard is complete before anyone probes it
+		// ---- query (CandidateCheckingWorker)
+		LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_QUERY, lo, hi, geom), "shard_plan(query)");
+		for (uint64_t b = 0; b < geom[0]; b++)
+		{
+			HashAndExchange(r, net, TPC_SHARD_QUERY, geom, b, lo, hi);
+			uint64_t n = 0;
+			LibCheck(r.ctx, tpc_shard_apply(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
+			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
+			// function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together
+			if (hashFunctions > 1) n = VerifyStep(r, net, n, 1, 1);
+			if (hashFunctions > 2) n = VerifyStep(r, net, n, 2, hashFunctions - 2);
+			LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");
+		}
+
+		// ---- union of the candidate masks: OR all-reduce by word ranges
+		const uint64_t words = tpc_mask_words(r.ctx);
+		const uint64_t chunk = (words + W - 1) / W;
+		uint32_t * mine = static_cast<uint32_t*>(r.Ensure(SEND_R, size_t(W) * chunk * 4));
+		uint32_t * parts = static_cast<uint32_t*>(r.Ensure(RECV_R, size_t(W) * chunk * 4));
+		uint32_t * folded = static_cast<uint32_t*>(r.Ensure(MISC_A, chunk * 4));
+		LibCheck(r.ctx, tpc_mask_export_padded(r.ctx, mine, W * chunk), "mask_export_padded");
+		net.AllToAll(r.rank, mine, parts, chunk * 4);
+		LibCheck(r.ctx, tpc_mask_or_blocks(r.ctx, parts, uint32_t(W), chunk, folded), "mask_or_blocks");
+		net.AllGather(r.rank, folded, mine, chunk * 4);
+		LibCheck(r.ctx, tpc_mask_import(r.ctx, mine), "mask_import");
+	}
+}

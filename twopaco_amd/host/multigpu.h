@@ -1,0 +1,91 @@
+// multigpu.h -- the first pass with the Bloom filter sharded by bit address over several GPUs of one node
+// (BASELINE.json north_star; the shared filter it replaces: reference graphconstructor/concurrentbitvector.cpp:31-52,
+// filled by FilterFillerWorker vertexenumerator.h:995-1105 and read by CandidateCheckingWorker :586-704).
+//
+// One host thread per GPU ("rank"), each with its own context of the device library; the library never communicates
+// (include/twopaco_hip.h, tpc_shard_*), this layer moves the device buffers between the ranks:
+//   RcclTransport      ncclSend / ncclRecv groups and ncclAllGather over xGMI (one communicator per device,
+//                      ncclCommInitAll); librccl is loaded on first use, so single-GPU runs never pay for it
+//   LoopbackTransport  device-to-device copies between the ranks of this process: the fallback transport, and the way the
+//                      whole orchestration is tested with several ranks on ONE device (RCCL refuses duplicate devices)
+// Host-side scalars (counts, overflow sizes) travel through the process's own memory.
+#ifndef _TPC_MULTIGPU_H_
+#define _TPC_MULTIGPU_H_
+
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct tpc_ctx;
+
+namespace TwoPaCo
+{
+	// Reusable barrier for the rank threads; also carries the first error so that no rank waits for a dead one.
+	class RankBarrier
+	{
+	public:
+		explicit RankBarrier(int ranks) : ranks_(ranks), waiting_(0), generation_(0), failed_(false) {}
+		void Wait();                         // throws if any rank reported a failure
+		void Fail(const std::string & what);  // wakes everyone
+		bool Failed() const { return failed_; }
+		const std::string & Error() const { return error_; }
+	private:
+		int ranks_, waiting_;
+		uint64_t generation_;
+		bool failed_;
+		std::string error_;
+		std::mutex mutex_;
+		std::condition_variable cv_;
+	};
+
+	// Collectives on DEVICE buffers; every rank calls the same sequence, a call returns when the rank's data is in place.
+	class Transport
+	{
+	public:
+		Transport(int ranks) : ranks_(ranks), barrier_(ranks), scratch_(size_t(ranks) * 64) {}
+		virtual ~Transport() {}
+		int Ranks() const { return ranks_; }
+		// block d of `send` goes to rank d; block s of `recv` came from rank s
+		virtual void AllToAll(int rank, const void * send, void * recv, size_t blockBytes) = 0;
+		// sendCounts[d] elements for rank d (contiguous, rank order); recvCounts[s] elements from rank s
+		virtual void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes) = 0;
+		virtual void AllGather(int rank, const void * send, void * recv, size_t bytes) = 0;
+		virtual const char * Name() const = 0;
+		// n host values per rank -> all[r * n + i] on every rank (n <= 64)
+		void ExchangeHost(int rank, const uint64_t * mine, int n, std::vector<uint64_t> & all);
+		RankBarrier & Barrier() { return barrier_; }
+		uint64_t BytesMoved() const { return bytesMoved_; }
+	protected:
+		int ranks_;
+		RankBarrier barrier_;
+		std::vector<uint64_t> scratch_;
+		uint64_t bytesMoved_ = 0;  // by rank 0
+	};
+
+	// devices[r] = HIP device of rank r.  rccl = false, or a device listed twice: LoopbackTransport.
+	std::unique_ptr<Transport> MakeTransport(const std::vector<int> & devices, bool rccl);
+
+	// One round of the address-sharded first pass on rank `rank` (all ranks call it with the same lo/hi): insert, query,
+	// verification of the survivors, union of the candidate masks.  Afterwards every rank's context holds the round mask
+	// tpc_pass1_query would have produced on one GPU.  marks = set bits of that mask.
+	struct ShardedRank
+	{
+		int rank;
+		int device;
+		tpc_ctx * ctx;
+		// device scratch owned by the rank (grown on demand, freed by Release)
+		void * buf[12];
+		size_t cap[12];
+		ShardedRank() : rank(0), device(0), ctx(0) { for (int i = 0; i < 12; i++) { buf[i] = 0; cap[i] = 0; } }
+		void * Ensure(int which, size_t bytes);
+		void Release();
+	};
+
+	void ShardedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi);
+}
+
+#endif

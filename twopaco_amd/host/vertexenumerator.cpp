@@ -15,6 +15,7 @@
 #include <stdexcept>
 
 #include "../../include/twopaco_hip.h"
+#include "multigpu.h"
 #include "streamfastaparser.h"
 #include "textpack.h"
 
@@ -46,6 +47,12 @@ namespace TwoPaCo
 			HipVertexEnumerator() : ctx_(0), vertices_(0) {}
 			~HipVertexEnumerator()
 			{
+				for (ShardedRank & r : peers_)
+				{
+					r.Release();
+					if (r.ctx && r.ctx != ctx_) tpc_ctx_destroy(r.ctx);
+				}
+
 				if (ctx_) tpc_ctx_destroy(ctx_);
 			}
 
@@ -89,6 +96,23 @@ namespace TwoPaCo
 					throw std::runtime_error("The number of rounds must be positive");
 				}
 
+				// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
+				// ~25 ms per GiB, beyond the first ~48 GiB), an extra batch costs 15-20 ms of kernel time at f=36.
+				// Every rank of a sharded run gets the SAME budget: the batch geometry must agree on all of them.
+				const char * budgetGb = std::getenv("TWOPACO_PART_BUDGET_GB");
+				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : 20.0) * double(1ull << 30));
+				const int gpus = std::max(1, options.gpus);
+				const bool sharded = gpus > 1 || options.forceSharded;
+				// filter slices of 2^20 bits (128 KiB of LDS) unless the filter is too small to give every rank its level-1 buckets:
+				// the fan-out 2^(L - slice_bits) is split over two levels and the first must have at least `gpus` buckets
+				int logGpus = 0;
+				while ((1 << logGpus) < gpus) ++logGpus;
+				const int shardSliceBits = int(std::min<int64_t>(20, std::max<int64_t>(6, int64_t(filterSize) - std::max(2, 2 * logGpus))));
+				if (gpus > 64 || (gpus & (gpus - 1)))
+				{
+					throw std::runtime_error("The number of GPUs must be a power of two (the Bloom filter is cut by bit address)");
+				}
+
 				const size_t capacity = (vertexLength + 4 + 31) / 32;  // CalculateNeededCapacity
 				if (capacity >= 20)
 				{
@@ -130,11 +154,13 @@ namespace TwoPaCo
 						warm = std::thread([this]() { PhaseTimer warmTimer; tpc_warmup(ctx_); warmTimer.Lap("  warm-up thread: code objects"); });
 
 						Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
-						// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
-						// ~25 ms per GiB, beyond the first ~48 GiB), an extra batch costs 15-20 ms of kernel time at f=36
-						const char * gb = std::getenv("TWOPACO_PART_BUDGET_GB");
-						const double budget = gb ? std::atof(gb) : 20.0;
-						Check(tpc_set_option(ctx_, "part_budget_bytes", int64_t(budget * double(1ull << 30))), "set_option");
+						Check(tpc_set_option(ctx_, "part_budget_bytes", partBudget), "set_option");
+						if (sharded)
+						{
+							Check(tpc_set_option(ctx_, "slice_bits", shardSliceBits), "set_option");
+							Check(tpc_shard_config(ctx_, 0, uint32_t(gpus)), "shard_config");
+						}
+
 						Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 						setupTimer.Lap("  setup thread: parameters + filter allocation");
 					}
@@ -187,6 +213,47 @@ namespace TwoPaCo
 
 				if (!nothing) Check(tpc_run_begin(ctx_), "run_begin");
 
+				// ---- several GPUs: one rank (thread + context) per device, the filter cut by bit address (multigpu.h)
+				std::unique_ptr<Transport> net;
+				if (sharded && !nothing)
+				{
+					std::vector<int> devices(gpus);
+					for (int r = 0; r < gpus; r++) devices[r] = options.emulateRanks ? options.device : options.device + r;
+					net = MakeTransport(devices, options.rccl && !options.emulateRanks);
+					logStream << "GPUs = " << gpus << " (Bloom filter sharded by bit address; transport: " << net->Name() << ")" << std::endl;
+					peers_.resize(gpus);
+					peers_[0].rank = 0; peers_[0].device = devices[0]; peers_[0].ctx = ctx_;
+					std::vector<std::string> errors(gpus);
+					std::vector<std::thread> pool;
+					for (int r = 1; r < gpus; r++)
+					{
+						pool.emplace_back([&, r]()
+						{
+							try
+							{
+								ShardedRank & me = peers_[r];
+								me.rank = r; me.device = devices[r];
+								if (tpc_ctx_create(devices[r], &me.ctx) != 0) throw std::runtime_error("Can't create a GPU context on device " + std::to_string(devices[r]));
+								auto check = [&](int rc, const char * what) { if (rc != 0) throw std::runtime_error(std::string(what) + ": " + tpc_last_error(me.ctx)); };
+								check(tpc_set_option(me.ctx, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
+								check(tpc_set_option(me.ctx, "slice_bits", shardSliceBits), "set_option");
+								check(tpc_set_option(me.ctx, "part_budget_bytes", partBudget), "set_option");
+								check(tpc_shard_config(me.ctx, uint32_t(r), uint32_t(gpus)), "shard_config");
+								check(tpc_set_params(me.ctx, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
+								check(tpc_seq_upload(me.ctx, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
+							}
+							catch (std::exception & e)
+							{
+								errors[r] = e.what();
+							}
+						});
+					}
+
+					for (std::thread & th : pool) th.join();
+					for (const std::string & e : errors) if (!e.empty()) throw std::runtime_error(e);
+					timer.Lap("peer contexts + text upload");
+				}
+
 				const uint64_t BIN_SIZE = std::max(uint64_t(1), realSize / BINS_COUNT);
 				std::vector<uint32_t> binCounter;
 				double roundSize = 0;
@@ -194,7 +261,19 @@ namespace TwoPaCo
 				{
 					logStream << "Splitting the input kmers set..." << std::endl;
 					binCounter.resize(BINS_COUNT + 1);
-					if (!nothing) Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
+					if (sharded)
+					{
+						// The split pass needs the whole filter as scratch, which no rank holds.  The vertex hash is the minimum of
+						// two well mixed L-bit hashes (density 2(1-x) over [0, 2^L)), so the histogram the pass would measure is
+						// known in expectation: bin b gets the mass of [b, b+1) * BIN_SIZE; the planner below then cuts equal shares.
+						const double bins = double(BINS_COUNT);
+						for (uint64_t b = 0; b < BINS_COUNT; b++)
+						{
+							const double x0 = double(b) / bins, x1 = double(b + 1) / bins;
+							binCounter[b] = uint32_t(((1.0 - (1.0 - x1) * (1.0 - x1)) - (1.0 - (1.0 - x0) * (1.0 - x0))) * 4e9 / 2.0);
+						}
+					}
+					else if (!nothing) Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
 					roundSize = double(std::accumulate(binCounter.begin(), binCounter.begin() + BINS_COUNT, size_t(0))) / rounds;
 				}
 
@@ -233,21 +312,53 @@ namespace TwoPaCo
 					logStream << "Round " << round << ", " << low << ":" << high << std::endl;
 					logStream << "Pass\tFilling\tFiltering" << std::endl << "1\t";
 					PhaseTimer sub;
-					if (!nothing) Check(tpc_filter_reset(ctx_), "filter_reset");
 					uint64_t kmers = 0;
-					if (!nothing) Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
-					sub.Lap("  round: insert");
-					logStream << time(0) - mark << "\t";
-					mark = time(0);
 					uint64_t marks = 0;
-					if (!nothing) Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
-					sub.Lap("  round: query");
-					logStream << time(0) - mark << "\t" << std::endl;
+					if (net)
+					{
+						// every rank runs the same round; rank 0 is this thread's context
+						std::vector<std::string> errors(gpus);
+						std::vector<std::thread> pool;
+						for (int r = 0; r < gpus; r++)
+						{
+							pool.emplace_back([&, r]()
+							{
+								try
+								{
+									ShardedFirstPass(peers_[r], *net, int(hashFunctions), low, high);
+								}
+								catch (std::exception & e)
+								{
+									errors[r] = e.what();
+									net->Barrier().Fail(e.what());
+								}
+							});
+						}
+
+						for (std::thread & th : pool) th.join();
+						for (const std::string & e : errors) if (!e.empty()) throw std::runtime_error(e);
+						sub.Lap("  round: sharded insert + query");
+						logStream << time(0) - mark << "\t";
+						mark = time(0);
+						logStream << time(0) - mark << "\t" << std::endl;
+					}
+					else
+					{
+						if (!nothing) Check(tpc_filter_reset(ctx_), "filter_reset");
+						if (!nothing) Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+						sub.Lap("  round: insert");
+						logStream << time(0) - mark << "\t";
+						mark = time(0);
+						if (!nothing) Check(tpc_pass1_query(ctx_, low, high, &marks), "pass1_query");
+						sub.Lap("  round: query");
+						logStream << time(0) - mark << "\t" << std::endl;
+					}
 
 					mark = time(0);
 					logStream << "2\t";
 					uint64_t truePositives = 0, falsePositives = 0, hashTableSize = 0;
 					if (!nothing) Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
+					if (net) marks = uint64_t(std::max<int64_t>(0, tpc_get_stat(ctx_, "round_marks")));
 					sub.Lap("  round: exact filter");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
@@ -365,6 +476,7 @@ namespace TwoPaCo
 			tpc_ctx * ctx_;
 			size_t vertices_;
 			VertexRollingHashSeed seed_;
+			std::vector<ShardedRank> peers_;  // gpus > 1: one rank per device; peers_[0].ctx == ctx_
 		};
 	}
 

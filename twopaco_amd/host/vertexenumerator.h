@@ -49,7 +49,11 @@ namespace TwoPaCo
 		uint64_t seed;        // with pinnedSeed: the TPC_URANDOM_SEED of oracle/urandom_shim.c
 		int device;           // HIP device ordinal
 		bool insertTestFirst; // test-then-set insert (reference vertexenumerator.h:1088) instead of plain atomicOr
-		EnumeratorOptions() : pinnedSeed(false), seed(0), device(0), insertTestFirst(false) {}
+		int gpus;             // > 1: Bloom filter sharded by bit address over devices device .. device+gpus-1 (a power of two; multigpu.h)
+		bool rccl;            // transport between the GPUs: RCCL (default) or device-to-device copies
+		bool emulateRanks;    // testing: all `gpus` ranks on ONE device (copies instead of RCCL, which refuses duplicate devices)
+		bool forceSharded;    // testing: take the sharded path (and its transport) even with gpus == 1
+		EnumeratorOptions() : pinnedSeed(false), seed(0), device(0), insertTestFirst(false), gpus(1), rccl(true), emulateRanks(false), forceSharded(false) {}
 	};
 
 	std::unique_ptr<VertexEnumerator> CreateEnumerator(const std::vector<std::string> & fileName,

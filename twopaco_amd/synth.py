@@ -8,6 +8,8 @@ independent of numpy's RNG streams, cheap to regenerate on the GPU box.
       substitutions (BASELINE.json configs[1], k=25 f=32)
   m2: 62 E. coli-like genomes x 5 Mbp: 6 clades at 2 % from the root, members at 0.2 % from
       their clade ancestor, N runs (length 1..100) covering ~0.1 % (configs[2], k=25 f=36)
+  m3: 7 "human-like" genomes x 160 Mbp (1.12 Gbp: more than 2^30 positions, so the partitioned query needs
+      several tile batches), 0.1 % substitutions from a common root, N runs (configs[3]'s shape, k=25 f=38)
 Codes: A0 C1 G2 T3, N = 4.
 """
 import numpy as np
@@ -34,12 +36,36 @@ def _stream(seed, n, salt=0):
         return _mix(np.arange(n, dtype=np.uint64) * _G + base)
 
 
+def _native():
+    """host/synthgen.cpp: the same streams on all host threads (a 1 Gbp workload in seconds instead of minutes).
+    TPC_SYNTH_NUMPY=1 forces the numpy code below (the definition; the two are compared bit for bit in the tests)."""
+    import os
+    if os.environ.get("TPC_SYNTH_NUMPY"):
+        return None
+    try:
+        from . import capi
+        return capi.host()
+    except Exception:  # library not built yet
+        return None
+
+
 def random_genome(n, seed):
+    L = _native()
+    if L is not None:
+        out = np.empty(n, dtype=np.uint8)
+        L.tpch_synth_genome(seed, n, out.ctypes.data)
+        return out
     return (_stream(seed, n) >> np.uint64(62)).astype(np.uint8)
 
 
 def substitute(codes, rate, seed):
     """i.i.d. substitutions at `rate`, uniform over the three other letters."""
+    L = _native()
+    if L is not None:
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        out = np.empty_like(codes)
+        L.tpch_synth_substitute(codes.ctypes.data, codes.size, int(rate * 2.0 ** 64), seed, out.ctypes.data)
+        return out
     r = _stream(seed, codes.size, 1)
     hit = r < np.uint64(int(rate * 2.0 ** 64))
     shift = (_stream(seed, codes.size, 2) % np.uint64(3)).astype(np.uint8) + np.uint8(1)
@@ -49,6 +75,11 @@ def substitute(codes, rate, seed):
 
 
 def add_n_runs(codes, start_rate, seed, max_len=100):
+    L = _native()
+    if L is not None:
+        out = np.array(codes, dtype=np.uint8, copy=True)
+        L.tpch_synth_n_runs(out.ctypes.data, out.size, int(start_rate * 2.0 ** 64), seed, max_len)
+        return out
     r = _stream(seed, codes.size, 3)
     starts = np.nonzero(r < np.uint64(int(start_rate * 2.0 ** 64)))[0]
     lens = (_stream(seed, starts.size, 4) % np.uint64(max_len)).astype(np.int64) + 1
@@ -75,6 +106,11 @@ def workload(name, seed=12345, scale=1.0):
             mem = substitute(anc, 0.002, seed + 2000 + g)
             recs.append(add_n_runs(mem, 2e-5, seed + 3000 + g))
         return recs, dict(k=25, L=36, q=5)
+    if name == "m3":
+        n = int(160_000_000 * scale)
+        root = random_genome(n, seed)
+        recs = [add_n_runs(substitute(root, 0.001, seed + 4000 + g), 2e-6, seed + 5000 + g) for g in range(7)]
+        return recs, dict(k=25, L=38, q=5)
     raise ValueError("unknown workload " + name)
 
 
