@@ -206,8 +206,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--e2e-runs", type=int, default=3, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
-    ap.add_argument("--decomposition", default="ranges", choices=["ranges", "address"],
-                    help="multi-GPU: vertex-hash ranges (default) or the address-sharded filter (power-of-two N)")
+    ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
+                    help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
+                         "power-of-two N), or vertex-hash ranges (the reference's rounds side by side, no data-path exchange).  auto: "
+                         "address from 8 GPUs up, where every GPU spreads its all-to-all over 7 xGMI links; ranges below, where one or "
+                         "three links would carry 16 B per k-mer (DESIGN.md section 5)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -215,6 +218,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.decomposition == "auto":
+        args.decomposition = "address" if (world >= 8 and world & (world - 1) == 0) else "ranges"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("TPC_FORCE_DIST"):  # TPC_FORCE_DIST: exercise the distributed path with one rank
         from twopaco_amd import dist as tdist
@@ -238,8 +243,9 @@ def main():
 
     for _ in range(args.warmup):
         one_step(ctx)
-    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit"]
+    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "fused"]
     kms = {n: 0.0 for n in names}
+    fused0 = ctx.stat("fused_lookups")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -249,6 +255,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms = {n: v / args.steps for n, v in kms.items()}
+    fused = ctx.stat("fused_lookups") - fused0 == args.steps  # deferred apply: the query's lookup built the filter slices
     result = {"candidate_marks": marks, "junctions": J, "junction_occurrences": n_valid, **st}
     result_ok = None
     if golden:  # the reference's own counters for this workload (VE.h:384-388), tests/golden/cases.json
@@ -269,7 +276,13 @@ def main():
     filter_bytes = (1 << p["L"]) // 8
     ins_addr, qry_addr = q * n_kmers, 6 * n_kmers
     design_ins = 0.375 * n_kmers + ins_addr * 4 * 4 + filter_bytes          # W l1, R+W l2, R apply; filter written once
-    design_qry = 0.375 * n_kmers + qry_addr * 8 * 4 + filter_bytes          # uint64 entries; filter read once
+    design_qry = 0.375 * n_kmers + qry_addr * 8 * 4 + (0 if fused else filter_bytes)  # uint64 entries; filter read once unless fused
+    # With the apply deferred into the query's lookup kernel ("fused" = k_q_split + k_apply_lookup, timed inside "query"),
+    # the insert's share of that group is what its apply has to move: its level-2 entries in, the filter out.
+    ins_ms, qry_ms = kms["insert"], kms["query"]
+    if fused:
+        share = (ins_addr * 4 + filter_bytes) / (ins_addr * 4 + filter_bytes + qry_addr * 8 * 3)
+        ins_ms, qry_ms = kms["insert"] + share * kms["fused"], kms["query"] - share * kms["fused"]
     traffic_ins = traffic_qry = None
     pmc_tag = None
     pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
@@ -298,18 +311,20 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d, 1 round"
                                % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
-                   "kmers": n_kmers, "filter_bytes": filter_bytes, "insert_test_first": args.test_first, "decomposition": "single GPU"},
+                   "kmers": n_kmers, "filter_bytes": filter_bytes, "insert_test_first": args.test_first, "decomposition": "single GPU",
+                   "apply_fused_into_lookup": fused},
         "junction_occurrences_per_sec": n_valid * args.steps / dt,
-        "insert_kmers_per_sec": n_kmers / (kms["insert"] * 1e-3),
-        "query_kmers_per_sec": n_kmers / (kms["query"] * 1e-3),
+        "insert_kmers_per_sec": n_kmers / (ins_ms * 1e-3),
+        "query_kmers_per_sec": n_kmers / (qry_ms * 1e-3),
         "kernel_ms": kms,
+        "insert_ms_with_its_share_of_fused": ins_ms, "query_ms_without_it": qry_ms,
         "result": result,
         "result_equals_reference_golden": result_ok,
         "upload_s_pcie": upload_s,
         # the dominant kernel group of a step is the first-pass query (k_q_hash + k_q_split + k_q_lookup + k_q_verify)
-        "roofline": roof("first-pass query (k_q_hash, k_q_split, k_q_lookup, k_q_verify)", kms["query"], design_qry, traffic_qry, 0.375 + 6 * G_BYTES),
+        "roofline": roof("first-pass query (k_q_hash, k_q_split, k_q_lookup / its share of k_apply_lookup, k_q_verify)", qry_ms, design_qry, traffic_qry, 0.375 + 6 * G_BYTES),
         # the north star's roofline kernel: first-pass Bloom insert
-        "roofline_insert": roof("first-pass insert (k_part_hash, k_part_split, k_part_apply)", kms["insert"], design_ins, traffic_ins, 0.25 + q * 2 * G_BYTES),
+        "roofline_insert": roof("first-pass insert (k_part_hash, k_part_split, k_part_apply / its share of k_apply_lookup)", ins_ms, design_ins, traffic_ins, 0.25 + q * 2 * G_BYTES),
     }
     tmp = tempfile.mkdtemp(prefix="tpc_bench_")
     try:

@@ -53,7 +53,8 @@ enum {
     TPC_K_SHARD_HASH = 9,   /* tpc_shard_hash: level 1 of a sharded pass                       */
     TPC_K_SHARD_APPLY = 10, /* tpc_shard_apply: levels 2-3 of a sharded pass                   */
     TPC_K_STREAM = 11,      /* tpc_emit_stream: FlushEdgeResults + JunctionPositionWriter bytes  */
-    TPC_K_COUNT = 12
+    TPC_K_FUSED = 12,       /* deferred apply: k_q_split + k_apply_lookup (inside TPC_K_QUERY), or the apply alone when it was flushed */
+    TPC_K_COUNT = 13
 };
 
 /* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:
@@ -244,13 +245,16 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *   insert_mode / query_mode   0 = automatic, 1 = direct scattered kernel, 2 = LDS write-combining passes
  *   slice_bits         log2 bits of a filter slice held in LDS (6..20, default 20)
  *   part_levels        0 = automatic (three binning levels when L - slice_bits > 18), 2, 3
+ *   fuse_apply_lookup  1 (default): when the insert and the query of a round both fit one tile batch, the insert stops after its
+ *                      level-2 binning and the query's lookup kernel builds each filter slice itself (the filter is written once,
+ *                      never read back); TPC_K_INSERT then covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
  *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 45 % of the free device
  *                      memory when that is more); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
- * with the full-size table by the last tpc_pass2_filter; "round_marks" = candidate marks of the round the last
+ * with the full-size table by the last tpc_pass2_filter; "fused_lookups" = queries that built the filter slices themselves (deferred apply); "round_marks" = candidate marks of the round the last
  * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does).
  * -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);

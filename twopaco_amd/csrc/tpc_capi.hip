@@ -77,6 +77,17 @@ struct tpc_ctx {
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = 0;  // bytes of partition buffers per batch; 0 = automatic (part_budget())
     int opt_query_mode = 0;    // 0 auto, 1 direct loads, 2 partitioned
+    // deferred apply (insert and query of a round both in one tile batch): the insert stops after its level-2 binning and the
+    // query's lookup kernel builds every filter slice itself (k_apply_lookup), so the filter is written once and never read back
+    int opt_fuse = 1;
+    bool pending_apply = false;   // the filter in HBM does not hold the last insert yet
+    bool pending_fresh = false;
+    TpcPartPlan pending_pl;
+    void *ikeep[2] = {nullptr, nullptr};  // the insert's level-2 regions and counts while an apply is pending
+    size_t ikeep_bytes[2] = {0, 0};
+    uint64_t *ikeep_ovf = nullptr;        // ... and its (few) overflow entries: the query reuses the overflow list
+    uint32_t pending_novf = 0;
+    int64_t stat_fused = 0;
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
     TpcPartPlan sh_ipl;
@@ -152,12 +163,30 @@ int read_counter(tpc_ctx *c, int i, uint64_t *out)
     return 0;
 }
 
+int flush_pending_apply(tpc_ctx *c);
+
 int materialize_reset(tpc_ctx *c)
 {   // a pending tpc_filter_reset becomes a real zero fill before anything reads the filter
+    { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }
     if (!c->filter_zero_pending) return 0;
     Timed t(c, TPC_K_FILTER_RESET);
     HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
     c->filter_zero_pending = false;
+    return 0;
+}
+
+int flush_pending_apply(tpc_ctx *c)
+{   // the deferred apply of the last insert, for anything that reads or extends the filter other than the fused lookup
+    if (!c->pending_apply) return 0;
+    c->pending_apply = false;
+    Timed t(c, TPC_K_FUSED);
+    // the insert's overflow entries were set aside (the list buffer is shared with the query): put them back for k_part_ovf
+    const unsigned long long cur[2] = {c->pending_novf, 0};
+    if (c->pending_novf) HIPCHK(c, hipMemcpyAsync(c->pending_pl.ovf, c->ikeep_ovf, c->pending_novf * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pending_pl.ovf_cur, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `cur` is on this stack frame
+    if (tpc_launch_insert_part_apply_only(make_launch(c), c->pending_pl, c->pending_fresh)) return fail(c, -1, "apply launch failed");
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 
@@ -271,6 +300,8 @@ void tpc_ctx_destroy(tpc_ctx *c)
                      c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
+    for (void *p : c->ikeep) if (p) (void)hipFree(p);
+    if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -288,6 +319,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "part_budget_bytes")) { c->opt_part_budget = value; return 0; }
     if (!strcmp(name, "part_levels")) { c->opt_part_levels = (int)value; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
+    if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -320,6 +352,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "insert_batches")) return c->stat_batches[0];
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
+    if (!strcmp(name, "fused_lookups")) return c->stat_fused;
     if (!strcmp(name, "round_marks")) return c->marks_valid ? (int64_t)c->n_marks : -1;  // set bits of the round mask (after tpc_pass2_filter)
     return -1;
 }
@@ -354,6 +387,7 @@ int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
         c->filter_words = fw;
     }
     c->have_params = true;
+    c->pending_apply = false;
     c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
     return 0;
 }
@@ -387,6 +421,7 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     if (n_text & 31) nm[nw - 1] |= ~0u << (n_text & 31);
     HIPCHK(c, hipMemcpyAsync(c->nmask, nm.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending_apply = false;
     c->n_text = n_text; c->n_words = (n_text >> 5) + 1; c->n_words_alloc = alloc; c->n_tiles = tiles;
     c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
     return 0;
@@ -406,6 +441,7 @@ int tpc_filter_reset(tpc_ctx *c)
     // Lazy: the partitioned insert writes every slice of the filter itself, so the zero fill is
     // only materialised (hipMemsetAsync, timed as TPC_K_FILTER_RESET) when something else needs it.
     c->filter_zero_pending = true;
+    c->pending_apply = false;  // an insert nobody looked at is forgotten with the filter
     c->ev_used[TPC_K_FILTER_RESET] = false;
     return 0;
 }
@@ -416,12 +452,14 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
     TpcPartPlan pl;
     const double m_ins = gated ? range_mass(c, lo, hi) : 1.0;
     const double ins_frac = gated ? std::min(1.0, (1.0 - (1.0 - m_ins) * (1.0 - m_ins)) * 1.15) : 1.0;  // either endpoint in range
     const uint64_t tiles = text_tiles512(c);
     uint64_t batches = 1;
+    bool defer = false;
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
     if (c->P.q > 8) part = false;  // the partitioned kernels are instantiated for q <= 8
     if (part) {
@@ -447,11 +485,26 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         const bool qpart = plan_query(c, lo, hi, gated, qpl);
         for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
+        // deferred apply: both passes of the round in one batch with the same slice geometry, and room for the insert's level-2
+        // regions beside the query's buffers
+        defer = part && c->opt_fuse && batches == 1 && qpart && pl.b3 == 0 && qpl.b3 == 0 && qpl.n_tiles >= tiles && qpl.slice_bits == pl.slice_bits &&
+                qpl.b1 == pl.b1 && qpl.b2 == pl.b2;
+        if (defer) {
+            const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
+            for (int i = 0; i < 2 && defer; i++) {
+                if (want[i] <= c->ikeep_bytes[i]) continue;
+                if (c->ikeep[i]) (void)hipFree(c->ikeep[i]);
+                c->ikeep[i] = nullptr; c->ikeep_bytes[i] = 0;
+                if (hipMalloc(&c->ikeep[i], want[i]) != hipSuccess) { (void)hipGetLastError(); defer = false; break; }
+                c->ikeep_bytes[i] = want[i];
+            }
+        }
     }
     if (part) {
         pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
         pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
+        if (defer) { pl.buf2 = (uint32_t *)c->ikeep[0]; pl.cnt2 = (uint32_t *)c->ikeep[1]; }
         bool fresh = c->filter_zero_pending;
         unsigned long long ov[2] = {0, 0};
         bool overflowed = false;
@@ -465,6 +518,20 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                 pl.tile0 = t0;
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 2 * sizeof(unsigned long long), c->stream));
+                if (defer) {  // levels 1 and 2 only; whether the apply can wait is known once the overflow count is back
+                    TpcPartPlan p1 = pl;
+                    p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
+                    if (tpc_launch_insert_part_hash(make_launch(c), p1, lo, hi, gated, n_kmers ? c->counters : nullptr) ||
+                        tpc_launch_insert_part_split(make_launch(c), p1)) return fail(c, -1, "partitioned insert launch failed");
+                    HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    if (ov[0] <= TPC_FUSE_MAX_OVF && ov[1] == 0) {
+                        if (!c->ikeep_ovf) HIPCHK(c, hipMalloc((void **)&c->ikeep_ovf, TPC_FUSE_MAX_OVF * sizeof(uint64_t)));
+                        if (ov[0]) HIPCHK(c, hipMemcpyAsync(c->ikeep_ovf, pl.ovf, ov[0] * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                        c->pending_apply = true; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = (uint32_t)ov[0];
+                    } else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
+                    break;
+                }
                 if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
                     return fail(c, -1, "partitioned insert launch failed");
                 fresh = false;  // later batches OR into the slices
@@ -506,6 +573,7 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t BINS = 1ull << 24;  // VE.h:471
     c->filter_zero_pending = false;  // the split pass zeroes its scratch filter itself
+    c->pending_apply = false;
     // positions where a (k+1)-mer of 'N'+record+'N' starts, for dispatched records only (VE.h:1177)
     std::vector<uint32_t> em(c->n_words_alloc, 0u);
     for (uint32_t r = 0; r < n_rec; r++) {
@@ -544,13 +612,16 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
-    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     c->marks_valid = false;
     TpcQPlan pl;
     const uint64_t tiles = text_tiles512(c);
     bool part = plan_query(c, lo, hi, gated, pl);
     if (part)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (tpc_qpart_bytes(pl, i)) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
+    // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
+    const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.n_tiles >= tiles && pl.slice_bits == c->pending_pl.slice_bits &&
+                       pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2;
+    if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     if (part) {
         pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
@@ -578,6 +649,18 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
                 HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+                if (fused) {
+                    TpcQPlan p1 = pl;
+                    p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
+                    c->pending_apply = false;
+                    c->stat_fused++;
+                    if (tpc_launch_query_part_hash(make_launch(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+                    {
+                        Timed tf(c, TPC_K_FUSED);
+                        if (tpc_launch_query_part_fused_lookup(make_launch(c), p1, c->pending_pl, c->pending_fresh, c->ikeep_ovf, c->pending_novf)) return fail(c, -1, "fused lookup launch failed");
+                    }
+                    if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");
+                } else
                 if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                 HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
@@ -1290,6 +1373,7 @@ int tpc_filter_upload(tpc_ctx *c, const uint32_t *words_host)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->filter, words_host, c->filter_words * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->filter_zero_pending = false;  // the uploaded bits are the filter now
+    c->pending_apply = false;
     return 0;
 }
 

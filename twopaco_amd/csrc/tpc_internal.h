@@ -93,6 +93,12 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPl
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
 bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0);
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
+// deferred apply: the insert stops after its level-2 binning (tpc_launch_insert_part_split), the query's lookup builds the slices itself
+int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl);   // level 2 (and 3) only
+int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh);  // k_part_apply + k_part_ovf
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, uint32_t n_iovf);
+#define TPC_FUSE_MAX_OVF 4096u  // insert overflow entries the fused kernel still folds in (every workgroup scans the list)  // k_q_split + k_apply_lookup + k_q_ovf
+int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
 // halves for the sharded path: hash (level 1, marks N-adjacent vertices in rmask), then split + lookup on
 // the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);

@@ -391,10 +391,10 @@ int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint6
     return -1;
 }
 
-int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh)
+int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl) { return launch_split(a, pl); }
+
+int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh)
 {
-    int rc;
-    if ((rc = launch_split(a, pl))) return rc;
     const size_t lds = (size_t)4 << (pl.slice_bits - 5);
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     (void)hipFuncSetAttribute((const void *)k_part_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -407,6 +407,13 @@ int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool
                            pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
     hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2);
     return 0;
+}
+
+int tpc_launch_insert_part_apply(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh)
+{
+    int rc;
+    if ((rc = launch_split(a, pl))) return rc;
+    return tpc_launch_insert_part_apply_only(a, pl, fresh);
 }
 
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl0, uint64_t lo, uint64_t hi, bool gated, bool fresh,

@@ -331,6 +331,115 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     flush();
 }
 
+// ------------------------------------------------------------------------------------------ C'
+// Fused k_part_apply + k_q_lookup (tpc_partition.hip: deferred apply).  When the insert and the query of a round both
+// fit one tile batch, the workgroup that builds a filter slice in LDS from the insert's level-2 entries writes it out
+// AND tests the query's entries of that slice on the spot: the 2^L / 8 bytes of the filter are not read back.
+__global__ void __launch_bounds__(PT_APPLY_THREADS)
+k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
+               const uint64_t *__restrict__ iovf, uint32_t n_iovf, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
+               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t words = 1u << (slice_bits - 5);
+    uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(slice + ((words + 3u) & ~3u));
+    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(stage + QL_STAGE);
+    const uint32_t nb2 = 1u << log_nb2;
+    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
+    uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
+    const bool wide = (words & 3u) == 0;
+    // ---- apply (k_part_apply)
+    if (fresh) {
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
+    } else {
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
+    }
+    if (threadIdx.x == 0) s_ctl[0] = 0;
+    __syncthreads();
+    for (uint32_t j = 0; j < iwpb; j++) {
+        const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
+        const uint32_t *src = ibuf2 + r * icap2;
+        const uint32_t n = icnt2[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 8 * PT_APPLY_THREADS) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
+                v[u] = i < n ? src[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (v[u] != 0xFFFFFFFFu) atomicOr(&slice[v[u] >> 5], 1u << (v[u] & 31u));
+        }
+    }
+    // the insert's few overflow entries (permuted addresses that found a ring or region full): every workgroup picks out its own
+    for (uint32_t i = threadIdx.x; i < n_iovf; i += PT_APPLY_THREADS) {
+        const uint64_t a = iovf[i];
+        if ((uint32_t)(a >> slice_bits) == blockIdx.x) atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+    }
+    __syncthreads();
+    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
+    // ---- lookup (k_q_lookup) against the slice still in LDS
+    const uint32_t slice_mask = (1u << slice_bits) - 1u;
+    const int list = blockIdx.x % QS_LISTS;
+    uint64_t *my_list = surv + (uint64_t)list * surv_cap;
+    auto flush = [&]() {  // all threads
+        __syncthreads();
+        const uint32_t m = min(s_ctl[0], (uint32_t)QL_STAGE);
+        if (m) {
+            if (threadIdx.x == 0) {
+                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
+                s_ctl[2] = (uint32_t)base; s_ctl[3] = (uint32_t)(base >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = (uint64_t)s_ctl[2] | ((uint64_t)s_ctl[3] << 32);
+            for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
+                if (base + i < surv_cap) my_list[base + i] = stage[i];
+                else surv_cur[QS_LISTS] = 1ull;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_ctl[0] = 0;
+        }
+        __syncthreads();
+    };
+    for (uint32_t j = 0; j < qwpb; j++) {
+        const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
+        const uint64_t *src = qbuf2 + qoff2[r];
+        const uint32_t n = qcnt2[r];
+        for (uint32_t i0 = 0; i0 < n; i0 += 4 * PT_APPLY_THREADS) {
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
+                v[u] = i < n ? src[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (v[u] != ~0ull) {
+                    const uint32_t a = (uint32_t)v[u] & slice_mask;
+                    if ((slice[a >> 5] >> (a & 31u)) & 1u) {
+                        const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
+                        if (slot < (uint32_t)QL_STAGE) stage[slot] = v[u] >> QE_E_SHIFT;
+                        else {
+                            const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
+                            if (o < surv_cap) my_list[o] = v[u] >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
+        __syncthreads();
+        if (staged > QL_STAGE / 2) flush();
+    }
+    flush();
+}
+
 // Region-overflow entries: first probe straight from the filter; hits join sub-list 0.
 __global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long long *cursor, uint64_t cap, const uint32_t *__restrict__ filter,
                         uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh, int log_nb2)
@@ -799,6 +908,47 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
                        sh, pl.b2);
+    return 0;
+}
+
+// Fused tail of the query when the insert's apply was deferred (see tpc_capi.hip:flush_pending_apply): level-2 binning of
+// the query, then k_apply_lookup over the insert's and the query's level-2 regions, then the overflow probes.
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, uint32_t n_iovf)
+{
+    if (pl.b3 || ipl.b3 || pl.world != 1 || ipl.world != 1 || pl.slice_bits != ipl.slice_bits || pl.b1 != ipl.b1 || pl.b2 != ipl.b2) return -1;
+    const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
+    const PtShard sh{0, 1};
+    QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
+    {
+        const size_t lds = Bins<uint64_t, QS_THREADS>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
+        (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits,
+                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
+    }
+    {
+        const size_t words = (size_t)1 << (pl.slice_bits - 5);
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
+        (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_apply_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
+                           ipl.cap2, fresh ? 1 : 0, iovf, n_iovf, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+    }
+    hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
+    return 0;
+}
+
+int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
+{
+    switch (a.P.q) {
+    case 1: launch_qverify<1>(a, pl, rmask); break;
+    case 2: launch_qverify<2>(a, pl, rmask); break;
+    case 3: launch_qverify<3>(a, pl, rmask); break;
+    case 4: launch_qverify<4>(a, pl, rmask); break;
+    case 5: launch_qverify<5>(a, pl, rmask); break;
+    case 6: launch_qverify<6>(a, pl, rmask); break;
+    case 7: launch_qverify<7>(a, pl, rmask); break;
+    case 8: launch_qverify<8>(a, pl, rmask); break;
+    default: return -1;
+    }
     return 0;
 }
 
