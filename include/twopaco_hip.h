@@ -175,7 +175,8 @@ void tpc_host_free(void *ptr);
  *                        [3] bytes of one destination block of the count buffer
  *                        [4] survivor capacity (entries)  [5] overflow capacity (entries)
  *                        [6] bytes per overflow entry  [7] slice_bits  [8] b1  [9] b2
- *                        [10] slice permutation multiplier  [11] its inverse
+ *                        [10] slice permutation multiplier  [11] its inverse  [12] b3 (0: two levels; filters beyond
+ *                        2^38 bits take a third level on the owner: the exchange stays at level 1)
  *                      send and receive buffers hold `world` blocks each
  *   tpc_shard_hash     level 1 of the pass over this rank's tiles of `batch` into send_regions /
  *                      send_counts (block d = entries for rank d); the query also marks the

@@ -19,7 +19,7 @@ CASES = {c["name"]: c for c in golden_cases()}
 def assemble(shards, geom, L, world):
     """Filter words of the whole filter from the per-rank shards: shard layout is [local bucket][b2][slice],
     rank r owns the level-1 buckets b1 = bl * world + r of the PERMUTED slice index."""
-    sb, b1, b2 = geom["slice_bits"], geom["b1"], geom["b2"]
+    sb, b1, b2 = geom["slice_bits"], geom["b1"], geom["b2"] + geom.get("b3", 0)  # the levels below the first are local to the owner
     F = b1 + b2
     words = 1 << (sb - 5)
     full = np.zeros(((1 << L) >> 5) + 1, dtype=np.uint32)
@@ -75,6 +75,24 @@ def test_address_sharded_golden_cases(name, slice_bits, world, tmp_path):
     for f in files:
         o.add_fasta(f)
     check(spec, o, run(spec, world, tmp_path), world)
+
+
+@pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("rand6_k25_q3", 12, 4), ("rand6_k9_L33", 20, 2), ("c2_k51_r2", 13, 4), ("c2_k125", 12, 2)])
+def test_address_sharded_three_levels(name, slice_bits, world, tmp_path):
+    """The three-level geometry (filters beyond 2^38 bits: f = 39 / 40, config 5) under sharding, forced on small filters:
+    level 1 is exchanged, levels 2 and 3 run on the owner.  Shards reassemble to the oracle's filter, masks and ids as above."""
+    case = CASES[name]
+    files = case_files(case, tmp_path)
+    ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+    spec = {"files": files, "k": case["k"], "L": case["L"], "q": case["q"], "seed": case["seed"], "ranges": ranges,
+            "abundance": case["abundance"] if case["abundance"] is not None else (1 << 64) - 1,
+            "options": {"slice_bits": slice_bits, "part_levels": 3}}
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in files:
+        o.add_fasta(f)
+    gathered = run(spec, world, tmp_path)
+    assert gathered[0]["rounds"][0]["geom"]["b3"] > 0 and gathered[0]["rounds"][0]["qgeom"]["b3"] > 0
+    check(spec, o, gathered, world)
 
 
 @pytest.mark.parametrize("world,budget", [(2, 40 << 30), (4, 3 << 20)])

@@ -417,6 +417,22 @@ def test_f38_geometry_bytes_equal_reference(capi, tmp_path):
     ctx.close()
 
 
+def test_config4_shape_m3_f38_bytes_equal_reference(capi, tmp_path):
+    """BASELINE.json configs[3]'s shape: 7 genomes x 160 Mbp (1.12 G positions, more than one 2^30-position query batch can
+    address), k=25, f=38 (32 GiB filter, 512 bins per level).  Insert and query run in several tile batches under the CLI's
+    20 GiB buffer budget; sha256 of de_bruijn.bin and every counter equal the real reference's (tests/golden/make_golden.py)."""
+    case = [c for c in CASES if c["name"] == "m3_f38"][0]
+    out = str(tmp_path / "m3.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], threads=32)
+    assert os.path.getsize(out) == case["bin_bytes"]
+    assert sha256_file(out) == case["bin_sha256"]
+    log = parse_log(e.log)
+    assert log["rounds"] == case["rounds"] and log["true_marks"] == case["true_marks"]
+    assert e.vertices_count() == case["distinct"]
+    e.close()
+
+
 def test_naive_positions_seed_free(capi, tmp_path):
     """Random seeds (like the reference's own --test, test.cpp:163-254): positions == naive oracle."""
     fa = os.path.join(GOLDEN, "rand6.fa")

@@ -371,7 +371,7 @@ class Context:
         g = np.zeros(16, dtype=np.uint64)
         self._ck(hip().tpc_shard_plan(self._h, which, lo, (1 << self.L) if hi is None else hi, g.ctypes.data))
         names = ["batches", "tiles_per_rank", "region_block_bytes", "count_block_bytes", "survivor_cap", "overflow_cap", "overflow_entry_bytes",
-                 "slice_bits", "b1", "b2", "perm_mult", "perm_inv"]
+                 "slice_bits", "b1", "b2", "perm_mult", "perm_inv", "b3"]
         return {n: int(g[i]) for i, n in enumerate(names)}
 
     def shard_hash(self, which, batch, send_regions_ptr, send_counts_ptr, lo=0, hi=None):

@@ -1065,27 +1065,34 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         TpcPartPlan &pl = c->sh_ipl;
         for (uint64_t batches = 1;; batches *= 2) {
             per = (per_total + batches - 1) / batches;
-            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->sh_world > 1 ? 2 : c->opt_part_levels))
+            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->opt_part_levels))
                 return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
-            if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles) break;
+            if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles) break;
         }
         const size_t need[6] = { 0, 0, tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl), pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
         for (int i = 2; i < 6; i++) if (!ensure_pbuf(c, i, need[i])) return fail(c, -10, "out of device memory for the partition buffers");
+        if (pl.b3 && (!ensure_pbuf(c, 9, tpc_part_buf3_bytes(pl)) || !ensure_pbuf(c, 10, tpc_part_cnt3_bytes(pl)))) return fail(c, -10, "out of device memory for the partition buffers");
         pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
         geom[2] = tpc_part_buf1_bytes(pl) / W; geom[3] = tpc_part_cnt1_bytes(pl) / W;
         geom[4] = 0; geom[5] = pl.ovf_cap; geom[6] = 8;
-        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv;
+        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv; geom[12] = pl.b3;
     } else {
         TpcQPlan &pl = c->sh_qpl;
         for (uint64_t batches = 1;; batches *= 2) {
             per = (per_total + batches - 1) / batches;
             const bool fits = per * W * (uint64_t)(512 * TPC_RUN) <= (1ull << 30);  // survivor ids hold a 30-bit position relative to the batch
-            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, 2);
+            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, c->opt_part_levels);
             if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
-            if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
+            if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");
         }
-        for (int i = 2; i < 9; i++) if (!ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");
+        for (int i = 2; i < 12; i++) if (tpc_qpart_bytes(pl, i) && !ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");
+        pl.buf3 = (uint64_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];
+        if (pl.b3 && c->off3_uploaded != pl.off3_host) {
+            HIPCHK(c, hipMemcpy(c->pbuf[11], pl.off3_host.data(), pl.off3_host.size() * 8, hipMemcpyHostToDevice));
+            c->off3_uploaded = pl.off3_host;
+        }
         pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
         pl.surv = (uint64_t *)c->pbuf[6]; pl.surv_cur = (unsigned long long *)c->pbuf[7]; pl.off2 = (const uint64_t *)c->pbuf[8];
         if (c->off2_uploaded != pl.off2_host) {
@@ -1094,14 +1101,14 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         }
         geom[2] = tpc_qpart_bytes(pl, 0) / W; geom[3] = tpc_qpart_bytes(pl, 1) / W;
         geom[4] = 64 * pl.surv_cap; geom[5] = pl.ovf_cap; geom[6] = 16;
-        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv;
+        geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv; geom[12] = pl.b3;
     }
     c->sh_per[pass] = per;
     c->sh_batches[pass] = (tiles + W * per - 1) / (W * per);
     c->sh_have[pass] = true;
     c->sh_have[1 - pass] = false;  // the two passes share the partition buffers
     geom[0] = c->sh_batches[pass]; geom[1] = per;
-    for (int i = 12; i < 16; i++) geom[i] = 0;
+    for (int i = 13; i < 16; i++) geom[i] = 0;
     return 0;
 }
 

@@ -151,7 +151,9 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     bins.carve(smem, LOG_NB2);
     bins.init();
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
-    const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
+    // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
+    const uint32_t b1 = prev_wpb ? (sh.world > 1 ? ((((bl >> log_prev_nb2) * sh.world + sh.rank) << log_prev_nb2) | (bl & ((1u << log_prev_nb2) - 1u))) : bl)
+                                 : (SHARDED ? bl * sh.world + sh.rank : bl);
     const uint32_t nvw = prev_wpb ? prev_wpb : SHARDED ? nwg1 * sh.world : nwg1;  // source regions: (source rank, workgroup)
     auto r1 = [=](uint32_t vw) {
         if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
@@ -301,7 +303,7 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
         hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
                            pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, split_loads(pl.b2));
     if (pl.b3)  // third level: bucket (b1, b2), input = the regions written above
-        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
+        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
                            pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, split_loads(pl.b3));
     return 0;
 }
@@ -327,7 +329,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // level-1 entries are the L - b1 low address bits in a uint32 below the 0xFFFFFFFF sentinel
     const bool three = levels == 3 || (levels == 0 && F > 18);
     if (three) {
-        if (F < 3 || world > 1) return false;  // the sharded path exchanges two-level regions only
+        if (F < 3) return false;
         pl.b1 = std::max((F + 2) / 3, L - 31);
         pl.b2 = (F - pl.b1 + 1) / 2;
         pl.b3 = F - pl.b1 - pl.b2;
@@ -361,7 +363,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     pl.wpb3 = 1;
-    const double avg3 = a_max / ((double)(1ull << F) * pl.wpb3);
+    const double avg3 = a_max * world / ((double)(1ull << F) * pl.wpb3);
     pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
     const PtPerm pm = pt_make_perm(slice_bits, F);
@@ -373,8 +375,8 @@ size_t tpc_part_buf1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * 4; }
 size_t tpc_part_buf2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 4; }
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * 4; }
-size_t tpc_part_buf3_bytes(const TpcPartPlan &pl) { return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * pl.cap3 * 4 : 0; }
-size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * 4 : 0; }
+size_t tpc_part_buf3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * pl.cap3 * 4 : 0; }
+size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * 4 : 0; }
 
 int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
 {
@@ -400,12 +402,12 @@ int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl,
     (void)hipFuncSetAttribute((const void *)k_part_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const PtShard sh{pl.rank, pl.world};
     if (pl.b3)  // regions of the third level: [(b1, b2)][j][b3]
-        hipLaunchKernelGGL(k_part_apply, dim3(1u << (pl.b1 + pl.b2 + pl.b3)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+        hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
                            pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh);
     else
         hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
                            pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
-    hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2);
+    hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2 + pl.b3);
     return 0;
 }
 

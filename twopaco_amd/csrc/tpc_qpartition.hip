@@ -203,7 +203,9 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     bins.init();
     for (uint32_t i = threadIdx.x; i <= NB2; i += QS_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
-    const uint32_t b1 = SHARDED ? bl * sh.world + sh.rank : bl;   // global bucket
+    // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
+    const uint32_t b1 = prev_wpb ? (sh.world > 1 ? ((((bl >> log_prev_nb2) * sh.world + sh.rank) << log_prev_nb2) | (bl & ((1u << log_prev_nb2) - 1u))) : bl)
+                                 : (SHARDED ? bl * sh.world + sh.rank : bl);
     const uint32_t nvw = prev_wpb ? prev_wpb : SHARDED ? nwg1 * sh.world : nwg1;  // source regions: (source rank, workgroup)
     auto r1 = [=](uint32_t vw) {
         if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
@@ -762,7 +764,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     pl.slice_bits = slice_bits;
     const bool three = levels == 3 || (levels == 0 && F > 18);  // as in tpc_part_plan_sharded
     if (three) {
-        if (F < 3 || world > 1) return false;
+        if (F < 3) return false;
         pl.b1 = std::max((F + 2) / 3, L - 31);
         pl.b2 = (F - pl.b1 + 1) / 2;
         pl.b3 = F - pl.b1 - pl.b2;
@@ -806,12 +808,14 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     // address whose density over the slices falls linearly from 2x to 0 (tpc_bins.h).  With three levels the
     // middle regions each collect 2^b3 slices spread over the whole filter by the permutation: uniform.
     const double S = (double)(1ull << F);
-    auto slice_table = [&](std::vector<uint64_t> &off, uint64_t nreg, int log_last, uint32_t wpb_last, double avg) {
+    // log_mid: bits of the bucket index that sit below the rank-interleaved level-1 bits (0 for the two-level table, b2 for the third level)
+    auto slice_table = [&](std::vector<uint64_t> &off, uint64_t nreg, int log_last, uint32_t wpb_last, double avg, int log_mid) {
         off.resize(nreg + 1);
         uint64_t o = 0;
         for (uint64_t r = 0; r < nreg; r++) {
             const uint32_t bl = (uint32_t)(r / ((uint64_t)wpb_last << log_last)), bb = (uint32_t)(r & ((1u << log_last) - 1));
-            const uint32_t s = pm.slice_of(((world > 1 ? bl * world + rank : bl) << log_last) | bb);  // the filter slice behind this region
+            const uint32_t gb = world > 1 ? ((((bl >> log_mid) * world + rank) << log_mid) | (bl & ((1u << log_mid) - 1u))) : bl;  // global bucket
+            const uint32_t s = pm.slice_of((gb << log_last) | bb);  // the filter slice behind this region
             const double d = avg * 2.0 * (1.0 - ((double)s + 0.5) / S) + avg * 0.02;
             off[r] = o;
             o += ((uint64_t)(d * 1.25 + 8 * std::sqrt(d) + 96) + 15) & ~15ull;
@@ -828,12 +832,12 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         pl.off2_host.resize(nreg2 + 1);
         for (uint64_t r = 0; r <= nreg2; r++) pl.off2_host[r] = r * pl.cap2;
         pl.buf2_entries = nreg2 * pl.cap2;
-        const uint64_t nreg3 = (uint64_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3);
-        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_max / (double)nreg3);
+        const uint64_t nreg3 = ((uint64_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / world;  // local regions
+        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_max / (double)nreg3, pl.b2);
         pl.loads3 = loads_for(pl.b3);
     } else {
         pl.cap2 = 0;
-        pl.buf2_entries = slice_table(pl.off2_host, nreg2, pl.b2, pl.wpb, avg2);
+        pl.buf2_entries = slice_table(pl.off2_host, nreg2, pl.b2, pl.wpb, avg2, 0);
         pl.off3_host.clear();
         pl.buf3_entries = 0;
     }
@@ -853,7 +857,7 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     case 7: return (QS_LISTS + 1) * sizeof(unsigned long long);
     case 8: return pl.off2_host.size() * 8;
     case 9: return (size_t)pl.buf3_entries * 8;
-    case 10: return pl.b3 ? ((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) * 4 : 0;
+    case 10: return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * 4 : 0;
     case 11: return pl.off3_host.size() * 8;
     }
     return 0;
@@ -892,7 +896,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
             hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
                                pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
         if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
-            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)((1u << (pl.b1 + pl.b2)) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
+            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
                                a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2);
     }
     {
@@ -900,14 +904,14 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (pl.b3)
-            hipLaunchKernelGGL(k_q_lookup, dim3(1u << (pl.b1 + pl.b2 + pl.b3)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+            hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
                                pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
         else
             hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
                                pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
-                       sh, pl.b2);
+                       sh, pl.b2 + pl.b3);
     return 0;
 }
 
@@ -985,7 +989,7 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
     const PtShard sh{pl.rank, pl.world};
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
-#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2, fn, fn_count, addr_out, owner_out)
+#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out)
     switch (a.P.q) {
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;
