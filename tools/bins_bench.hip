@@ -55,6 +55,11 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
         bins.carve(smem, LOG_NB);
         bins.init();
         __syncthreads();
+        if (filler < 0) {  // stagger the workgroups: phase * D
+            const unsigned long long t0 = wall_clock64(), d = (unsigned long long)(blockIdx.x % 4) * (unsigned long long)(-filler);
+            while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+            filler = 0;
+        }
         for (int s0 = 0; s0 < steps; s0 += ppr) {
             for (int s = s0; s < min(steps, s0 + ppr); s++) {
                 uint32_t b[N];
@@ -75,6 +80,7 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
         }
         bins.flush(true, reg, lost);
         bins.store_counts(cnt + (uint64_t)wg * NB, reg, [](uint32_t b) { return b; });
+        bins.dump(sums + 8);
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
@@ -108,14 +114,14 @@ int run(const char *name, int log_nb, int steps, int ppr, int filler)
     unsigned long long *sums;
     CK(hipMalloc(&buf, (size_t)nwg * NB * cap * sizeof(T)));
     CK(hipMalloc(&cnt, (size_t)nwg * NB * 4));
-    CK(hipMalloc(&sums, 64));
+    CK(hipMalloc(&sums, 256));
     const size_t lds = V2 ? RBins<T, THREADS>::lds_bytes(log_nb) : Bins<T, THREADS>::lds_bytes(log_nb);
     CK(hipFuncSetAttribute((const void *)k_bins<T, N, V2, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
-        CK(hipMemset(sums, 0, 64));
+        CK(hipMemset(sums, 0, 256));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((k_bins<T, N, V2, THREADS>), dim3(nwg), dim3(THREADS), lds, 0, log_nb, steps, ppr, filler, buf, cnt, cap, sums);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -123,8 +129,11 @@ int run(const char *name, int log_nb, int steps, int ppr, int filler)
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
     hipLaunchKernelGGL((k_check<T>), dim3(nwg * NB), dim3(256), 0, 0, buf, cnt, cap, NB, sums);
-    unsigned long long h[8];
-    CK(hipMemcpy(h, sums, 64, hipMemcpyDeviceToHost));
+    unsigned long long h[32];
+    CK(hipMemcpy(h, sums, 256, hipMemcpyDeviceToHost));
+#ifdef TPC_PROFILE_PHASES
+    if (!V2) printf("    phases (wall_clock ticks summed over WGs): push %llu  bookkeeping %llu  copy %llu  rounds %llu\n", h[8], h[9], h[10], h[12]);
+#endif
     const double n = (double)nwg * THREADS * steps * N;
     printf("%-28s NB %3d N %d filler %2d: %8.3f ms %8.1f G entries/s %6.2f TB/s written   %s (entries %.0f, found %llu, lost %llu)\n", name, NB, N, filler, ms,
            n / ms / 1e6, n * sizeof(T) / ms / 1e9, (h[0] == h[1] && h[4] + h[2] == (unsigned long long)n && h[2] == 0) ? "OK" : "MISMATCH", n, h[4], h[2]);
@@ -140,6 +149,10 @@ int main()
         run<uint64_t, 6, true>("RBins u64 (barrier-free)", 8, 1184, 1, filler);
         run<uint32_t, 5, false>("Bins  u32 (flush/3 steps)", 8, 1184, 3, filler);
         run<uint32_t, 5, true>("RBins u32 (barrier-free)", 8, 1184, 3, filler);
+    }
+    for (int d : {30, 60, 110, 200}) {
+        run<uint64_t, 6, false>("Bins  u64 staggered x4", 8, 1184, 1, -d);
+        run<uint32_t, 5, false>("Bins  u32 staggered x4", 8, 1184, 3, -d);
     }
     run<uint64_t, 4, false>("Bins  u64 split-like", 8, 1776, 1, 0);
     run<uint64_t, 4, true>("RBins u64 split-like", 8, 1776, 1, 0);

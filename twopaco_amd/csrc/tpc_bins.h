@@ -78,6 +78,15 @@ __host__ __device__ __forceinline__ uint64_t pt_local_addr(const PtPerm &perm, P
     return ((uint64_t)ls << perm.slice_bits) | (a_perm & smask);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)
+// before s_barrier): after a flush that is 48 KB of region lines per workgroup, ~2 us of HBM write latency per round and
+// almost half of a binning kernel's time (tools/bins_bench.hip phase profile).  Nothing in these kernels reads back what
+// a flush stored, so the barriers around the rings wait for the LDS operations alone.
+__device__ __forceinline__ void pt_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // exclusive scan over a THREADS-thread workgroup
 template <int THREADS>
 __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total)
@@ -89,7 +98,7 @@ __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w
         if (lane >= off) inc += t;
     }
     if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
+    pt_barrier_lds();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < THREADS / 64; i++) { const uint32_t x = s_w[i]; if (i < wv) base += x; tot += x; }
@@ -177,7 +186,7 @@ struct Bins {
     template <class Reg, class Lost>
     __device__ __forceinline__ void flush(bool final, Reg reg, Lost lost)
     {
-        __syncthreads();
+        pt_barrier_lds();
         tick(0);  // everything since the previous flush: loads + hashing + pushes
         const uint32_t tid = threadIdx.x;
         uint32_t n = 0, f = 0, h = 0;
@@ -186,26 +195,59 @@ struct Bins {
             n = min(tail[tid] - h, (uint32_t)CAP);  // entries beyond CAP were handed to lost() by push_batch
             f = final ? ((n + GROUP - 1u) & ~(uint32_t)(GROUP - 1)) : (n & ~(uint32_t)(GROUP - 1));
         }
-        uint32_t total;
+        uint32_t total;  // (one same-address LDS atomic per bin instead of this scan serialises: 3x slower bookkeeping)
         const uint32_t off = pt_block_excl_scan<THREADS>(f >> LOG_GROUP, scan, total);
         for (uint32_t g = 0; g < (f >> LOG_GROUP); g++) {
             const uint32_t left = n - g * GROUP;
             items[off + g] = make_uint2(tid | (((h + g * GROUP) & (uint32_t)(CAP - 1)) << 10) | (min(left, (uint32_t)GROUP) << 24), h + g * GROUP);
         }
         if (tid < (uint32_t)NB) { head[tid] = h + f; tail[tid] = h + (final ? f : n); }
-        __syncthreads();
+        pt_barrier_lds();
         tick(1);
-        const uint32_t l = tid & (GROUP - 1);
-        for (uint32_t w = tid >> LOG_GROUP; w < total; w += THREADS / GROUP) {
-            const uint2 it = items[w];
-            const uint32_t b = it.x & 1023u, idx0 = (it.x >> 10) & 16383u, valid = it.x >> 24;
-            const T val = l < valid ? data[(b << LOG_CAP) + idx0 + l] : SENT;
-            const uint64_t pos = (uint64_t)it.y + l;
-            const PtRegion<T> rg = reg(b);
-            if (pos < rg.cap) rg.base[pos] = val;
-            else if (val != SENT) lost(b, val);
+        // copy: 8 lanes per 128-byte group, 16 bytes per lane (ds_read_b128 -> global_store_dwordx4).  Narrow stores are
+        // issue bound: with one entry per lane this phase was 47 % of a binning kernel (tools/bins_bench.hip).
+        constexpr int EPL = 16 / (int)sizeof(T);   // entries per lane
+        constexpr int LPG = GROUP / EPL;           // lanes per group = 8
+        const uint32_t l = tid & (LPG - 1);
+        // four groups per lane in flight: all item reads, then all ring reads, then all stores (a dependent chain per group,
+        // taken one group at a time, left the LDS latency of every step exposed)
+        constexpr int UNR = 4;
+        for (uint32_t w0 = tid / LPG; w0 < total; w0 += UNR * (THREADS / LPG)) {
+            uint2 it[UNR];
+            union { uint4 q; T e[EPL]; } u[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; k++) {
+                const uint32_t w = w0 + k * (THREADS / LPG);
+                it[k] = w < total ? items[w] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; k++) {
+                const uint32_t b = it[k].x & 1023u, idx0 = (it[k].x >> 10) & 16383u;
+                u[k].q = *reinterpret_cast<const uint4 *>(&data[(b << LOG_CAP) + idx0 + l * EPL]);
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; k++) {
+                const uint32_t w = w0 + k * (THREADS / LPG);
+                if (w >= total) continue;
+                const uint32_t b = it[k].x & 1023u, valid = it[k].x >> 24;
+                if (valid < (uint32_t)GROUP) {  // the final flush pads a bin's last group
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) if (l * EPL + e >= valid) u[k].e[e] = SENT;
+                }
+                const uint64_t pos = (uint64_t)it[k].y + l * EPL;
+                const PtRegion<T> rg = reg(b);
+#ifdef TPC_BINS_NOSTORE  // experiment: everything but the HBM write
+                if (pos < rg.cap) { if (u[k].q.x == 0x12345678u && u[k].q.y == 0x9ABCDEF0u) *reinterpret_cast<uint4 *>(rg.base + pos) = u[k].q; }
+#else
+                if (pos < rg.cap) *reinterpret_cast<uint4 *>(rg.base + pos) = u[k].q;
+#endif
+                else {
+#pragma unroll
+                    for (int e = 0; e < EPL; e++) if (u[k].e[e] != SENT) lost(b, u[k].e[e]);
+                }
+            }
         }
-        __syncthreads();
+        pt_barrier_lds();
         tick(2);
 #ifdef TPC_PROFILE_PHASES
         prof[4]++;

@@ -217,26 +217,37 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     auto reg = [buf2, s_off](uint32_t b) { const uint64_t o = s_off[b]; return PtRegion<uint64_t>{buf2 + o, s_off[b + 1] - o}; };
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
     __syncthreads();
-    uint32_t w = j, base = 0;
-    uint32_t n = w < nvw ? cnt1[r1(w)] : 0;
-    while (w < nvw && n == 0) { w += wpb; n = w < nvw ? cnt1[r1(w)] : 0; }
-    uint64_t v[LOADS], vn[LOADS];
-    auto load = [&](uint64_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
-        const uint64_t *src = buf1 + r1(ww) * cap1;
+    // rounds of `loads` x QS_THREADS entries over the source regions; the loads of the next TWO rounds are in flight while a
+    // round is binned and flushed (one round ahead left ~32 KB per CU outstanding, short of what HBM latency needs)
+    struct Cursor { uint32_t w, base, n; };
+    auto first = [&](uint32_t w0) {
+        Cursor c{w0, 0u, 0u};
+        c.n = c.w < nvw ? cnt1[r1(c.w)] : 0;
+        while (c.w < nvw && c.n == 0) { c.w += wpb; c.n = c.w < nvw ? cnt1[r1(c.w)] : 0; }
+        return c;
+    };
+    auto next = [&](Cursor c) {
+        c.base += (uint32_t)loads * QS_THREADS;
+        if (c.base >= c.n) {
+            c.base = 0;
+            do { c.w += wpb; c.n = c.w < nvw ? cnt1[r1(c.w)] : 0; } while (c.w < nvw && c.n == 0);
+        }
+        return c;
+    };
+    auto load = [&](uint64_t (&dst)[LOADS], const Cursor &c) {
+        const uint64_t *src = buf1 + r1(c.w) * cap1;
 #pragma unroll
         for (int i = 0; i < LOADS; i++) {
-            const uint32_t idx = bb + i * QS_THREADS + threadIdx.x;
-            dst[i] = (i < loads && idx < nn) ? src[idx] : SENT;
+            const uint32_t idx = c.base + i * QS_THREADS + threadIdx.x;
+            dst[i] = (i < loads && idx < c.n) ? src[idx] : SENT;
         }
     };
-    if (w < nvw) load(v, w, base, n);
-    while (w < nvw) {
-        uint32_t w2 = w, base2 = base + (uint32_t)loads * QS_THREADS, n2 = n;
-        if (base2 >= n2) {
-            base2 = 0;
-            do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
-        }
-        if (w2 < nvw) load(vn, w2, base2, n2);
+    uint64_t v[LOADS], v1[LOADS], v2[LOADS];
+    Cursor c0 = first(j), c1 = c0, c2 = c0;
+    if (c0.w < nvw) { load(v, c0); c1 = next(c0); }
+    if (c0.w < nvw && c1.w < nvw) { load(v1, c1); c2 = next(c1); } else c2 = c1;
+    while (c0.w < nvw) {
+        if (c1.w < nvw && c2.w < nvw) load(v2, c2);
         {
             uint32_t bb[LOADS];
             bool ok[LOADS];
@@ -246,8 +257,9 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         }
         bins.flush(false, reg, lost);
 #pragma unroll
-        for (int i = 0; i < LOADS; i++) v[i] = vn[i];
-        w = w2; base = base2; n = n2;
+        for (int i = 0; i < LOADS; i++) { v[i] = v1[i]; v1[i] = v2[i]; }
+        c0 = c1; c1 = c2;
+        if (c1.w < nvw) c2 = next(c1);
     }
     bins.flush(true, reg, lost);
     bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
