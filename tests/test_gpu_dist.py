@@ -39,3 +39,24 @@ def test_bench_single_rank_over_rccl(decomposition):
     assert dist_line["result"]["junctions"] == single["result"]["junctions"] > 0
     assert dist_line["result"]["junction_occurrences"] == single["result"]["junction_occurrences"]
     assert dist_line["result"]["candidate_marks"] == single["result"]["candidate_marks"]
+
+
+def test_bench_address_path_full_size_over_rccl():
+    """The address decomposition at the bench's full size (62 x 5 Mbp, f=36) with one RCCL rank: the 8.6 GB and 19 GB exchange
+    buffers cross `_Comm` in 256 MiB messages (a single multi-GiB all_to_all_single arrived truncated here), and the counters
+    equal the real reference's (tests/golden m2_full)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    case = CASES["m2_full"]
+    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("TPC_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--decomposition", "address"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["backend"] == "rccl" and line["config"]["decomposition"] == "address"
+    r = case["rounds"][0]
+    assert line["result"] == {"candidate_marks": r["marks"], "junctions": case["distinct"], "junction_occurrences": case["true_marks"]}

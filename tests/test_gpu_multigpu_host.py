@@ -60,6 +60,18 @@ def test_rccl_transport_single_rank(capi, tmp_path):
     e.close()
 
 
+def test_rccl_transport_single_rank_full_size(capi, tmp_path):
+    """The bench workload (62 x 5 Mbp, f=36) through the sharded path over RCCL with one rank: 8.6 GB and 19 GB exchange
+    buffers cross the transport in 256 MiB messages; sha256 == the real reference's."""
+    case = CASES["m2_full"]
+    out = str(tmp_path / "m2rccl.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], tmpdir=str(tmp_path), out=out, seed=case["seed"],
+                        threads=16, gpus=1, force_sharded=True, rccl=True)
+    log = _check(case, e, out)
+    assert "RCCL" in e.log and log["rounds"] == case["rounds"]
+    e.close()
+
+
 def test_m1_full_four_emulated_ranks(capi, tmp_path):
     """BASELINE configs[1] at full size with the filter cut over four ranks: sha256 == the real reference's."""
     case = CASES["m1_full"]

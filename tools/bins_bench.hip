@@ -87,6 +87,77 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
     if (acc == 0x12345) sums[3] = 1;
 }
 
+template <class T> __global__ void k_check(const T *buf, const uint32_t *cnt, uint64_t cap, int NB, unsigned long long *sums);
+// two workgroups per CU: 512 threads, 64 KiB of rings, 64-byte flush granules
+template <class T, int N>
+__global__ void __launch_bounds__(512) k_bins_half(int LOG_NB, int steps, T *buf, uint32_t *cnt, uint64_t cap, unsigned long long *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    const uint32_t wg = blockIdx.x;
+    auto reg = [buf, cap, wg, NB](uint32_t b) { return PtRegion<T>{buf + ((uint64_t)wg * NB + b) * cap, cap}; };
+    unsigned long long *lostc = sums + 2;
+    auto lost = [lostc](uint32_t, T) { atomicAdd(lostc, 1ull); };
+    uint32_t rng = (blockIdx.x * 512 + threadIdx.x) * 2654435761u + 12345u;
+    unsigned long long sum = 0;
+    Bins<T, 512, 65536, 64> bins;
+    bins.carve(smem, LOG_NB);
+    bins.init();
+    __syncthreads();
+    for (int s = 0; s < steps; s++) {
+        uint32_t b[N];
+        T val[N];
+        bool ok[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint32_t r = lcg(rng);
+            b[i] = (r >> 8) & (uint32_t)(NB - 1);
+            val[i] = make_val<T>(r, (uint32_t)s);
+            ok[i] = true;
+            sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
+        }
+        bins.template push_batch<N>(b, val, ok, lost);
+        bins.flush(false, reg, lost);
+    }
+    bins.flush(true, reg, lost);
+    bins.store_counts(cnt + (uint64_t)wg * NB, reg, [](uint32_t b) { return b; });
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
+}
+
+template <class T, int N>
+int run_half(const char *name, int log_nb, int steps)
+{
+    const int nwg = 512, NB = 1 << log_nb;
+    const uint64_t per_bin = (uint64_t)steps * 512 * N / NB;
+    const uint64_t cap = ((uint64_t)(per_bin * 1.2) + 256 + 31) & ~31ull;
+    T *buf; uint32_t *cnt; unsigned long long *sums;
+    CK(hipMalloc(&buf, (size_t)nwg * NB * cap * sizeof(T)));
+    CK(hipMalloc(&cnt, (size_t)nwg * NB * 4));
+    CK(hipMalloc(&sums, 256));
+    const size_t lds = Bins<T, 512, 65536, 64>::lds_bytes(log_nb);
+    CK(hipFuncSetAttribute((const void *)k_bins_half<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemset(sums, 0, 256));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_bins_half<T, N>), dim3(nwg), dim3(512), lds, 0, log_nb, steps, buf, cnt, cap, sums);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    hipLaunchKernelGGL((k_check<T>), dim3(nwg * NB), dim3(256), 0, 0, buf, cnt, cap, NB, sums);
+    unsigned long long h[32];
+    CK(hipMemcpy(h, sums, 256, hipMemcpyDeviceToHost));
+    const double n = (double)nwg * 512 * steps * N;
+    printf("%-28s NB %3d N %d (2 WG/CU, lds %zu): %8.3f ms %8.1f G entries/s   (entries %.0f, found %llu, lost %llu) %s\n", name, NB, N, lds, ms, n / ms / 1e6, n, h[4], h[2],
+           h[4] + h[2] == (unsigned long long)n ? "count OK" : "COUNT MISMATCH");
+    CK(hipFree(buf)); CK(hipFree(cnt)); CK(hipFree(sums));
+    return 0;
+}
+
 template <class T>
 __global__ void k_check(const T *buf, const uint32_t *cnt, uint64_t cap, int NB, unsigned long long *sums)
 {   // one workgroup per region
@@ -143,6 +214,8 @@ int run(const char *name, int log_nb, int steps, int ppr, int filler)
 
 int main()
 {
+    run_half<uint64_t, 6>("Bins u64 half-size WGs", 8, 1184);
+    run_half<uint32_t, 5>("Bins u32 half-size WGs", 8, 1184);
     // M2: query 1.86 G uint64 entries (6 per position), insert 1.55 G uint32 entries (5 per position)
     for (int filler : {0, 40}) {
         run<uint64_t, 6, false>("Bins  u64 (flush/round)", 8, 1184, 1, filler);

@@ -113,11 +113,12 @@ struct PtRegion { T *base; uint64_t cap; };
 // workgroup, so every global write is a full aligned 128-byte line; the < GROUP leftovers simply stay
 // in the ring.  A flush is two short data-parallel phases: one bookkeeping thread per bin builds the
 // list of 128-byte groups (scan of the group counts), then GROUP lanes copy each group.
-template <class T, int THREADS = PT_THREADS>
+template <class T, int THREADS = PT_THREADS, int BIN_BYTES = PT_BIN_BYTES, int LINE = PT_LINE>
 struct Bins {
-    static constexpr int ENTRIES = PT_BIN_BYTES / (int)sizeof(T);
-    static constexpr int GROUP = PT_LINE / (int)sizeof(T);
-    static constexpr int LOG_GROUP = sizeof(T) == 4 ? 5 : 4;
+    static constexpr int ENTRIES = BIN_BYTES / (int)sizeof(T);
+    static constexpr int GROUP = LINE / (int)sizeof(T);
+    static constexpr int LOG_GROUP = (sizeof(T) == 4 ? 5 : 4) - (LINE == 64 ? 1 : 0);
+    static constexpr int LOG_ENTRIES = (BIN_BYTES == 131072 ? 17 : 16) - (sizeof(T) == 4 ? 2 : 3);
     static constexpr int MAX_ITEMS = ENTRIES / GROUP;
     static constexpr T SENT = (T)~(T)0;
     int NB, CAP, LOG_CAP;  // bins (<= PT_THREADS: one bookkeeping thread per bin), entries per bin
@@ -136,16 +137,16 @@ struct Bins {
     __device__ __forceinline__ void dump(unsigned long long *) {}
 #endif
 
-    static size_t lds_bytes(int log_nb) { return (size_t)PT_BIN_BYTES + ((size_t)8 << log_nb) + 16 + (size_t)MAX_ITEMS * 8 + 128 + 64; }
+    static size_t lds_bytes(int log_nb) { return (size_t)BIN_BYTES + ((size_t)8 << log_nb) + 16 + (size_t)MAX_ITEMS * 8 + 128 + 64; }
 
     // carve: data first (16-byte aligned), then the bookkeeping arrays; returns the first free byte
     __device__ __forceinline__ unsigned char *carve(unsigned char *p, int log_nb)
     {
         NB = 1 << log_nb;
-        LOG_CAP = (sizeof(T) == 4 ? 15 : 14) - log_nb;
+        LOG_CAP = LOG_ENTRIES - log_nb;
         CAP = 1 << LOG_CAP;
         data = reinterpret_cast<T *>(p);
-        items = reinterpret_cast<uint2 *>(p + PT_BIN_BYTES);
+        items = reinterpret_cast<uint2 *>(p + BIN_BYTES);
         tail = reinterpret_cast<uint32_t *>(items + MAX_ITEMS);
         head = tail + NB + 2;
         scan = head + NB + 2;

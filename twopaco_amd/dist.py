@@ -160,14 +160,37 @@ class _Comm:
     def _out(self, t):
         return t if self.direct else t.to(self.device)
 
+    CHUNK = 1 << 28  # bytes per peer and message: multi-GiB all_to_all_single calls arrived truncated under RCCL (zeros past a point)
+
     def a2a_equal(self, send):
-        """Block d of `send` goes to rank d; block s of the result came from rank s."""
+        """Block d of `send` goes to rank d; block s of the result came from rank s.  Over RCCL: grouped send/recv of at
+        most CHUNK bytes per peer (what a C++ host issues as ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd)."""
+        torch = self.torch
         self.sync()
-        s = self._in(send)
-        r = self.torch.empty_like(s)
-        self.dist.all_to_all_single(r, s)
         self.bytes_moved += send.numel() * send.element_size()
-        return self._out(r)
+        if not self.direct:
+            s = self._in(send)
+            r = torch.empty_like(s)
+            self.dist.all_to_all_single(r, s)
+            return self._out(r)
+        sb = send.contiguous().view(torch.uint8)
+        wide = sb.numel() % (8 * self.world) == 0   # 8-byte elements: byte-wise copy kernels are slow
+        sb = (sb.view(torch.int64) if wide else sb).view(self.world, -1)
+        recv = torch.empty_like(sb)
+        block, step = sb.shape[1], self.CHUNK // (8 if wide else 1)
+        for c0 in range(0, block, step):
+            c1 = min(block, c0 + step)
+            ops = []
+            for p in range(self.world):
+                if p == self.rank:
+                    recv[p, c0:c1].copy_(sb[p, c0:c1])
+                else:
+                    ops.append(self.dist.P2POp(self.dist.isend, sb[p, c0:c1], p))
+                    ops.append(self.dist.P2POp(self.dist.irecv, recv[p, c0:c1], p))
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+        return recv.view(-1).view(torch.uint8).view(send.dtype).view(send.shape)
 
     def a2a_var(self, send, counts):
         """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source)."""
@@ -183,11 +206,37 @@ class _Comm:
             rc = torch.empty(self.world, dtype=torch.int64)
             self.dist.all_to_all_single(rc, sc)
         rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in sc.tolist()]
-        s = self._in(send)
-        r = torch.empty(sum(rcl), dtype=send.dtype, device=s.device)
-        self.dist.all_to_all_single(r, s, output_split_sizes=rcl, input_split_sizes=scl)
         self.bytes_moved += send.numel() * send.element_size()
-        return self._out(r), rcl
+        if not self.direct:
+            s = self._in(send)
+            r = torch.empty(sum(rcl), dtype=send.dtype, device=s.device)
+            self.dist.all_to_all_single(r, s, output_split_sizes=rcl, input_split_sizes=scl)
+            return self._out(r), rcl
+        # RCCL: grouped send/recv, at most CHUNK bytes per peer and message
+        r = torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
+        step = max(1, self.CHUNK // send.element_size())
+        so, ro = [0], [0]
+        for p in range(self.world):
+            so.append(so[-1] + scl[p]); ro.append(ro[-1] + rcl[p])
+        if scl[self.rank] != rcl[self.rank]:
+            raise RuntimeError("a2a_var: a rank's own block must have one size")
+        if scl[self.rank]:
+            r[ro[self.rank]:ro[self.rank + 1]].copy_(send[so[self.rank]:so[self.rank + 1]])
+        for c0 in range(0, max(max(scl), max(rcl), 1), step):
+            ops = []
+            for p in range(self.world):
+                if p == self.rank:
+                    continue
+                a, b = min(c0, scl[p]), min(c0 + step, scl[p])
+                if b > a:
+                    ops.append(self.dist.P2POp(self.dist.isend, send[so[p] + a:so[p] + b], p))
+                a, b = min(c0, rcl[p]), min(c0 + step, rcl[p])
+                if b > a:
+                    ops.append(self.dist.P2POp(self.dist.irecv, r[ro[p] + a:ro[p] + b], p))
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+        return r, rcl
 
     def all_gather(self, t):
         """[world, *t.shape]"""

@@ -203,17 +203,26 @@ namespace TwoPaCo
 
 			const char * Name() const { return "RCCL (ncclSend/ncclRecv groups over xGMI)"; }
 
+			// One ncclGroupStart ... ncclSend / ncclRecv per peer ... ncclGroupEnd moves at most CHUNK bytes per peer: multi-GiB
+			// messages are cut up (a multi-GiB all_to_all arrived truncated in the torch.distributed driver; dist.py does the same).
+			static const size_t CHUNK = size_t(1) << 28;
+
 			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
 			{
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
-				Check(api_.GroupStart(), "ncclGroupStart");
-				for (int p = 0; p < ranks_; p++)
+				for (size_t c0 = 0; c0 < blockBytes; c0 += CHUNK)
 				{
-					Check(api_.Send(static_cast<const char*>(send) + size_t(p) * blockBytes, blockBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
-					Check(api_.Recv(static_cast<char*>(recv) + size_t(p) * blockBytes, blockBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
+					const size_t n = std::min(CHUNK, blockBytes - c0);
+					Check(api_.GroupStart(), "ncclGroupStart");
+					for (int p = 0; p < ranks_; p++)
+					{
+						Check(api_.Send(static_cast<const char*>(send) + size_t(p) * blockBytes + c0, n, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
+						Check(api_.Recv(static_cast<char*>(recv) + size_t(p) * blockBytes + c0, n, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
+					}
+
+					Check(api_.GroupEnd(), "ncclGroupEnd");
 				}
 
-				Check(api_.GroupEnd(), "ncclGroupEnd");
 				HipCheck(hipStreamSynchronize(streams_[rank]), "all-to-all");
 				if (rank == 0) bytesMoved_ += uint64_t(ranks_) * blockBytes;
 			}
@@ -221,19 +230,28 @@ namespace TwoPaCo
 			void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes)
 			{
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
-				Check(api_.GroupStart(), "ncclGroupStart");
-				uint64_t so = 0, ro = 0;
-				for (int p = 0; p < ranks_; p++)
+				uint64_t most = 0, total = 0;
+				for (int p = 0; p < ranks_; p++) { most = std::max(most, std::max(sendCounts[p], recvCounts[p])); total += sendCounts[p]; }
+				const uint64_t step = std::max<uint64_t>(1, CHUNK / elemBytes);
+				for (uint64_t c0 = 0; c0 < most; c0 += step)
 				{
-					if (sendCounts[p]) Check(api_.Send(static_cast<const char*>(send) + so * elemBytes, size_t(sendCounts[p]) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
-					if (recvCounts[p]) Check(api_.Recv(static_cast<char*>(recv) + ro * elemBytes, size_t(recvCounts[p]) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
-					so += sendCounts[p];
-					ro += recvCounts[p];
+					Check(api_.GroupStart(), "ncclGroupStart");
+					uint64_t so = 0, ro = 0;
+					for (int p = 0; p < ranks_; p++)
+					{
+						const uint64_t sa = std::min(c0, sendCounts[p]), sb = std::min(c0 + step, sendCounts[p]);
+						const uint64_t ra = std::min(c0, recvCounts[p]), rb = std::min(c0 + step, recvCounts[p]);
+						if (sb > sa) Check(api_.Send(static_cast<const char*>(send) + (so + sa) * elemBytes, size_t(sb - sa) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
+						if (rb > ra) Check(api_.Recv(static_cast<char*>(recv) + (ro + ra) * elemBytes, size_t(rb - ra) * elemBytes, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
+						so += sendCounts[p];
+						ro += recvCounts[p];
+					}
+
+					Check(api_.GroupEnd(), "ncclGroupEnd");
 				}
 
-				Check(api_.GroupEnd(), "ncclGroupEnd");
 				HipCheck(hipStreamSynchronize(streams_[rank]), "all-to-all");
-				if (rank == 0) bytesMoved_ += so * elemBytes;
+				if (rank == 0) bytesMoved_ += total * elemBytes;
 			}
 
 			void AllGather(int rank, const void * send, void * recv, size_t bytes)
