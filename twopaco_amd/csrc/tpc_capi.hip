@@ -1037,6 +1037,7 @@ int tpc_shard_config(tpc_ctx *c, uint32_t rank, uint32_t world)
     HIPCHK(c, hipSetDevice(c->device));
     c->sh_rank = rank; c->sh_world = world;
     c->sh_have[0] = c->sh_have[1] = false;
+    c->pending_apply = false;  // the filter is about to be re-cut
     if (c->have_params) {
         const uint64_t fw = filter_words_for(c->P.L, world);
         if (fw != c->filter_words) {
