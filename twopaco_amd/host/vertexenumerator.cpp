@@ -97,10 +97,15 @@ namespace TwoPaCo
 				}
 
 				// partition buffers per tile batch: a cold process pays for every GiB it allocates (hipMalloc gets slow,
-				// ~25 ms per GiB, beyond the first ~48 GiB), an extra batch costs 15-20 ms of kernel time at f=36.
+				// ~25 ms per GiB, beyond the first ~48 GiB), an extra batch costs a pass over the filter and, for the 62-genome
+				// workload, the deferred apply (the query must fit one batch): 40 GiB measured 0.28 s end to end against 0.35 s at 20.
 				// Every rank of a sharded run gets the SAME budget: the batch geometry must agree on all of them.
 				const char * budgetGb = std::getenv("TWOPACO_PART_BUDGET_GB");
-				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : 20.0) * double(1ull << 30));
+				// so: whatever keeps filter + buffers inside those first 48 GiB, between 20 and 40 GiB (measured on the 1.12 Gbp / f = 38
+				// workload: 16 / 20 / 28 GiB -> 0.82 / 0.76 / 0.83 s)
+				const double filterGb = std::ldexp(1.0, int(filterSize) - 33);
+				const double autoGb = std::max(20.0, std::min(40.0, 48.0 - filterGb));
+				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : autoGb) * double(1ull << 30));
 				const int gpus = std::max(1, options.gpus);
 				const bool sharded = gpus > 1 || options.forceSharded;
 				// filter slices of 2^20 bits (128 KiB of LDS) unless the filter is too small to give every rank its level-1 buckets:
