@@ -188,6 +188,9 @@ void tpc_host_free(void *ptr);
  *                      tests the first probe of every received edge and keeps the hits as the
  *                      survivor list (*n_survivors; ids relative to the batch)
  *   tpc_shard_survivors       copy the survivor ids to a device buffer
+ *   tpc_shard_survivor_sources   the rank that hashed each survivor's position (it rides in the id): survivors go BACK to
+ *                             that rank (route + variable all_to_all) and are verified there, where their text is -- a
+ *                             rank then needs only its own chunk of the packed text (tpc_set_option "text_window")
  *   tpc_shard_verify_addrs    for hash functions fn .. fn+fn_count-1: owner rank and shard-local bit
  *                             address of every survivor id in sid_dev (entry i*fn_count + j)
  *   tpc_shard_probe           answer probes against this rank's shard (hit_dev[i] = 0/1)
@@ -213,6 +216,7 @@ int tpc_shard_overflow_get(tpc_ctx *ctx, int pass, void *dst_dev, uint64_t n);
 int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t n);
 int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
 int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
+int tpc_shard_survivor_sources(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n, int32_t *source_dev);
 int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
 int tpc_shard_probe(tpc_ctx *ctx, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev);
 int tpc_shard_mark(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n);
@@ -246,6 +250,9 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *   insert_mode / query_mode   0 = automatic, 1 = direct scattered kernel, 2 = LDS write-combining passes
  *   slice_bits         log2 bits of a filter slice held in LDS (6..20, default 20)
  *   part_levels        0 = automatic (three binning levels when L - slice_bits > 18), 2, 3
+ *   text_window        1: on a sharded context tpc_seq_upload keeps only the words of the tiles this rank hashes (chunk
+ *                      rank * ceil(tiles / world) ..., + halo); such a context runs the sharded first pass only (rank 0 of the
+ *                      C++ host keeps the whole text for the second pass)
  *   fuse_apply_lookup  1 (default): when the insert and the query of a round both fit one tile batch, the insert stops after its
  *                      level-2 binning and the query's lookup kernel builds each filter slice itself (the filter is written once,
  *                      never read back); TPC_K_INSERT then covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
@@ -255,7 +262,7 @@ int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
- * with the full-size table by the last tpc_pass2_filter; "fused_lookups" = queries that built the filter slices themselves (deferred apply); "round_marks" = candidate marks of the round the last
+ * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "round_marks" = candidate marks of the round the last
  * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does).
  * -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);

@@ -48,6 +48,32 @@ def test_emulated_ranks_write_reference_bytes(capi, tmp_path, name, ranks):
     e.close()
 
 
+def test_text_window_on_sharded_context(capi):
+    """Option text_window: rank r of W keeps only the words of its chunk of tiles (+ halo); such a context refuses the
+    second pass (the C++ host gives it to every rank but 0)."""
+    import numpy as np
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.05)   # 8 x 250 kbp = 2 M positions = 123 tiles
+    text = capi.PackedText.from_codes(recs)
+    held = []
+    for rank in range(4):
+        ctx = capi.Context(0)
+        ctx.shard_config(rank, 4)
+        ctx.set_option("text_window", 1)
+        ctx.set_params(25, 30, 5, capi.seed_table(5, 30, seed=3))
+        ctx.seq_upload(text)
+        held.append(ctx.stat("text_words"))
+        with pytest.raises(RuntimeError, match="window"):
+            ctx.pass2_filter()
+        ctx.close()
+    full = capi.Context(0)
+    full.set_params(25, 30, 5, capi.seed_table(5, 30, seed=3))
+    full.seq_upload(text)
+    whole = full.stat("text_words")
+    full.close()
+    assert all(h < 0.3 * whole for h in held) and sum(held) >= text.length // 32
+
+
 def test_rccl_transport_single_rank(capi, tmp_path):
     """The sharded path over the RCCL transport with the one rank a single-GPU box allows: librccl is loaded, the
     communicator created, and every collective of the pass (send/recv groups to self, all-gather) runs through it."""

@@ -19,7 +19,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
-               "tpc_shard_survivors", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
+               "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup"]
@@ -84,6 +84,7 @@ def hip():
         L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]
         L.tpc_shard_survivors.argtypes = [p, p]
         L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
+        L.tpc_shard_survivor_sources.argtypes = [p, p, u64, p]
         L.tpc_shard_probe.argtypes = [p, p, u64, p]
         L.tpc_shard_mark.argtypes = [p, p, u64]
         L.tpc_mask_export.argtypes = [p, p]
@@ -392,6 +393,9 @@ class Context:
 
     def shard_survivors(self, sid_ptr):
         self._ck(hip().tpc_shard_survivors(self._h, sid_ptr))
+
+    def shard_survivor_sources(self, sid_ptr, n, src_ptr):
+        self._ck(hip().tpc_shard_survivor_sources(self._h, sid_ptr, n, src_ptr))
 
     def shard_verify_addrs(self, fn, fn_count, sid_ptr, n, addr_ptr, owner_ptr):
         self._ck(hip().tpc_shard_verify_addrs(self._h, fn, fn_count, sid_ptr, n, addr_ptr, owner_ptr))

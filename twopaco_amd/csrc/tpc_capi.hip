@@ -26,6 +26,13 @@ struct tpc_ctx {
     uint64_t *bases = nullptr;
     uint32_t *nmask = nullptr;
     uint64_t n_text = 0, n_words = 0, n_words_alloc = 0, n_tiles = 0;
+    // sharded contexts may hold only the words of the tiles they hash (+ halo): bases / nmask then point text_w0 words BEFORE
+    // the allocations, so that kernels keep indexing by global word
+    uint64_t *bases_alloc = nullptr;
+    uint32_t *nmask_alloc = nullptr;
+    int opt_text_window = 0;
+    bool text_windowed = false;
+    uint64_t text_w0 = 0, text_w1 = 0;
     // filter + masks
     uint32_t *filter = nullptr;
     uint64_t filter_words = 0;
@@ -296,7 +303,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = { c->tab, c->bases, c->nmask, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
+    void *ptrs[] = { c->tab, c->bases_alloc, c->nmask_alloc, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
                      c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
@@ -320,6 +327,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "part_levels")) { c->opt_part_levels = (int)value; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
+    if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -353,6 +361,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
+    if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
     if (!strcmp(name, "round_marks")) return c->marks_valid ? (int64_t)c->n_marks : -1;  // set bits of the round mask (after tpc_pass2_filter)
     return -1;
 }
@@ -403,24 +412,44 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     // whole 512-word tiles of text_tiles512() (one more than nw needs when n_text is a multiple of 16384: the kernels of the
     // partitioned passes stage words [tile * 512 - 1, tile * 512 + 512 + xw) and k_q_hash stores a tile's rmask unguarded)
     const uint64_t alloc = ((n_text / TPC_RUN + 512) / 512) * 512 + TPC_XW_MAX + 2;
-    for (void *p : { (void *)c->bases, (void *)c->nmask, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
+    // window (option text_window on a sharded context): only the words of this rank's chunk of tiles, plus the halo a tile
+    // stages (one word before, TPC_XW_MAX + 1 after).  Everything a windowed context may run reads inside it: the hash
+    // kernels over its own tiles and the verification of survivors at its own positions.
+    uint64_t w0 = 0, w1 = alloc;
+    const bool windowed = c->opt_text_window && c->sh_world > 1;
+    if (windowed) {
+        const uint64_t t512 = (n_text / TPC_RUN + 512) / 512, chunk = (t512 + c->sh_world - 1) / c->sh_world;
+        const uint64_t ta = std::min<uint64_t>(t512, (uint64_t)c->sh_rank * chunk), tb = std::min<uint64_t>(t512, ta + chunk);
+        w0 = ta * 512 > 0 ? ta * 512 - 1 : 0;
+        w1 = std::min<uint64_t>(alloc, tb * 512 + TPC_XW_MAX + 2);
+        if (w1 <= w0) w1 = w0 + 1;
+    }
+    for (void *p : { (void *)c->bases_alloc, (void *)c->nmask_alloc, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
         if (p) (void)hipFree(p);
-    c->bases = nullptr; c->nmask = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
-    HIPCHK(c, hipMalloc((void **)&c->bases, alloc * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void **)&c->nmask, alloc * sizeof(uint32_t)));
+    c->bases = nullptr; c->nmask = nullptr; c->bases_alloc = nullptr; c->nmask_alloc = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
+    const uint64_t wn = w1 - w0;
+    HIPCHK(c, hipMalloc((void **)&c->bases_alloc, wn * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void **)&c->nmask_alloc, wn * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&c->rmask, alloc * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&c->mask, alloc * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&c->block_sums, (alloc / 256 + 2) * sizeof(uint64_t)));
-    HIPCHK(c, hipMemsetAsync(c->bases, 0, alloc * sizeof(uint64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->nmask, 0xFF, alloc * sizeof(uint32_t), c->stream));  // padding = N
+    HIPCHK(c, hipMemsetAsync(c->bases_alloc, 0, wn * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nmask_alloc, 0xFF, wn * sizeof(uint32_t), c->stream));  // padding = N
     HIPCHK(c, hipMemsetAsync(c->rmask, 0, alloc * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->mask, 0, alloc * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->bases, bases, nw * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    // the last word may be partial: mark the bits past n_text as N
-    std::vector<uint32_t> nm(nmask, nmask + nw);
-    if (n_text & 31) nm[nw - 1] |= ~0u << (n_text & 31);
-    HIPCHK(c, hipMemcpyAsync(c->nmask, nm.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    const uint64_t ce = std::min(nw, w1);  // host words [w0, ce) exist
+    std::vector<uint32_t> nm;
+    if (ce > w0) {
+        HIPCHK(c, hipMemcpyAsync(c->bases_alloc, bases + w0, (ce - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        // the last word may be partial: mark the bits past n_text as N
+        nm.assign(nmask + w0, nmask + ce);
+        if ((n_text & 31) && ce == nw) nm[nw - 1 - w0] |= ~0u << (n_text & 31);
+        HIPCHK(c, hipMemcpyAsync(c->nmask_alloc, nm.data(), (ce - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bases = c->bases_alloc - w0;
+    c->nmask = c->nmask_alloc - w0;
+    c->text_windowed = windowed; c->text_w0 = w0; c->text_w1 = w1;
     c->pending_apply = false;
     c->n_text = n_text; c->n_words = (n_text >> 5) + 1; c->n_words_alloc = alloc; c->n_tiles = tiles;
     c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
@@ -704,6 +733,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
 int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = compact_mask(c, c->rmask);
     if (rc) return rc;
@@ -1082,7 +1112,9 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         TpcQPlan &pl = c->sh_qpl;
         for (uint64_t batches = 1;; batches *= 2) {
             per = (per_total + batches - 1) / batches;
-            const bool fits = per * W * (uint64_t)(512 * TPC_RUN) <= (1ull << 30);  // survivor ids hold a 30-bit position relative to the batch
+            uint32_t log_w = 0;
+            while ((1u << log_w) < c->sh_world) ++log_w;
+            const bool fits = per * (uint64_t)(512 * TPC_RUN) <= (1ull << (30 - log_w));  // survivor ids: source rank + position relative to its batch in 30 bits
             const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, c->opt_part_levels);
             if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
             if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
@@ -1104,8 +1136,11 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         geom[4] = 64 * pl.surv_cap; geom[5] = pl.ovf_cap; geom[6] = 16;
         geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv; geom[12] = pl.b3;
     }
+    // Tile ownership is contiguous: rank r hashes the chunk [r * per_total, (r + 1) * per_total) of the text, `per` tiles per
+    // batch -- so a rank needs only its chunk of the packed text (option text_window) -- and a query entry names its source
+    // rank in the top log2(world) bits of its 30-bit position field, the rest being the position relative to that rank's batch.
     c->sh_per[pass] = per;
-    c->sh_batches[pass] = (tiles + W * per - 1) / (W * per);
+    c->sh_batches[pass] = (per_total + per - 1) / per;
     c->sh_have[pass] = true;
     c->sh_have[1 - pass] = false;  // the two passes share the partition buffers
     geom[0] = c->sh_batches[pass]; geom[1] = per;
@@ -1120,8 +1155,9 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
-    const uint64_t t_batch = batch * W * per, t0 = t_batch + c->sh_rank * per;
-    const uint64_t n = t0 < tiles ? std::min<uint64_t>(per, tiles - t0) : 0;
+    const uint64_t chunk = (tiles + W - 1) / W, c0 = std::min(tiles, c->sh_rank * chunk), c1 = std::min(tiles, c0 + chunk);
+    const uint64_t t0 = c0 + batch * per;
+    const uint64_t n = t0 < c1 ? std::min<uint64_t>(per, c1 - t0) : 0;
     unsigned long long ov[2] = {0, 0};
     if (pass == TPC_SHARD_INSERT) {
         TpcPartPlan pl = c->sh_ipl;
@@ -1135,7 +1171,7 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
         HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
     } else {
         TpcQPlan pl = c->sh_qpl;
-        pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t_batch;
+        pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t0;  // positions in the entries are relative to this rank's batch
         pl.buf1 = (uint64_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
         { int rc0 = materialize_reset(c); if (rc0) return rc0; }
         HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
@@ -1201,9 +1237,10 @@ int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regio
     }
     TpcQPlan pl = c->sh_qpl;
     pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts;
-    const uint64_t W = c->sh_world, per = c->sh_per[pass];
-    pl.tile0_global = batch * W * per;
-    c->sh_qpl.tile0_global = pl.tile0_global;  // survivor ids handed out below are relative to this batch
+    const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
+    const uint64_t chunk = (tiles + W - 1) / W;
+    pl.tile0_global = std::min(tiles, c->sh_rank * chunk) + batch * per;
+    c->sh_qpl.tile0_global = pl.tile0_global;  // the survivors that come BACK to this rank (tpc_shard_survivor_sources) are relative to its own batch
     unsigned long long cur[65];
     {
         Timed t(c, TPC_K_SHARD_APPLY);
@@ -1279,6 +1316,16 @@ int tpc_mask_merge(tpc_ctx *c, const uint32_t *src_dev, uint32_t count)
     HIPCHK(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < count; i++) tpc_launch_mask_or(c->stream, c->rmask, src_dev + (uint64_t)i * c->n_words, c->n_words);
     c->marks_valid = false;
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_shard_survivor_sources(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n, int32_t *source_dev)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || (n && (!sid_dev || !source_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    tpc_launch_survivor_sources(c->stream, sid_dev, n, c->sh_world, source_dev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1400,6 +1447,7 @@ int tpc_hash_dump(tpc_ctx *c, uint64_t g0, uint64_t n, uint64_t *out_host)
 {
     if (!c || !c->have_params || !c->bases) return -1;
     if (g0 + n + c->P.k > c->n_text) return fail(c, -1, "range past the text");
+    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t *d = nullptr;
     const size_t bytes = n * 2 * c->P.q * sizeof(uint64_t);

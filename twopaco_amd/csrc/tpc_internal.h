@@ -109,6 +109,7 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
 int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n, uint8_t *hit);
 int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask);
 
+int tpc_launch_survivor_sources(hipStream_t s, const uint64_t *sid, uint64_t n, uint32_t world, int32_t *src);
 // owner routing of survivor probes (world <= 64): counts -> cursors -> perm; dst[perm[i]] = src[i]; survivors with all answers 1
 int tpc_launch_route(hipStream_t s, const int32_t *owner, uint64_t n, unsigned long long *counts, unsigned long long *cursor, uint32_t *perm, int phase);
 int tpc_launch_permute64(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, uint64_t *dst);

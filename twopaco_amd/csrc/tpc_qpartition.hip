@@ -137,7 +137,8 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                         if (c_prev == TPC_CODE_N || c_next == TPC_CODE_N) {
                             word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
                         } else {
-                            const uint64_t sid_g = (g - gbase) << 3;  // position relative to the batch
+                            // position relative to the batch; sharded: the source rank rides in the top log2(world) bits of the 30
+                            const uint64_t sid_g = ((g - gbase) | (SHARDED ? (uint64_t)sh.rank << (30u - sh.log_world()) : 0ull)) << 3;
                             uint32_t eb[8];
                             uint64_t ev[8];
                             bool eok[8];
@@ -588,7 +589,7 @@ k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
         const uint64_t sid = sid_list[idx];
         const int e = (int)(sid & 7);
-        const uint64_t g = gbase + (sid >> 3);
+        const uint64_t g = gbase + ((sid >> 3) & ((1ull << (30u - sh.log_world())) - 1ull));  // the source-rank bits are this rank's own
         uint64_t pos[Q], neg[Q];
 #pragma unroll
         for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
@@ -650,11 +651,11 @@ __global__ void k_v_probe(const uint32_t *__restrict__ filter, const uint64_t *_
     }
 }
 
-__global__ void k_v_mark(const uint64_t *__restrict__ sid_list, uint64_t n, uint64_t gbase, uint32_t *rmask)
+__global__ void k_v_mark(const uint64_t *__restrict__ sid_list, uint64_t n, uint64_t gbase, uint64_t posmask, uint32_t *rmask)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t g = gbase + (sid_list[i] >> 3);
+        const uint64_t g = gbase + ((sid_list[i] >> 3) & posmask);
         atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
@@ -1019,8 +1020,24 @@ int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n,
 
 int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask)
 {
+    uint32_t lw = 0;
+    while ((1u << lw) < pl.world) ++lw;
     if (n) hipLaunchKernelGGL(k_v_mark, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, a.stream, sid, n,
-                              pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+                              pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), (1ull << (30u - lw)) - 1ull, rmask);
+    return 0;
+}
+
+__global__ void k_survivor_sources(const uint64_t *__restrict__ sid, uint64_t n, uint32_t shift, int32_t *__restrict__ src)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) src[i] = (int32_t)((sid[i] >> 3) >> shift);
+}
+
+int tpc_launch_survivor_sources(hipStream_t s, const uint64_t *sid, uint64_t n, uint32_t world, int32_t *src)
+{   // the rank that hashed the survivor's position: the top log2(world) bits of its 30-bit position field (k_q_hash<SHARDED>)
+    uint32_t lw = 0;
+    while ((1u << lw) < world) ++lw;
+    if (n) hipLaunchKernelGGL(k_survivor_sources, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, sid, n, 30u - lw, src);
     return 0;
 }
 

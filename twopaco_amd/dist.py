@@ -266,7 +266,8 @@ class AddressSharded:
       hash    tpc_shard_hash: this rank's tiles -> level-1 regions, destination major
       move    all_to_all (equal blocks) of the regions and their fill counts
       apply   tpc_shard_apply: levels 2-3 on the owned filter slices (insert: OR; query: first probe)
-    Query only: the survivors of the first probe (edge ids) are checked against hash functions
+    Query only: the survivors of the first probe (edge ids) return to the rank that hashed them (tpc_shard_survivor_sources,
+    variable all_to_all) and are checked there against hash functions
     1..q-1 -- addresses to their owners (variable all_to_all), one byte back per address; function 1
     alone first, which rejects most Bloom false positives, then the rest in one exchange -- and the
     survivors of all q functions are the candidate marks.  The grouping of the probes by owner is done by the library
@@ -351,6 +352,17 @@ class AddressSharded:
             t0 = self._tick("query_apply", t0)
             sid = torch.empty(n, dtype=torch.int64, device=self.device)
             ctx.shard_survivors(sid.data_ptr())
+            # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
+            # their text is: a rank then needs only its own chunk of the packed text
+            src = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            ctx.shard_survivor_sources(sid.data_ptr(), n, src.data_ptr())
+            perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            counts = ctx.shard_route(src.data_ptr(), n, perm.data_ptr(), W)
+            send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            ctx.shard_permute64(sid.data_ptr(), perm.data_ptr(), n, send.data_ptr())
+            sid, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
+            sid = sid.contiguous()
+            self.comm.sync()
             trace = [n]
             # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange
             for fn, cnt in ([(1, 1)] if ctx.q > 1 else []) + ([(2, ctx.q - 2)] if ctx.q > 2 else []):

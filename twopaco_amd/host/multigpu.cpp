@@ -356,6 +356,36 @@ namespace TwoPaCo
 			}
 		}
 
+		// The survivors of the first probe (ids in r.buf[SID]) go back to the rank that hashed their position -- it rides in the id --
+		// so that they are verified where their text is.  Returns how many arrived here (ids in r.buf[SID]).
+		uint64_t ReturnSurvivors(ShardedRank & r, Transport & net, uint64_t n)
+		{
+			const int W = net.Ranks();
+			uint64_t * sid = static_cast<uint64_t*>(r.buf[SID]);
+			int32_t * source = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(n, 1) * 4));
+			LibCheck(r.ctx, tpc_shard_survivor_sources(r.ctx, sid, n, source), "shard_survivor_sources");
+			uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(n, 1) * 4));
+			uint64_t counts[64];
+			LibCheck(r.ctx, tpc_shard_route(r.ctx, source, n, perm, counts), "shard_route");
+			uint64_t * send = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(n, 1) * 8));
+			LibCheck(r.ctx, tpc_shard_permute64(r.ctx, sid, perm, n, send), "shard_permute64");
+			std::vector<uint64_t> all;
+			net.ExchangeHost(r.rank, counts, W, all);
+			std::vector<uint64_t> recvCounts(W);
+			uint64_t arriving = 0;
+			for (int s = 0; s < W; s++)
+			{
+				recvCounts[s] = all[size_t(s) * W + r.rank];
+				arriving += recvCounts[s];
+			}
+
+			uint64_t * mine = static_cast<uint64_t*>(r.Ensure(SID2, std::max<uint64_t>(arriving, 1) * 8));
+			net.AllToAllV(r.rank, send, counts, mine, recvCounts.data(), 8);
+			std::swap(r.buf[SID], r.buf[SID2]);
+			std::swap(r.cap[SID], r.cap[SID2]);
+			return arriving;
+		}
+
 		// Survivors of the first probe against functions fn .. fn+count-1; returns the number that passed (ids in r.buf[SID]).
 		uint64_t VerifyStep(ShardedRank & r, Transport & net, uint64_t n, int fn, int count)
 		{
@@ -419,6 +449,7 @@ namespace TwoPaCo
 			LibCheck(r.ctx, tpc_shard_apply(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
 			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
 			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
+			n = ReturnSurvivors(r, net, n);
 			// function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together
 			if (hashFunctions > 1) n = VerifyStep(r, net, n, 1, 1);
 			if (hashFunctions > 2) n = VerifyStep(r, net, n, 2, hashFunctions - 2);

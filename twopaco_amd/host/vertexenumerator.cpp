@@ -243,6 +243,7 @@ namespace TwoPaCo
 								check(tpc_set_option(me.ctx, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
 								check(tpc_set_option(me.ctx, "slice_bits", shardSliceBits), "set_option");
 								check(tpc_set_option(me.ctx, "part_budget_bytes", partBudget), "set_option");
+								check(tpc_set_option(me.ctx, "text_window", 1), "set_option");  // ranks other than 0 keep only their chunk of the text (rank 0 runs the second pass)
 								check(tpc_shard_config(me.ctx, uint32_t(r), uint32_t(gpus)), "shard_config");
 								check(tpc_set_params(me.ctx, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 								check(tpc_seq_upload(me.ctx, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
