@@ -161,9 +161,9 @@ void tpc_host_free(void *ptr);
 /* ---- address-sharded filter (multi-GPU) -------------------------------------------------
  * The Bloom filter (ConcurrentBitVector bitVector, VE.h:257) is cut over `world` ranks (a power of
  * two) by bit address: the partitioned passes route every address to the workgroup that owns its
- * filter slice, and rank r owns the slices of the level-1 buckets b1 with b1 % world == r.  Every
- * rank holds the whole packed text and hashes 1/world of its tiles; the level-1 regions are what
- * travels (one equal-split all_to_all per pass and batch).  The library does no communication:
+ * filter slice, and rank r owns the slices of the level-1 buckets b1 with b1 % world == r.  Rank r
+ * hashes the r-th contiguous chunk of the text's tiles (and, with option text_window, holds only that
+ * chunk + halo); the level-1 regions are what travels (one equal-split all_to_all per pass and batch).  The library does no communication:
  * the caller (twopaco_amd/dist.py over torch.distributed, or MPI/RCCL in a C++ host) moves the
  * DEVICE buffers named below between the calls.  All ranks must make the same calls with the
  * same lo/hi.  tpc_pass1_insert / tpc_pass1_query refuse to run on a sharded context.
