@@ -237,11 +237,7 @@ struct Bins {
                 }
                 const uint64_t pos = (uint64_t)it[k].y + l * EPL;
                 const PtRegion<T> rg = reg(b);
-#ifdef TPC_BINS_NOSTORE  // experiment: everything but the HBM write
-                if (pos < rg.cap) { if (u[k].q.x == 0x12345678u && u[k].q.y == 0x9ABCDEF0u) *reinterpret_cast<uint4 *>(rg.base + pos) = u[k].q; }
-#else
                 if (pos < rg.cap) *reinterpret_cast<uint4 *>(rg.base + pos) = u[k].q;
-#endif
                 else {
 #pragma unroll
                     for (int e = 0; e < EPL; e++) if (u[k].e[e] != SENT) lost(b, u[k].e[e]);

@@ -66,6 +66,7 @@ struct tpc_ctx {
     uint64_t stream_cap = 0, stream_bytes = 0;
     // scalars
     unsigned long long *counters = nullptr;  // device, 8 words
+    unsigned long long *route_scratch = nullptr;  // device, 128 words: tpc_shard_route's per-owner counts and cursors
     // options
     int opt_test_first = 0;
     int opt_insert_mode = 0;   // 0 auto, 1 direct atomicOr, 2 partitioned (LDS write-combining)
@@ -293,7 +294,8 @@ int tpc_ctx_create(int device, tpc_ctx **out)
         if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { delete c; return -5; }
     }
     if (hipMalloc((void **)&c->tab, TPC_TAB_WORDS * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return -6; }
+        hipMalloc((void **)&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->route_scratch, 128 * sizeof(unsigned long long)) != hipSuccess) { delete c; return -6; }
     *out = c;
     return 0;
 }
@@ -304,7 +306,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases_alloc, c->nmask_alloc, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->scan_blocks, c->sort_scratch };
+                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->route_scratch, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
@@ -1337,8 +1339,7 @@ int tpc_shard_route(tpc_ctx *c, const int32_t *owner_dev, uint64_t n, uint32_t *
     if (c->sh_world > 64) return fail(c, -1, "routing supports at most 64 ranks");
     if (n > 0xFFFFFFFFull) return fail(c, -1, "too many items to route at once");
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long *d = nullptr;  // [0..63] counts, [64..127] cursors
-    HIPCHK(c, hipMalloc((void **)&d, 128 * sizeof(unsigned long long)));
+    unsigned long long *d = c->route_scratch;  // [0..63] counts, [64..127] cursors
     HIPCHK(c, hipMemsetAsync(d, 0, 128 * sizeof(unsigned long long), c->stream));
     tpc_launch_route(c->stream, owner_dev, n, d, d + 64, perm_dev, 0);
     unsigned long long h[64], cur[64];
@@ -1350,7 +1351,6 @@ int tpc_shard_route(tpc_ctx *c, const int32_t *owner_dev, uint64_t n, uint32_t *
     tpc_launch_route(c->stream, owner_dev, n, d, d + 64, perm_dev, 1);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(d);
     return 0;
 }
 
