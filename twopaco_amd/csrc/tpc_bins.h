@@ -106,6 +106,48 @@ __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w
     return base + inc - v;
 }
 
+// Host side of the round schedule below: LDS words for a split workgroup that streams up to ceil(nvw / wpb) regions of at
+// most cap1 entries in rounds of `step` entries.  The whole schedule when it fits beside lds_base bytes, else a segment.
+inline void pt_schedule_dims(uint32_t nvw, uint32_t wpb, uint64_t cap1, uint32_t step, size_t lds_base, uint32_t &nreg_cap, uint32_t &sched_cap, size_t &lds)
+{
+    constexpr size_t LDS_MAX = 160 * 1024 - 256;  // gfx950: 160 KB per workgroup
+    nreg_cap = (nvw + wpb - 1) / wpb;
+    const uint64_t need = (uint64_t)nreg_cap * ((cap1 + step - 1) / step) + 1;
+    const size_t fixed = lds_base + (size_t)nreg_cap * 4;
+    const uint64_t room = LDS_MAX > fixed + 1024 ? (LDS_MAX - fixed) / 4 : 256;
+    sched_cap = (uint32_t)(need < room ? need : room);
+    lds = fixed + (size_t)sched_cap * 4;
+}
+
+// Round schedule of a level-2 (or level-3) workgroup.  The workgroup streams `nreg` source regions with count(t) entries
+// each, `step` entries per round; a round never spans two regions.  The schedule lists, for every round, the region and
+// the chunk inside it: sched[r] = t | chunk << 16.  Built once with a block scan, it turns the round loop into a
+// counted loop over uniform (scalar) values -- a cursor that walked the regions by loading their counts on the way kept
+// the loop's control flow in vector registers, and the compiler then waited with vmcnt(0) on every prefetch.
+// Rounds [skip, skip + cap) are stored (segments, for inputs whose schedule outgrows the LDS left beside the rings);
+// returns the total number of rounds.  s_cnt[nreg] receives the counts.  Ends with a barrier.
+template <int THREADS, class Count>
+__device__ __forceinline__ uint32_t pt_build_schedule(uint32_t nreg, uint32_t step, uint32_t skip, uint32_t cap, uint32_t *s_cnt, uint32_t *s_sched,
+                                                      uint32_t *s_w, Count count)
+{
+    uint32_t running = 0;
+    for (uint32_t t0 = 0; t0 < nreg; t0 += THREADS) {
+        const uint32_t t = t0 + threadIdx.x;
+        uint32_t n = 0;
+        if (t < nreg) { n = skip ? s_cnt[t] : count(t); s_cnt[t] = n; }
+        const uint32_t rounds = (n + step - 1) / step;
+        uint32_t total;
+        const uint32_t off = running + pt_block_excl_scan<THREADS>(rounds, s_w, total);
+        for (uint32_t c = 0; c < rounds; c++) {
+            const uint32_t r = off + c;
+            if (r >= skip && r - skip < cap) s_sched[r - skip] = t | (c << 16);
+        }
+        running += total;
+        pt_barrier_lds();  // s_w is reused by the next pass; the schedule is complete after the last one
+    }
+    return running;
+}
+
 template <class T>
 struct PtRegion { T *base; uint64_t cap; };
 

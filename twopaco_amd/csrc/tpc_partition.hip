@@ -141,14 +141,15 @@ constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips be
 template <bool SHARDED>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
-             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads)
+             uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads,
+             uint32_t nreg_cap, uint32_t sched_cap)
 {   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
     // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 16;  // upper bound; `loads` of them are used
     Bins<uint32_t, PS_THREADS> bins;
-    bins.carve(smem, LOG_NB2);
+    unsigned char *s_free = bins.carve(smem, LOG_NB2);
     bins.init();
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
@@ -166,40 +167,55 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
     auto reg = [region, cap2](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap2, cap2}; };
     __syncthreads();
-    // rounds of LOADS x PS_THREADS entries over the regions (w, b1), w = j, j + wpb, ...; the next
-    // round's loads are issued before the current round is binned and flushed
-    uint32_t w = j, base = 0;
-    uint32_t n = w < nvw ? cnt1[r1(w)] : 0;
-    while (w < nvw && n == 0) { w += wpb; n = w < nvw ? cnt1[r1(w)] : 0; }
-    uint32_t v[LOADS], vn[LOADS];
-    auto load = [&](uint32_t (&dst)[LOADS], uint32_t ww, uint32_t bb, uint32_t nn) {
-        const uint32_t *src = buf1 + r1(ww) * cap1;
+    // rounds of `loads` x PS_THREADS entries over the regions (w, b1), w = j, j + wpb, ..., taken from the round schedule;
+    // the next round's loads are issued before the current round is binned and flushed.  The loads are unpredicated (lanes
+    // past the end read entry 0 and are masked when the round is consumed) and the two buffers alternate by name.
+    const uint32_t nreg = j < nvw ? (nvw - j + wpb - 1) / wpb : 0;
+    const uint32_t step = (uint32_t)loads * PS_THREADS;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_free);  // [nreg_cap]
+    uint32_t *s_sched = s_cnt + nreg_cap;                    // [sched_cap]
+    struct Round { uint32_t t, base, n; };  // region (j + t * wpb), first entry of the round, entries in the region; all scalar
+    uint32_t va[LOADS], vb[LOADS];
+    for (uint32_t skip = 0;; skip += sched_cap) {
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<PS_THREADS>(
+            nreg, step, skip, sched_cap, s_cnt, s_sched, bins.scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+        const uint32_t n_seg = min(total - min(total, skip), sched_cap);
+        auto round_at = [&](uint32_t r) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
+            Round x{e & 0xFFFFu, (e >> 16) * step, 0u};
+            if (r < n_seg) x.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[x.t]);
+            return x;
+        };
+        auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * PS_THREADS + threadIdx.x < x.n; };
+        auto load = [&](uint32_t (&dst)[LOADS], const Round &x) {
+            const uint32_t *src = buf1 + r1(j + x.t * wpb) * cap1;
 #pragma unroll
-        for (int i = 0; i < LOADS; i++) {
-            const uint32_t idx = bb + i * PS_THREADS + threadIdx.x;
-            dst[i] = (i < loads && idx < nn) ? src[idx] : PT_SENT;
-        }
-    };
-    if (w < nvw) load(v, w, base, n);
-    while (w < nvw) {
-        // advance to the next round and prefetch it
-        uint32_t w2 = w, base2 = base + (uint32_t)loads * PS_THREADS, n2 = n;
-        if (base2 >= n2) {
-            base2 = 0;
-            do { w2 += wpb; n2 = w2 < nvw ? cnt1[r1(w2)] : 0; } while (w2 < nvw && n2 == 0);
-        }
-        if (w2 < nvw) load(vn, w2, base2, n2);
-        {
-            uint32_t bb[LOADS], val[LOADS];
-            bool ok[LOADS];
+            for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * PS_THREADS + threadIdx.x : 0u];
+        };
+        if (n_seg) {
+            Round x0 = round_at(0);
+            load(va, x0);
+            uint32_t r = 0;
+            auto round = [&](uint32_t (&cur)[LOADS], uint32_t (&pre)[LOADS]) {
+                const Round x1 = round_at(r + 1);
+                load(pre, x1);
+                uint32_t bb[LOADS], val[LOADS];
+                bool ok[LOADS];
 #pragma unroll
-            for (int i = 0; i < LOADS; i++) { ok[i] = v[i] != PT_SENT; bb[i] = v[i] >> slice_bits; val[i] = v[i] & slice_mask; }
-            bins.template push_batch<LOADS>(bb, val, ok, lost);
+                for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != PT_SENT; bb[i] = cur[i] >> slice_bits; val[i] = cur[i] & slice_mask; }
+                bins.template push_batch<LOADS>(bb, val, ok, lost);
+                bins.flush(false, reg, lost);
+                x0 = x1; r++;
+            };
+            while (true) {
+                if (r >= n_seg) break;
+                round(va, vb);
+                if (r >= n_seg) break;
+                round(vb, va);
+            }
         }
-        bins.flush(false, reg, lost);
-#pragma unroll
-        for (int i = 0; i < LOADS; i++) v[i] = vn[i];
-        w = w2; base = base2; n = n2;
+        if (total <= skip + sched_cap) break;
+        pt_barrier_lds();  // every wave is done with this segment of the schedule
     }
     bins.flush(true, reg, lost);
     bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
@@ -291,20 +307,29 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3));
-    (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds_base = Bins<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3));
     const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
     const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
-    if (pl.world > 1)
+    uint32_t nreg_cap, sched_cap;
+    size_t lds;
+    const int loads2 = split_loads(pl.b2);
+    pt_schedule_dims(pl.nwg1 * pl.world, pl.wpb, pl.cap1, (uint32_t)loads2 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+    if (pl.world > 1) {
+        (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, split_loads(pl.b2));
-    else
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap);
+    } else {
+        (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, split_loads(pl.b2));
-    if (pl.b3)  // third level: bucket (b1, b2), input = the regions written above
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap);
+    }
+    if (pl.b3) {  // third level: bucket (b1, b2), input = the regions written above
+        const int loads3 = split_loads(pl.b3);
+        pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)loads3 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+        (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
-                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, split_loads(pl.b3));
+                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap);
+    }
     return 0;
 }
 

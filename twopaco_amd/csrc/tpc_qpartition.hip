@@ -50,31 +50,14 @@ struct QOverflow {  // entries that did not fit a region: {full address, survivo
 __device__ __forceinline__ bool within(uint64_t v, uint64_t lo, uint64_t hi) { return v >= lo && v <= hi; }
 
 // ------------------------------------------------------------------------------------------ A
-// Only hash function 0 is rolled here: the first probe of an edge is its function-0 address, and the
-// canonical strand is decided by function 0 unless its two strand values tie (probability 2^-L), in
-// which case the other functions are evaluated from the tile.  k_q_verify recomputes all q functions
-// for the few survivors.
-template <int Q>
-__device__ bool q_tie_break(const TpcHashParams &P, const uint64_t *s_h, const uint64_t *s_hk, const uint64_t *sb, const uint32_t *sn,
-                            uint64_t g, uint64_t wbase, int c, bool out_edge)
-{   // DetermineStrandExtend / Prepend (vertexrollinghash.h:170-200) for functions 1..Q-1; true = negative strand
-    for (int i = 1; i < Q; i++) {
-        uint64_t pos = 0, neg = 0;
-        for (int t = 0; t < P.k; t++) {
-            pos = tpc_rotl1(pos, P.L, P.lmask) ^ s_h[i * 5 + tpc_tile_char(sb, sn, g + t, wbase)];
-            neg = tpc_rotl1(neg, P.L, P.lmask) ^ s_h[i * 5 + tpc_rc(tpc_tile_char(sb, sn, g + P.k - 1 - t, wbase))];
-        }
-        const uint64_t p = out_edge ? (tpc_rotl1(pos, P.L, P.lmask) ^ s_h[i * 5 + c]) : (s_hk[i * 5 + c] ^ pos);
-        const uint64_t n = out_edge ? (neg ^ s_hk[i * 5 + 3 - c]) : (tpc_rotl1(neg, P.L, P.lmask) ^ s_h[i * 5 + 3 - c]);
-        if (p != n) return n < p;
-    }
-    return false;
-}
-
+// Only hash function 0 is rolled here: the first probe of an edge is its function-0 address, the smaller of the
+// two strand values (DetermineStrandExtend / Prepend, vertexrollinghash.h:170-200).  When the two values tie the
+// reference lets functions 1..q-1 pick the strand, but the function-0 address is the same either way, so nothing
+// more is needed at this level; k_q_verify recomputes all q functions, ties included, for the few survivors.
 constexpr int QH_THREADS = 1024;  // two threads per packed word: 16 positions each
 constexpr int QH_RUN = 16;
 
-template <int Q, bool GATED, bool SHARDED>
+template <bool GATED, bool SHARDED>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, int sub_rounds,
@@ -87,11 +70,11 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     Bins<uint64_t, QH_THREADS> bins;
     uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
     uint64_t *s_h = s_b + TW;
-    uint64_t *s_hk = s_h + Q * 5;
-    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + Q * 5);
+    uint64_t *s_hk = s_h + 5;
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + 5);
     bins.init();
     const int tid = threadIdx.x;
-    if (tid < Q * 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }
+    if (tid < 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }  // function 0, letters A C G T N
     const int shift = P.L - LOG_NB;
     const uint32_t wg = blockIdx.x, nwg = gridDim.x;
     // one rank: a workgroup's regions are contiguous ([w][b1]); sharded: destination-major (pt_r1_send)
@@ -100,6 +83,11 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
     const int xw = (P.k + 1) / 32 + 2;
     uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
+    // function 0's table entries of the four letters, as scalars (uniform loads): the eight candidate edges of a
+    // position use them with constant letters, and LDS reads could not be hoisted over the ring traffic
+    uint64_t h0[4], hk0[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { h0[c] = tab[c]; hk0[c] = tab[TPC_TAB_HK + c]; }
     for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
         __syncthreads();
         const uint64_t wfirst = tile * PT_THREADS;
@@ -145,21 +133,13 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 {   // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200)
-                                    const uint64_t p0 = s_hk[c] ^ v.pos[0];
-                                    const uint64_t n0 = r1n ^ s_h[3 - c];
-                                    bool neg = n0 < p0;
-                                    if (p0 == n0 && c != c_prev) neg = q_tie_break<Q>(P, s_h, s_hk, s_b, s_n, g, wbase, c, false);
-                                    const uint64_t a0 = perm.fwd(neg ? n0 : p0);  // permuted address from here on
+                                    const uint64_t a0 = perm.fwd(tpc_min(hk0[c] ^ v.pos[0], r1n ^ h0[3 - c]));  // permuted address from here on
                                     eb[c] = (uint32_t)(a0 >> shift);
                                     ev[c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)c) << QE_E_SHIFT);
                                     eok[c] = c != c_prev;
                                 }
                                 {   // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184)
-                                    const uint64_t p0 = r1p ^ s_h[c];
-                                    const uint64_t n0 = v.neg[0] ^ s_hk[3 - c];
-                                    bool neg = n0 < p0;
-                                    if (p0 == n0 && c != c_next) neg = q_tie_break<Q>(P, s_h, s_hk, s_b, s_n, g, wbase, c, true);
-                                    const uint64_t a0 = perm.fwd(neg ? n0 : p0);
+                                    const uint64_t a0 = perm.fwd(tpc_min(r1p ^ h0[c], v.neg[0] ^ hk0[3 - c]));
                                     eb[4 + c] = (uint32_t)(a0 >> shift);
                                     ev[4 + c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)(4 + c)) << QE_E_SHIFT);
                                     eok[4 + c] = c != c_next;
@@ -193,7 +173,7 @@ template <bool SHARDED>
 __global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
-          PtShard sh, uint32_t prev_wpb, int log_prev_nb2)
+          PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap)
 {   // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -218,49 +198,60 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     auto reg = [buf2, s_off](uint32_t b) { const uint64_t o = s_off[b]; return PtRegion<uint64_t>{buf2 + o, s_off[b + 1] - o}; };
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
     __syncthreads();
-    // rounds of `loads` x QS_THREADS entries over the source regions; the loads of the next TWO rounds are in flight while a
-    // round is binned and flushed (one round ahead left ~32 KB per CU outstanding, short of what HBM latency needs)
-    struct Cursor { uint32_t w, base, n; };
-    auto first = [&](uint32_t w0) {
-        Cursor c{w0, 0u, 0u};
-        c.n = c.w < nvw ? cnt1[r1(c.w)] : 0;
-        while (c.w < nvw && c.n == 0) { c.w += wpb; c.n = c.w < nvw ? cnt1[r1(c.w)] : 0; }
-        return c;
-    };
-    auto next = [&](Cursor c) {
-        c.base += (uint32_t)loads * QS_THREADS;
-        if (c.base >= c.n) {
-            c.base = 0;
-            do { c.w += wpb; c.n = c.w < nvw ? cnt1[r1(c.w)] : 0; } while (c.w < nvw && c.n == 0);
-        }
-        return c;
-    };
-    auto load = [&](uint64_t (&dst)[LOADS], const Cursor &c) {
-        const uint64_t *src = buf1 + r1(c.w) * cap1;
+    // rounds of `loads` x QS_THREADS entries over the source regions (j, j + wpb, ...), taken from the round schedule; the
+    // loads of the next TWO rounds are in flight while a round is binned and flushed (one round ahead left ~32 KB per CU
+    // outstanding, short of what HBM latency needs).  Every round issues exactly LOADS unpredicated loads (lanes past the
+    // end read entry 0 and are masked when the round is consumed -- a select right after the load would make its result
+    // needed at once) and the three buffers rotate by name, not by copies.
+    const uint32_t nreg = j < nvw ? (nvw - j + wpb - 1) / wpb : 0;
+    const uint32_t step = (uint32_t)loads * QS_THREADS;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_off + NB2 + 1);  // [nreg_cap]
+    uint32_t *s_sched = s_cnt + nreg_cap;                             // [sched_cap]
+    struct Round { uint32_t t, base, n; };  // region (j + t * wpb), first entry of the round, entries in the region; all scalar
+    uint64_t va[LOADS], vb[LOADS], vc[LOADS];
+    for (uint32_t skip = 0;; skip += sched_cap) {
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<QS_THREADS>(
+            nreg, step, skip, sched_cap, s_cnt, s_sched, bins.scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+        const uint32_t n_seg = min(total - min(total, skip), sched_cap);
+        auto round_at = [&](uint32_t r) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
+            Round x{e & 0xFFFFu, (e >> 16) * step, 0u};
+            if (r < n_seg) x.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[x.t]);
+            return x;
+        };
+        auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * QS_THREADS + threadIdx.x < x.n; };
+        auto load = [&](uint64_t (&dst)[LOADS], const Round &x) {
+            const uint64_t *src = buf1 + r1(j + x.t * wpb) * cap1;
 #pragma unroll
-        for (int i = 0; i < LOADS; i++) {
-            const uint32_t idx = c.base + i * QS_THREADS + threadIdx.x;
-            dst[i] = (i < loads && idx < c.n) ? src[idx] : SENT;
-        }
-    };
-    uint64_t v[LOADS], v1[LOADS], v2[LOADS];
-    Cursor c0 = first(j), c1 = c0, c2 = c0;
-    if (c0.w < nvw) { load(v, c0); c1 = next(c0); }
-    if (c0.w < nvw && c1.w < nvw) { load(v1, c1); c2 = next(c1); } else c2 = c1;
-    while (c0.w < nvw) {
-        if (c1.w < nvw && c2.w < nvw) load(v2, c2);
-        {
-            uint32_t bb[LOADS];
-            bool ok[LOADS];
+            for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * QS_THREADS + threadIdx.x : 0u];
+        };
+        if (n_seg) {
+            Round x0 = round_at(0), x1 = round_at(1);
+            load(va, x0);
+            load(vb, x1);
+            uint32_t r = 0;
+            auto round = [&](uint64_t (&cur)[LOADS], uint64_t (&pre)[LOADS]) {
+                const Round x2 = round_at(r + 2);
+                load(pre, x2);
+                uint32_t bb[LOADS];
+                bool ok[LOADS];
 #pragma unroll
-            for (int i = 0; i < LOADS; i++) { ok[i] = v[i] != SENT; bb[i] = (uint32_t)((v[i] & rem_mask) >> slice_bits); }
-            bins.template push_batch<LOADS>(bb, v, ok, lost);
+                for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != SENT; bb[i] = (uint32_t)((cur[i] & rem_mask) >> slice_bits); }
+                bins.template push_batch<LOADS>(bb, cur, ok, lost);
+                bins.flush(false, reg, lost);
+                x0 = x1; x1 = x2; r++;
+            };
+            while (true) {
+                if (r >= n_seg) break;
+                round(va, vc);
+                if (r >= n_seg) break;
+                round(vb, va);
+                if (r >= n_seg) break;
+                round(vc, vb);
+            }
         }
-        bins.flush(false, reg, lost);
-#pragma unroll
-        for (int i = 0; i < LOADS; i++) { v[i] = v1[i]; v1[i] = v2[i]; }
-        c0 = c1; c1 = c2;
-        if (c1.w < nvw) c2 = next(c1);
+        if (total <= skip + sched_cap) break;
+        pt_barrier_lds();  // every wave is done with this segment of the schedule
     }
     bins.flush(true, reg, lost);
     bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
@@ -732,17 +723,16 @@ k_select(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8
     }
 }
 
-template <int Q>
 void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
 {
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)Q * 5 * 16 + 64;
+    const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)5 * 16 + 64;
 #define TPC_QHASH_GO(G, S)                                                                                                                  \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_q_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-        hipLaunchKernelGGL((k_q_hash<Q, G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
+        (void)hipFuncSetAttribute((const void *)k_q_hash<G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        hipLaunchKernelGGL((k_q_hash<G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,              \
                            pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
     } while (0)
@@ -878,17 +868,8 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
 
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
 {
-    switch (a.P.q) {
-    case 1: launch_qhash<1>(a, pl, gated, lo, hi, rmask); break;
-    case 2: launch_qhash<2>(a, pl, gated, lo, hi, rmask); break;
-    case 3: launch_qhash<3>(a, pl, gated, lo, hi, rmask); break;
-    case 4: launch_qhash<4>(a, pl, gated, lo, hi, rmask); break;
-    case 5: launch_qhash<5>(a, pl, gated, lo, hi, rmask); break;
-    case 6: launch_qhash<6>(a, pl, gated, lo, hi, rmask); break;
-    case 7: launch_qhash<7>(a, pl, gated, lo, hi, rmask); break;
-    case 8: launch_qhash<8>(a, pl, gated, lo, hi, rmask); break;
-    default: return -1;
-    }
+    if (a.P.q < 1 || a.P.q > 8) return -1;  // k_q_verify is instantiated for 1..8 functions
+    launch_qhash(a, pl, gated, lo, hi, rmask);
     return 0;
 }
 
@@ -898,19 +879,26 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     const PtShard sh{pl.rank, pl.world};
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-        const size_t lds = Bins<uint64_t, QS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
-        (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds_base = Bins<uint64_t, QS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
-        if (pl.world > 1)
+        uint32_t nreg_cap, sched_cap;
+        size_t lds;
+        pt_schedule_dims(pl.nwg1 * pl.world, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+        if (pl.world > 1) {
+            (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
-        else
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
-        if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
+        }
+        if (pl.b3) {  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
+            pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)pl.loads3 * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
-                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2);
+                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2, nreg_cap, sched_cap);
+        }
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
@@ -937,10 +925,13 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     const PtShard sh{0, 1};
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     {
-        const size_t lds = Bins<uint64_t, QS_THREADS>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
+        const size_t lds_base = Bins<uint64_t, QS_THREADS>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
+        uint32_t nreg_cap, sched_cap;
+        size_t lds;
+        pt_schedule_dims(pl.nwg1, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
         (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits,
-                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0);
+                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
