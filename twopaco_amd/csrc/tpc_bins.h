@@ -151,6 +151,50 @@ __device__ __forceinline__ uint32_t pt_build_schedule(uint32_t nreg, uint32_t st
 template <class T>
 struct PtRegion { T *base; uint64_t cap; };
 
+// Streams a region written by Bins (16-byte aligned, its count a multiple of the flush group, padded with the all-ones
+// sentinel) through f(entry): 16 bytes per lane and load, unpredicated, two batches of UNR loads in flight per lane.  n must
+// be uniform over the workgroup.  (One batch at a time with predicated loads left ~32 KB per CU in flight, short of the
+// bandwidth-delay product; the compiler also has to wait with vmcnt(0) after predicated loads.)
+template <int THREADS, int UNR, class T, class F>
+__device__ __forceinline__ void pt_stream_region(const T *__restrict__ src, uint32_t n, F f)
+{
+    constexpr int EPL = 16 / (int)sizeof(T);
+    constexpr T SENT = (T)~(T)0;
+    constexpr uint32_t STEP = UNR * THREADS;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    const uint32_t n4 = (n + EPL - 1) / EPL;
+    if (n4 == 0) return;
+    uint4 a[UNR], b[UNR];
+    auto ld = [&](uint4 (&d)[UNR], uint32_t i0) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) d[u] = src4[min(i0 + u * THREADS + threadIdx.x, n4 - 1u)];
+    };
+    auto use = [&](const uint4 (&d)[UNR], uint32_t i0) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const uint32_t idx = i0 + u * THREADS + threadIdx.x;
+            if (idx < n4) {
+                union { uint4 q; T e[EPL]; } x;
+                x.q = d[u];
+#pragma unroll
+                for (int e = 0; e < EPL; e++) if (x.e[e] != SENT && idx * EPL + e < n) f(x.e[e]);
+            }
+        }
+    };
+    ld(a, 0);
+    for (uint32_t i0 = 0;; i0 += 2 * STEP) {
+        const bool more1 = i0 + STEP < n4;
+        if (more1) ld(b, i0 + STEP);
+        use(a, i0);
+        if (!more1) break;
+        const bool more2 = i0 + 2 * STEP < n4;
+        if (more2) ld(a, i0 + 2 * STEP);
+        use(b, i0 + STEP);
+        if (!more2) break;
+    }
+}
+
+
 // LDS bins: each bin is a ring of CAP entries.  Only whole groups of GROUP entries leave the
 // workgroup, so every global write is a full aligned 128-byte line; the < GROUP leftovers simply stay
 // in the ring.  A flush is two short data-parallel phases: one bookkeeping thread per bin builds the

@@ -245,19 +245,8 @@ k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restri
     __syncthreads();
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        const uint32_t *src = buf2 + r * cap2;
-        const uint32_t n = cnt2[r];
-        for (uint32_t i0 = 0; i0 < n; i0 += 8 * PT_APPLY_THREADS) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
-                v[u] = i < n ? src[i] : PT_SENT;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (v[u] != PT_SENT) atomicOr(&slice[v[u] >> 5], 1u << (v[u] & 31u));
-        }
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+        pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + r * cap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
     }
     __syncthreads();
     if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];

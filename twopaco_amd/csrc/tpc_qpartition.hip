@@ -305,30 +305,18 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     };
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        const uint64_t *src = buf2 + off2[r];
-        const uint32_t n = cnt2[r];
-        for (uint32_t i0 = 0; i0 < n; i0 += 4 * PT_APPLY_THREADS) {
-            uint64_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
-                v[u] = i < n ? src[i] : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (v[u] != ~0ull) {
-                    const uint32_t a = (uint32_t)v[u] & slice_mask;
-                    if ((slice[a >> 5] >> (a & 31u)) & 1u) {
-                        const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
-                        if (slot < (uint32_t)QL_STAGE) stage[slot] = v[u] >> QE_E_SHIFT;
-                        else {  // staging full (dense hits): straight to the sub-list
-                            const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
-                            if (o < surv_cap) my_list[o] = v[u] >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
-                        }
-                    }
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+        pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, [&](uint64_t v) {
+            const uint32_t a = (uint32_t)v & slice_mask;
+            if ((slice[a >> 5] >> (a & 31u)) & 1u) {
+                const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
+                if (slot < (uint32_t)QL_STAGE) stage[slot] = v >> QE_E_SHIFT;
+                else {  // staging full (dense hits): straight to the sub-list
+                    const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
+                    if (o < surv_cap) my_list[o] = v >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
                 }
             }
-        }
+        });
         __syncthreads();
         const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
         __syncthreads();  // everyone has read the count before anyone stages more
@@ -367,19 +355,8 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     __syncthreads();
     for (uint32_t j = 0; j < iwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
-        const uint32_t *src = ibuf2 + r * icap2;
-        const uint32_t n = icnt2[r];
-        for (uint32_t i0 = 0; i0 < n; i0 += 8 * PT_APPLY_THREADS) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
-                v[u] = i < n ? src[i] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (v[u] != 0xFFFFFFFFu) atomicOr(&slice[v[u] >> 5], 1u << (v[u] & 31u));
-        }
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
+        pt_stream_region<PT_APPLY_THREADS, 2>(ibuf2 + r * icap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
     }
     // the insert's few overflow entries (permuted addresses that found a ring or region full): every workgroup picks out its own
     for (uint32_t i = threadIdx.x; i < n_iovf; i += PT_APPLY_THREADS) {
@@ -414,30 +391,18 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     };
     for (uint32_t j = 0; j < qwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
-        const uint64_t *src = qbuf2 + qoff2[r];
-        const uint32_t n = qcnt2[r];
-        for (uint32_t i0 = 0; i0 < n; i0 += 4 * PT_APPLY_THREADS) {
-            uint64_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = i0 + u * PT_APPLY_THREADS + threadIdx.x;
-                v[u] = i < n ? src[i] : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (v[u] != ~0ull) {
-                    const uint32_t a = (uint32_t)v[u] & slice_mask;
-                    if ((slice[a >> 5] >> (a & 31u)) & 1u) {
-                        const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
-                        if (slot < (uint32_t)QL_STAGE) stage[slot] = v[u] >> QE_E_SHIFT;
-                        else {
-                            const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
-                            if (o < surv_cap) my_list[o] = v[u] >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
-                        }
-                    }
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
+        pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], n, [&](uint64_t v) {
+            const uint32_t a = (uint32_t)v & slice_mask;
+            if ((slice[a >> 5] >> (a & 31u)) & 1u) {
+                const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
+                if (slot < (uint32_t)QL_STAGE) stage[slot] = v >> QE_E_SHIFT;
+                else {  // staging full (dense hits): straight to the sub-list
+                    const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
+                    if (o < surv_cap) my_list[o] = v >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
                 }
             }
-        }
+        });
         __syncthreads();
         const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
         __syncthreads();
