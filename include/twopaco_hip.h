@@ -187,6 +187,13 @@ void tpc_host_free(void *ptr);
  *   tpc_shard_apply    levels 2-3 over the received blocks: insert ORs the owned slices; query
  *                      tests the first probe of every received edge and keeps the hits as the
  *                      survivor list (*n_survivors; ids relative to the batch)
+ *   tpc_shard_pack / tpc_shard_apply_packed   exact-size exchange instead of the equal blocks: the regions have a fixed
+ *                      capacity and are ~3/4 full, so after tpc_shard_hash the used prefix of every region is packed
+ *                      (block d of packed_dev = the entries for rank d, bytes_per_dest_host[d] bytes, a multiple of 128);
+ *                      the host layer moves the count blocks as before (equal all_to_all) and the packed blocks with a
+ *                      variable all_to_all, source blocks back to back in rank order, and tpc_shard_apply_packed places
+ *                      every received region by a scan of the received counts.  packed_dev holds up to world blocks of
+ *                      geom[2] bytes (as the region buffer)
  *   tpc_shard_survivors       copy the survivor ids to a device buffer
  *   tpc_shard_survivor_sources   the rank that hashed each survivor's position (it rides in the id): survivors go BACK to
  *                             that rank (route + variable all_to_all) and are verified there, where their text is -- a
@@ -215,6 +222,8 @@ int tpc_shard_hash(tpc_ctx *ctx, int pass, uint64_t batch, uint64_t lo, uint64_t
 int tpc_shard_overflow_get(tpc_ctx *ctx, int pass, void *dst_dev, uint64_t n);
 int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t n);
 int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
+int tpc_shard_pack(tpc_ctx *ctx, int pass, const void *send_regions_dev, const void *send_counts_dev, void *packed_dev, uint64_t *bytes_per_dest_host);
+int tpc_shard_apply_packed(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_packed_dev, const void *recv_counts_dev, uint64_t *n_survivors);
 int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
 int tpc_shard_survivor_sources(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n, int32_t *source_dev);
 int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);

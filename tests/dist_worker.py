@@ -106,7 +106,7 @@ def addr_worker(rank, world, port, spec, result_path):
             ctx.set_option(opt, val)
         ctx.set_params(sp["k"], sp["L"], sp["q"], capi.seed_table(sp["q"], sp["L"], seed=sp["seed"]))
         ctx.seq_upload(text)
-        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0))
+        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True))
         out = {"rounds": []}
         for lo, hi in sp["ranges"]:
             geom = sh.insert(lo, hi)
@@ -115,7 +115,7 @@ def addr_worker(rank, world, port, spec, result_path):
             out["rounds"].append({"geom": geom, "qgeom": qgeom, "shard": shard, "mask": ctx.mask_download(False),
                                   "survivors": sh.stats["survivors"]})
         st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True)
-        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], moved=sh.comm.bytes_moved)
+        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], moved=sh.comm.bytes_moved, region_bytes_sent=sh.stats.get("region_bytes_sent", 0))
         gathered = [None] * world
         dist.all_gather_object(gathered, out)
         results.append(gathered)

@@ -115,6 +115,25 @@ def test_address_sharded_synthetic_batches(world, budget, tmp_path):
     check(spec, o, gathered, world)
 
 
+def test_compacted_exchange_moves_fewer_bytes(tmp_path):
+    """The exact-size exchange (tpc_shard_pack / tpc_shard_apply_packed) and the equal-block exchange give the same filter,
+    masks and ids; the packed one puts fewer region bytes on the wire (the fixed-capacity regions are about 3/4 full)."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.02)
+    base = {"workload": "m1", "scale": 0.02, "k": 25, "L": 28, "q": 5, "seed": 12, "ranges": [(0, 1 << 28)], "abundance": (1 << 64) - 1,
+            "options": {"slice_bits": 14}}
+    specs = [dict(base, compact_exchange=True), dict(base, compact_exchange=False)]
+    o = O.Oracle(25, 28, 5, O.seed_table(12, 5, 28))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    results = run(specs, 2, tmp_path)
+    for sp, gathered in zip(specs, results):
+        check(sp, o, gathered, 2)
+    packed, equal = results[0][0]["region_bytes_sent"], results[1][0]["region_bytes_sent"]
+    assert 0 < packed < 0.9 * equal, (packed, equal)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_address_sharded_randomized(world, tmp_path):
     """Random texts (N runs, skew) x random k, L, q, slice size, tile batches and gated ranges, all in one process group."""
@@ -140,7 +159,7 @@ def test_address_sharded_randomized(world, tmp_path):
         size = 1 << L
         cut = sorted(int(x) for x in rng.integers(0, size, 2))
         specs.append({"records": recs, "k": k, "L": L, "q": q, "seed": int(rng.integers(1, 1 << 40)), "ranges": [(0, size), (cut[0], cut[1])],
-                      "abundance": (1 << 64) - 1,
+                      "abundance": (1 << 64) - 1, "compact_exchange": trial % 3 != 2,  # both the exact-size and the equal-block exchange
                       "options": {"slice_bits": slice_bits, "part_min_tiles": 1, "part_budget_bytes": int(rng.choice([40 << 30, 1 << 20]))}})
     results = run(specs, world, tmp_path)
     for sp, gathered in zip(specs, results):

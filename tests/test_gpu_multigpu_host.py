@@ -109,6 +109,20 @@ def test_m1_full_four_emulated_ranks(capi, tmp_path):
     e.close()
 
 
+@pytest.mark.parametrize("name,ranks", [("rand6_k25_q3", 4), ("m2_small", 2)])
+def test_emulated_ranks_equal_block_exchange(capi, tmp_path, name, ranks, monkeypatch):
+    """The equal-block exchange of the level-1 regions (testing knob TWOPACO_EQUAL_EXCHANGE) gives the same bytes as the
+    default exact-size exchange covered by test_emulated_ranks_write_reference_bytes."""
+    monkeypatch.setenv("TWOPACO_EQUAL_EXCHANGE", "1")
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    e.close()
+
+
 def test_cli_gpus_flag(tmp_path):
     case = CASES["rand6_k9_fp_r4"]
     exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")

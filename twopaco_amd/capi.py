@@ -19,6 +19,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
+               "tpc_shard_pack", "tpc_shard_apply_packed",
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
@@ -82,6 +83,8 @@ def hip():
         L.tpc_shard_overflow_get.argtypes = [p, ci, p, u64]
         L.tpc_shard_overflow_set.argtypes = [p, ci, p, u64]
         L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]
+        L.tpc_shard_pack.argtypes = [p, ci, p, p, p, p]
+        L.tpc_shard_apply_packed.argtypes = [p, ci, u64, p, p, p]
         L.tpc_shard_survivors.argtypes = [p, p]
         L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
         L.tpc_shard_survivor_sources.argtypes = [p, p, u64, p]
@@ -389,6 +392,17 @@ class Context:
     def shard_apply(self, which, batch, recv_regions_ptr, recv_counts_ptr):
         n = ctypes.c_uint64(0)
         self._ck(hip().tpc_shard_apply(self._h, which, batch, recv_regions_ptr, recv_counts_ptr, ctypes.byref(n)))
+        return n.value
+
+    def shard_pack(self, which, send_regions_ptr, send_counts_ptr, packed_ptr, world):
+        """Used prefixes of the level-1 regions, destination major; returns the bytes for every destination rank."""
+        out = (ctypes.c_uint64 * world)()
+        self._ck(hip().tpc_shard_pack(self._h, which, send_regions_ptr, send_counts_ptr, packed_ptr, out))
+        return [int(x) for x in out]
+
+    def shard_apply_packed(self, which, batch, recv_packed_ptr, recv_counts_ptr):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_apply_packed(self._h, which, batch, recv_packed_ptr, recv_counts_ptr, ctypes.byref(n)))
         return n.value
 
     def shard_survivors(self, sid_ptr):

@@ -67,6 +67,8 @@ struct tpc_ctx {
     // scalars
     unsigned long long *counters = nullptr;  // device, 8 words
     unsigned long long *route_scratch = nullptr;  // device, 128 words: tpc_shard_route's per-owner counts and cursors
+    uint64_t *sh_off = nullptr;  // device, [regions + 1]: offsets of the level-1 regions in a packed buffer (compacted exchange)
+    size_t sh_off_bytes = 0;
     // options
     int opt_test_first = 0;
     int opt_insert_mode = 0;   // 0 auto, 1 direct atomicOr, 2 partitioned (LDS write-combining)
@@ -306,7 +308,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = { c->tab, c->bases_alloc, c->nmask_alloc, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
-                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->route_scratch, c->scan_blocks, c->sort_scratch };
+                     c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->route_scratch, c->sh_off, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
@@ -1216,15 +1218,78 @@ int tpc_shard_overflow_set(tpc_ctx *c, int pass, const void *src, uint64_t n)
     return 0;
 }
 
+namespace {
+
+// level-1 regions of a sharded pass: [rank][local bucket][workgroup], the same number on the sending and the receiving side
+uint32_t shard_regions(const tpc_ctx *c, int pass)
+{
+    return pass == TPC_SHARD_INSERT ? c->sh_ipl.nwg1 << c->sh_ipl.b1 : c->sh_qpl.nwg1 << c->sh_qpl.b1;
+}
+
+bool ensure_shard_offsets(tpc_ctx *c, uint32_t n_regions)
+{
+    const size_t need = ((size_t)n_regions + 1) * sizeof(uint64_t);
+    if (c->sh_off_bytes >= need) return true;
+    if (c->sh_off) (void)hipFree(c->sh_off);
+    c->sh_off = nullptr; c->sh_off_bytes = 0;
+    if (hipMalloc((void **)&c->sh_off, need) != hipSuccess) { (void)hipGetLastError(); return false; }
+    c->sh_off_bytes = need;
+    return true;
+}
+
+int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors);
+
+}  // namespace
+
 int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, uint64_t *n_survivors)
+{
+    return shard_apply_impl(c, pass, batch, recv_regions, recv_counts, false, n_survivors);
+}
+
+int tpc_shard_apply_packed(tpc_ctx *c, int pass, uint64_t batch, const void *recv_packed, const void *recv_counts, uint64_t *n_survivors)
+{
+    return shard_apply_impl(c, pass, batch, recv_packed, recv_counts, true, n_survivors);
+}
+
+int tpc_shard_pack(tpc_ctx *c, int pass, const void *send_regions, const void *send_counts, void *packed, uint64_t *bytes_per_dest)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
+    if (!send_regions || !send_counts || !packed || !bytes_per_dest) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = shard_regions(c, pass), W = c->sh_world, block = n / W;
+    const uint32_t eb = pass == TPC_SHARD_INSERT ? 4 : 8;
+    const uint64_t cap1 = pass == TPC_SHARD_INSERT ? c->sh_ipl.cap1 : c->sh_qpl.cap1;
+    if (!ensure_shard_offsets(c, n)) return fail(c, -10, "out of device memory for the region offsets");
+    const TpcLaunch a = make_launch(c);
+    tpc_launch_region_offsets(a, (const uint32_t *)send_counts, n, c->sh_off);
+    if (tpc_launch_region_pack(a, send_regions, cap1, eb, (const uint32_t *)send_counts, c->sh_off, n, packed)) return fail(c, -1, "pack launch failed");
+    // the regions of destination d are the index range [d * block, (d + 1) * block): its share of the packed buffer
+    std::vector<uint64_t> edge(W + 1);
+    HIPCHK(c, hipMemcpy2DAsync(edge.data(), sizeof(uint64_t), c->sh_off, (size_t)block * sizeof(uint64_t), sizeof(uint64_t), W + 1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's collective runs on another stream
+    for (uint32_t d = 0; d < W; d++) bytes_per_dest[d] = (edge[d + 1] - edge[d]) * eb;
+    return 0;
+}
+
+namespace {
+
+int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors)
 {
     if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
     if (!recv_regions || !recv_counts || batch >= c->sh_batches[pass]) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t *roff1 = nullptr;
+    if (packed) {  // the blocks of the source ranks follow one another: the scan over [source][local bucket][workgroup] places every region
+        const uint32_t n = shard_regions(c, pass);
+        if (!ensure_shard_offsets(c, n)) return fail(c, -10, "out of device memory for the region offsets");
+        tpc_launch_region_offsets(make_launch(c), (const uint32_t *)recv_counts, n, c->sh_off);
+        roff1 = c->sh_off;
+    }
     unsigned long long ov[2] = {0, 0};
     if (pass == TPC_SHARD_INSERT) {
         TpcPartPlan pl = c->sh_ipl;
-        pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts;
+        pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
         {
             Timed t(c, TPC_K_SHARD_APPLY);
             if (tpc_launch_insert_part_apply(make_launch(c), pl, c->filter_zero_pending)) return fail(c, -1, "apply launch failed");
@@ -1238,7 +1303,7 @@ int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regio
         return 0;
     }
     TpcQPlan pl = c->sh_qpl;
-    pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts;
+    pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
     const uint64_t chunk = (tiles + W - 1) / W;
     pl.tile0_global = std::min(tiles, c->sh_rank * chunk) + batch * per;
@@ -1259,6 +1324,8 @@ int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regio
     if (n_survivors) *n_survivors = ns;
     return 0;
 }
+
+}  // namespace
 
 int tpc_shard_survivors(tpc_ctx *c, uint64_t *sid_dev)
 {

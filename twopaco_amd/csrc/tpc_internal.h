@@ -43,6 +43,7 @@ struct TpcPartPlan {
     // kernel reads (== buf1 / cnt1 when world == 1, the all_to_all receive buffers otherwise)
     uint32_t rank = 0, world = 1;
     const uint32_t *rbuf1 = nullptr, *rcnt1 = nullptr;
+    const uint64_t *roff1 = nullptr;  // packed receive buffer: first entry of every received level-1 region (else region index * cap1)
 };
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch; levels 0 = auto
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
@@ -88,6 +89,7 @@ struct TpcQPlan {
     uint32_t rank = 0, world = 1;  // filter sharding, as in TpcPartPlan
     const uint64_t *rbuf1 = nullptr;
     const uint32_t *rcnt1 = nullptr;
+    const uint64_t *roff1 = nullptr;  // packed receive buffer, as in TpcPartPlan
 };
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
@@ -99,6 +101,12 @@ int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl,
 int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, uint32_t n_iovf);
 #define TPC_FUSE_MAX_OVF 4096u  // insert overflow entries the fused kernel still folds in (every workgroup scans the list)  // k_q_split + k_apply_lookup + k_q_ovf
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
+// compacted exchange of the sharded path: off[i] = entries before region i (off[n] = all of them), in 16-byte units of
+// `entry_bytes`-byte entries -- counts written by Bins are whole flush groups, so every region stays 128-byte aligned;
+// pack copies the used prefix of every fixed-capacity region to its offset
+int tpc_launch_region_offsets(const TpcLaunch &a, const uint32_t *cnt, uint32_t n_regions, uint64_t *off);
+int tpc_launch_region_pack(const TpcLaunch &a, const void *regions, uint64_t cap_entries, uint32_t entry_bytes, const uint32_t *cnt, const uint64_t *off,
+                           uint32_t n_regions, void *packed);
 // halves for the sharded path: hash (level 1, marks N-adjacent vertices in rmask), then split + lookup on
 // the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);

@@ -142,7 +142,7 @@ template <bool SHARDED>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
              uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads,
-             uint32_t nreg_cap, uint32_t sched_cap)
+             uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1)
 {   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
     // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,7 +188,8 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         };
         auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * PS_THREADS + threadIdx.x < x.n; };
         auto load = [&](uint32_t (&dst)[LOADS], const Round &x) {
-            const uint32_t *src = buf1 + r1(j + x.t * wpb) * cap1;
+            const uint64_t ri = r1(j + x.t * wpb);
+            const uint32_t *src = buf1 + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
 #pragma unroll
             for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * PS_THREADS + threadIdx.x : 0u];
         };
@@ -306,20 +307,54 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
     if (pl.world > 1) {
         (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1);
     } else {
         (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1);
     }
     if (pl.b3) {  // third level: bucket (b1, b2), input = the regions written above
         const int loads3 = split_loads(pl.b3);
         pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)loads3 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
         (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
-                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap);
+                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap, (const uint64_t *)nullptr);
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ compacted exchange
+// off[i] = sum of cnt[0..i) (entries), off[n] = total: one workgroup, every thread sums a run of regions.
+__global__ void __launch_bounds__(1024) k_region_offsets(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off)
+{
+    __shared__ unsigned long long s_w[16];
+    const uint32_t per = (n + 1023u) / 1024u, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = i0; i < i1; i++) sum += cnt[i];
+    unsigned long long inc = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int i = 0; i < 16; i++) { const unsigned long long x = s_w[i]; if (i < wv) base += x; tot += x; }
+    unsigned long long run = base + inc - sum;
+    for (uint32_t i = i0; i < i1; i++) { off[i] = run; run += cnt[i]; }
+    if (threadIdx.x == 0) off[n] = tot;
+}
+
+// One workgroup per region: the used prefix (a whole number of 16-byte units) moves to its packed position.
+__global__ void __launch_bounds__(256) k_region_pack(const uint4 *__restrict__ regions, uint64_t cap16, uint32_t per16, const uint32_t *__restrict__ cnt,
+                                                     const uint64_t *__restrict__ off, uint4 *__restrict__ packed)
+{   // per16: entries per 16 bytes
+    const uint32_t r = blockIdx.x;
+    const uint32_t n16 = (cnt[r] + per16 - 1) / per16;
+    const uint4 *src = regions + (uint64_t)r * cap16;
+    uint4 *dst = packed + off[r] / per16;
+    for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
 }
 
 }  // namespace
@@ -446,3 +481,19 @@ int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl0, ui
 // tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_partition() {}
 void tpc_warm_partition(hipStream_t s) { hipLaunchKernelGGL(k_warm_partition, dim3(1), dim3(64), 0, s); }
+
+int tpc_launch_region_offsets(const TpcLaunch &a, const uint32_t *cnt, uint32_t n_regions, uint64_t *off)
+{
+    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, a.stream, cnt, n_regions, off);
+    return 0;
+}
+
+int tpc_launch_region_pack(const TpcLaunch &a, const void *regions, uint64_t cap_entries, uint32_t entry_bytes, const uint32_t *cnt, const uint64_t *off,
+                           uint32_t n_regions, void *packed)
+{
+    if ((entry_bytes != 4 && entry_bytes != 8) || (cap_entries * entry_bytes) % 16) return -1;
+    if (n_regions)
+        hipLaunchKernelGGL(k_region_pack, dim3(n_regions), dim3(256), 0, a.stream, (const uint4 *)regions, cap_entries * entry_bytes / 16, 16u / entry_bytes, cnt, off,
+                           (uint4 *)packed);
+    return 0;
+}

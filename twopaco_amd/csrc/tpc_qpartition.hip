@@ -173,7 +173,7 @@ template <bool SHARDED>
 __global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
-          PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap)
+          PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1)
 {   // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -221,7 +221,8 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         };
         auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * QS_THREADS + threadIdx.x < x.n; };
         auto load = [&](uint64_t (&dst)[LOADS], const Round &x) {
-            const uint64_t *src = buf1 + r1(j + x.t * wpb) * cap1;
+            const uint64_t ri = r1(j + x.t * wpb);
+            const uint64_t *src = buf1 + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
 #pragma unroll
             for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * QS_THREADS + threadIdx.x : 0u];
         };
@@ -852,17 +853,17 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         if (pl.world > 1) {
             (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
         } else {
             (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
+                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
         }
         if (pl.b3) {  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
             pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)pl.loads3 * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
             (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
-                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2, nreg_cap, sched_cap);
+                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2, nreg_cap, sched_cap, (const uint64_t *)nullptr);
         }
     }
     {
@@ -896,7 +897,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         pt_schedule_dims(pl.nwg1, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
         (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits,
-                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap);
+                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);

@@ -277,9 +277,10 @@ class AddressSharded:
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
     list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
 
-    def __init__(self, ctx, dist, device):
+    def __init__(self, ctx, dist, device, compact=True):
         import torch
         self.ctx, self.torch = ctx, torch
+        self.compact = compact  # exact-size exchange of the level-1 regions (tpc_shard_pack) instead of equal blocks
         self.comm = _Comm(dist, device)
         self.device = device
         self.rank, self.world = self.comm.rank, self.comm.world
@@ -308,7 +309,19 @@ class AddressSharded:
         n_ovf = self.ctx.shard_hash(which, batch, send_r.data_ptr(), send_c.data_ptr(), lo, hi)
         t0 = self._tick(tag + "_hash", t0)
         recv_c = self.comm.a2a_equal(send_c)
-        recv_r = self.comm.a2a_equal(send_r)
+        if self.compact:
+            # the regions are ~3/4 full: pack their used prefixes, move exactly those (block sizes are multiples of 128 bytes)
+            packed = self._buf("packed", W * geom["region_block_bytes"])
+            nbytes = self.ctx.shard_pack(which, send_r.data_ptr(), send_c.data_ptr(), packed.data_ptr(), W)
+            t0 = self._tick(tag + "_pack", t0)
+            recv_r, _ = self.comm.a2a_var(packed[:sum(nbytes)].view(self.torch.int64), [b // 8 for b in nbytes])
+            recv_r = recv_r.view(self.torch.uint8)
+            if recv_r.numel() == 0:
+                recv_r = self._buf("recv_empty", 16)
+            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + sum(nbytes)
+        else:
+            recv_r = self.comm.a2a_equal(send_r)
+            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + send_r.numel()
         self.comm.sync()
         t0 = self._tick(tag + "_all_to_all", t0)
         # skew path: entries that did not fit their level-1 region, for any owner
@@ -337,7 +350,7 @@ class AddressSharded:
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(INSERT, geom, b, lo, hi)
             t0 = time.perf_counter()
-            self.ctx.shard_apply(INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
+            (self.ctx.shard_apply_packed if self.compact else self.ctx.shard_apply)(INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
             self._tick("insert_apply", t0)
         return geom
 
@@ -348,7 +361,7 @@ class AddressSharded:
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(QUERY, geom, b, lo, hi)
             t0 = time.perf_counter()
-            n = ctx.shard_apply(QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
+            n = (ctx.shard_apply_packed if self.compact else ctx.shard_apply)(QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
             t0 = self._tick("query_apply", t0)
             sid = torch.empty(n, dtype=torch.int64, device=self.device)
             ctx.shard_survivors(sid.data_ptr())

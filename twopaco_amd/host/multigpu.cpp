@@ -303,7 +303,7 @@ namespace TwoPaCo
 	void ShardedRank::Release()
 	{
 		(void)hipSetDevice(device);
-		for (int i = 0; i < 12; i++)
+		for (int i = 0; i < 13; i++)
 		{
 			if (buf[i]) (void)hipFree(buf[i]);
 			buf[i] = 0;
@@ -314,7 +314,7 @@ namespace TwoPaCo
 	// ------------------------------------------------------------------------------------------ the pass
 	namespace
 	{
-		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B };
+		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED };
 
 		// hash -> exchange -> (overflow lists) ; returns the receive buffers in r.buf[RECV_R], r.buf[RECV_C]
 		void HashAndExchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, uint64_t batch, uint64_t lo, uint64_t hi)
@@ -327,7 +327,30 @@ namespace TwoPaCo
 			uint64_t overflow = 0;
 			LibCheck(r.ctx, tpc_shard_hash(r.ctx, pass, batch, lo, hi, sendR, sendC, &overflow), "shard_hash");
 			net.AllToAll(r.rank, sendC, recvC, geom[3]);
-			net.AllToAll(r.rank, sendR, recvR, geom[2]);
+			if (r.compactExchange)
+			{
+				// the fixed-capacity regions are about 3/4 full: pack their used prefixes and move exactly those
+				// (every destination's share is a whole number of 128-byte lines)
+				void * packed = r.Ensure(PACKED, size_t(W) * geom[2]);
+				std::vector<uint64_t> bytes(W), all;
+				LibCheck(r.ctx, tpc_shard_pack(r.ctx, pass, sendR, sendC, packed, bytes.data()), "shard_pack");
+				net.ExchangeHost(r.rank, bytes.data(), W, all);
+				std::vector<uint64_t> sendUnits(W), recvUnits(W);
+				for (int s = 0; s < W; s++)
+				{
+					sendUnits[s] = bytes[s] / 16;
+					recvUnits[s] = all[size_t(s) * W + r.rank] / 16;
+					r.regionBytesSent += bytes[s];
+				}
+
+				net.AllToAllV(r.rank, packed, sendUnits.data(), recvR, recvUnits.data(), 16);
+			}
+			else
+			{
+				net.AllToAll(r.rank, sendR, recvR, geom[2]);
+				r.regionBytesSent += uint64_t(W) * geom[2];
+			}
+
 			// skew path: entries that did not fit their level-1 region travel as one all-gathered list
 			std::vector<uint64_t> all;
 			net.ExchangeHost(r.rank, &overflow, 1, all);
@@ -436,7 +459,7 @@ namespace TwoPaCo
 		for (uint64_t b = 0; b < geom[0]; b++)
 		{
 			HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
-			LibCheck(r.ctx, tpc_shard_apply(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
 		}
 
 		net.Barrier().Wait();  // every shard is complete before anyone probes it
@@ -446,7 +469,7 @@ namespace TwoPaCo
 		{
 			HashAndExchange(r, net, TPC_SHARD_QUERY, geom, b, lo, hi);
 			uint64_t n = 0;
-			LibCheck(r.ctx, tpc_shard_apply(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
 			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
 			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
 			n = ReturnSurvivors(r, net, n);

@@ -78,9 +78,12 @@ namespace TwoPaCo
 		int device;
 		tpc_ctx * ctx;
 		// device scratch owned by the rank (grown on demand, freed by Release)
-		void * buf[12];
-		size_t cap[12];
-		ShardedRank() : rank(0), device(0), ctx(0) { for (int i = 0; i < 12; i++) { buf[i] = 0; cap[i] = 0; } }
+		void * buf[13];
+		size_t cap[13];
+		// exact-size exchange of the level-1 regions (tpc_shard_pack / tpc_shard_apply_packed); false: equal blocks
+		bool compactExchange;
+		uint64_t regionBytesSent;
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), regionBytesSent(0) { for (int i = 0; i < 13; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};

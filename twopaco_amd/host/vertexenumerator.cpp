@@ -228,6 +228,9 @@ namespace TwoPaCo
 					logStream << "GPUs = " << gpus << " (Bloom filter sharded by bit address; transport: " << net->Name() << ")" << std::endl;
 					peers_.resize(gpus);
 					peers_[0].rank = 0; peers_[0].device = devices[0]; peers_[0].ctx = ctx_;
+					// testing knob: TWOPACO_EQUAL_EXCHANGE=1 moves the level-1 regions as equal fixed-capacity blocks instead of packed
+					const bool compact = std::getenv("TWOPACO_EQUAL_EXCHANGE") == 0;
+					for (int r = 0; r < gpus; r++) peers_[r].compactExchange = compact;
 					std::vector<std::string> errors(gpus);
 					std::vector<std::thread> pool;
 					for (int r = 1; r < gpus; r++)
