@@ -21,9 +21,10 @@
 // mark(g) <=> some unknown edge is present: with prev and next definite the known in- and out-edge
 // count 1 each, so "inCount > 1 || outCount > 1" (VE.h:656) holds exactly when one more edge passes
 // all q probes.  The mask is bit-identical to k_query's (tests/test_gpu_parity.py).
-#include "tpc_bins.h"
+#include "tpc_rbins.h"
 #include "tpc_internal.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <cmath>
 
@@ -57,7 +58,11 @@ __device__ __forceinline__ bool within(uint64_t v, uint64_t lo, uint64_t hi) { r
 constexpr int QH_THREADS = 1024;  // two threads per packed word: 16 positions each
 constexpr int QH_RUN = 16;
 
-template <bool GATED, bool SHARDED>
+// RB: barrier-free rings (tpc_rbins.h) instead of the flush-per-round bins.  At 512 bins a ring of the latter holds 32 uint64
+// entries, rounds have to be split over thread subsets and the kernel runs at half the rate of the 256-bin geometry; the
+// barrier-free rings do not care (tools/bins_bench.hip: 5.1 against 28 ms for 1.86 G entries).  Their pushes must be made by
+// whole waves, so this variant computes the candidate edges of every lane and masks the entries instead of branching.
+template <bool GATED, bool SHARDED, bool RB>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, int sub_rounds,
@@ -67,7 +72,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;  // a tile is still 512 packed words
-    Bins<uint64_t, QH_THREADS> bins;
+    typename std::conditional<RB, RBins<uint64_t, QH_THREADS>, Bins<uint64_t, QH_THREADS>>::type bins;
     uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
     uint64_t *s_h = s_b + TW;
     uint64_t *s_hk = s_h + 5;
@@ -101,6 +106,7 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
         const uint64_t g0 = wfirst * TPC_RUN + (uint64_t)tid * QH_RUN;
         const bool active = g0 < n_text;
         TpcVHash<1> v;  // function 0 only
+        v.pos[0] = 0; v.neg[0] = 0;
         int ncnt = 0, c_prev = TPC_CODE_N, c_first = TPC_CODE_N;
         uint32_t word = 0;
         if (active) {
@@ -111,6 +117,46 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
         }
         // a round = pos_per_round positions per thread, or (many small bins) one position for every
         // sub_rounds-th thread, so that a round never outgrows the rings
+        if constexpr (RB) {
+            for (int s = 0; s < QH_RUN; s++) {  // wave-uniform: every lane reaches every push
+                const uint64_t g = g0 + s;
+                const int c_next = tpc_tile_char(s_b, s_n, g + P.k, wbase);
+                const int c_first_nx = tpc_tile_char(s_b, s_n, g + 1, wbase);
+                const uint64_t r1p = tpc_rotl1(v.pos[0], P.L, P.lmask);
+                const uint64_t r1n = tpc_rotl1(v.neg[0], P.L, P.lmask);
+                bool check = active && ncnt == 0;
+                if (GATED) check = check && within(tpc_min(v.pos[0], v.neg[0]), lo, hi);  // VE.h:638
+                const bool nadj = c_prev == TPC_CODE_N || c_next == TPC_CODE_N;
+                if (check && nadj) word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
+                const bool probe = check && !nadj;
+                const uint64_t sid_g = ((g - gbase) | (SHARDED ? (uint64_t)sh.rank << (30u - sh.log_world()) : 0ull)) << 3;
+                uint32_t eb[8];
+                uint64_t ev[8];
+                bool eok[8];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    {   // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200)
+                        const uint64_t a0 = perm.fwd(tpc_min(hk0[c] ^ v.pos[0], r1n ^ h0[3 - c]));
+                        eb[c] = (uint32_t)(a0 >> shift);
+                        ev[c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)c) << QE_E_SHIFT);
+                        eok[c] = probe && c != c_prev;
+                    }
+                    {   // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184)
+                        const uint64_t a0 = perm.fwd(tpc_min(r1p ^ h0[c], v.neg[0] ^ hk0[3 - c]));
+                        eb[4 + c] = (uint32_t)(a0 >> shift);
+                        ev[4 + c] = (a0 & (((uint64_t)1 << shift) - 1)) | ((sid_g | (uint64_t)(4 + c)) << QE_E_SHIFT);
+                        eok[4 + c] = probe && c != c_next;
+                    }
+                }
+                bins.template push_batch<8>(eb, ev, eok, reg, lost);
+                // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113), function 0
+                v.pos[0] = r1p ^ s_h[c_next] ^ s_hk[c_first];
+                v.neg[0] = tpc_rotr1(v.neg[0] ^ s_hk[tpc_rc(c_next)] ^ s_h[tpc_rc(c_first)], P.L);
+                ncnt += (c_next == TPC_CODE_N) - (c_first == TPC_CODE_N);
+                c_prev = c_first;
+                c_first = c_first_nx;
+            }
+        } else
         for (int s0 = 0; s0 < QH_RUN * sub_rounds; s0 += pos_per_round) {
             if (active && (sub_rounds == 1 || (tid % sub_rounds) == (s0 % sub_rounds))) {
                 for (int s = s0 / sub_rounds; s < s0 / sub_rounds + pos_per_round; s++) {
@@ -163,13 +209,13 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     bins.flush(true, reg, lost);
     bins.store_counts(cnt1, reg, ridx);
 #ifdef TPC_PROFILE_PHASES
-    bins.dump(ovf.cursor + 16);
+    if constexpr (!RB) bins.dump(ovf.cursor + 16);
 #endif
 }
 
 // ------------------------------------------------------------------------------------------ B
 constexpr int QS_THREADS = 1024;  // split: 16 waves hide the LDS atomic round trips better than 8
-template <bool SHARDED>
+template <bool SHARDED, bool RB>
 __global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
@@ -179,7 +225,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 4;
     constexpr uint64_t SENT = ~0ull;
-    Bins<uint64_t, QS_THREADS> bins;
+    typename std::conditional<RB, RBins<uint64_t, QS_THREADS>, Bins<uint64_t, QS_THREADS>>::type bins;  // RB: see k_q_hash
     uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
     bins.init();
     for (uint32_t i = threadIdx.x; i <= NB2; i += QS_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
@@ -205,13 +251,14 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     // needed at once) and the three buffers rotate by name, not by copies.
     const uint32_t nreg = j < nvw ? (nvw - j + wpb - 1) / wpb : 0;
     const uint32_t step = (uint32_t)loads * QS_THREADS;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_off + NB2 + 1);  // [nreg_cap]
+    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_off + NB2 + 1);  // [32] scratch of the schedule's block scan
+    uint32_t *s_cnt = s_scan + 32;                                     // [nreg_cap]
     uint32_t *s_sched = s_cnt + nreg_cap;                             // [sched_cap]
     struct Round { uint32_t t, base, n; };  // region (j + t * wpb), first entry of the round, entries in the region; all scalar
     uint64_t va[LOADS], vb[LOADS], vc[LOADS];
     for (uint32_t skip = 0;; skip += sched_cap) {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<QS_THREADS>(
-            nreg, step, skip, sched_cap, s_cnt, s_sched, bins.scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
         const uint32_t n_seg = min(total - min(total, skip), sched_cap);
         auto round_at = [&](uint32_t r) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
@@ -238,7 +285,8 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
                 bool ok[LOADS];
 #pragma unroll
                 for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != SENT; bb[i] = (uint32_t)((cur[i] & rem_mask) >> slice_bits); }
-                bins.template push_batch<LOADS>(bb, cur, ok, lost);
+                if constexpr (RB) bins.template push_batch<LOADS>(bb, cur, ok, reg, lost);
+                else bins.template push_batch<LOADS>(bb, cur, ok, lost);
                 bins.flush(false, reg, lost);
                 x0 = x1; x1 = x2; r++;
             };
@@ -257,7 +305,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     bins.flush(true, reg, lost);
     bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
 #ifdef TPC_PROFILE_PHASES
-    bins.dump(ovf.cursor + 8);
+    if constexpr (!RB) bins.dump(ovf.cursor + 8);
 #endif
 }
 
@@ -689,22 +737,54 @@ k_select(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8
     }
 }
 
+// 512 bins per level (f = 37, 38 at the default slice size): the barrier-free rings (k_q_hash / k_q_split<.., RB = true>)
+inline bool q_use_rbins(int log_nb) { return log_nb >= 9; }
+
 void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t lo, uint64_t hi, uint32_t *rmask)
 {
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)5 * 16 + 64;
-#define TPC_QHASH_GO(G, S)                                                                                                                  \
+    const bool rb = q_use_rbins(pl.b1);
+    const size_t lds = (rb ? RBins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) : Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1)) +
+                       (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)5 * 16 + 64;
+#define TPC_QHASH_GO(G, S, R)                                                                                                               \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_q_hash<G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-        hipLaunchKernelGGL((k_q_hash<G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
+        (void)hipFuncSetAttribute((const void *)k_q_hash<G, S, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        hipLaunchKernelGGL((k_q_hash<G, S, R>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, pl.sub_rounds, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,              \
                            pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
     } while (0)
-    if (pl.world > 1) { if (gated) TPC_QHASH_GO(true, true); else TPC_QHASH_GO(false, true); }
-    else { if (gated) TPC_QHASH_GO(true, false); else TPC_QHASH_GO(false, false); }
+#define TPC_QHASH_GS(R)                                                                                                                     \
+    do {                                                                                                                                    \
+        if (pl.world > 1) { if (gated) TPC_QHASH_GO(true, true, R); else TPC_QHASH_GO(false, true, R); }                                    \
+        else { if (gated) TPC_QHASH_GO(true, false, R); else TPC_QHASH_GO(false, false, R); }                                               \
+    } while (0)
+    if (rb) TPC_QHASH_GS(true); else TPC_QHASH_GS(false);
+#undef TPC_QHASH_GS
 #undef TPC_QHASH_GO
+}
+
+// one level of k_q_split: log_nb1 bits already binned, log_nb2 bits binned here; nvw source regions per bucket
+void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, int low_bits, int loads, uint32_t nwg1, uint32_t wpb, uint32_t nvw,
+                   const uint64_t *buf1, const uint32_t *cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *off2, QOverflow ovf, PtShard sh,
+                   uint32_t prev_wpb, int log_prev_nb2, const uint64_t *off1, unsigned grid)
+{
+    const bool rb = q_use_rbins(log_nb2);
+    const size_t lds_base = (rb ? RBins<uint64_t, QS_THREADS>::lds_bytes(log_nb2) : Bins<uint64_t, QS_THREADS>::lds_bytes(log_nb2)) + ((size_t)8 << log_nb2) + 64 + 128;
+    if (rb) loads = 4;  // the barrier-free rings have no round to outgrow
+    uint32_t nreg_cap, sched_cap;
+    size_t lds;
+    pt_schedule_dims(nvw, wpb, cap1, (uint32_t)loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+#define TPC_QSPLIT_GO(S, R)                                                                                                                  \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_q_split<S, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+        hipLaunchKernelGGL((k_q_split<S, R>), dim3(grid), dim3(QS_THREADS), lds, a.stream, log_nb1, log_nb2, a.P.L, low_bits, loads, nwg1, wpb, buf1, cnt1, cap1,   \
+                           buf2, cnt2, off2, ovf, sh, prev_wpb, log_prev_nb2, nreg_cap, sched_cap, off1);                                    \
+    } while (0)
+    if (sharded) { if (rb) TPC_QSPLIT_GO(true, true); else TPC_QSPLIT_GO(true, false); }
+    else { if (rb) TPC_QSPLIT_GO(false, true); else TPC_QSPLIT_GO(false, false); }
+#undef TPC_QSPLIT_GO
 }
 
 template <int Q>
@@ -845,26 +925,12 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     const PtShard sh{pl.rank, pl.world};
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
-        const size_t lds_base = Bins<uint64_t, QS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + ((size_t)8 << std::max(pl.b2, pl.b3)) + 64;
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
-        uint32_t nreg_cap, sched_cap;
-        size_t lds;
-        pt_schedule_dims(pl.nwg1 * pl.world, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
-        if (pl.world > 1) {
-            (void)hipFuncSetAttribute((const void *)k_q_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_q_split<true>, dim3(((1u << pl.b1) / pl.world) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
-        } else {
-            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits,
-                               pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
-        }
-        if (pl.b3) {  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
-            pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)pl.loads3 * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
-            (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_q_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(QS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3,
-                               a.P.L, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3, ovf, sh, pl.wpb, pl.b2, nreg_cap, sched_cap, (const uint64_t *)nullptr);
-        }
+        launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, low_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2,
+                      ovf, sh, 0u, 0, pl.roff1, (unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));
+        if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
+            launch_qsplit(a, false, pl.b1 + pl.b2, pl.b3, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.wpb, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3,
+                          ovf, sh, pl.wpb, pl.b2, nullptr, (unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3));
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
@@ -891,13 +957,8 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     const PtShard sh{0, 1};
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     {
-        const size_t lds_base = Bins<uint64_t, QS_THREADS>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64;
-        uint32_t nreg_cap, sched_cap;
-        size_t lds;
-        pt_schedule_dims(pl.nwg1, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
-        (void)hipFuncSetAttribute((const void *)k_q_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_split<false>, dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits,
-                           pl.loads, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1);
+        launch_qsplit(a, false, pl.b1, pl.b2, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0,
+                      pl.roff1, (1u << pl.b1) * pl.wpb);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
