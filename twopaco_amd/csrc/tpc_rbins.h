@@ -18,9 +18,6 @@
 // that are free to proceed (their slot's previous occupant is older still), hence no deadlock.
 // push_batch must be called by whole waves (wave-uniform control flow); lanes without an entry pass
 // ok = false.  No workgroup barrier is needed until flush_final.
-//
-// Where it is used: k_q_hash / k_q_split<.., RB = true> (tpc_qpartition.hip) for levels of 512 bins, where a ring of the
-// barrier bins holds only 32 uint64 entries.  At 256 bins the barrier bins are as fast or faster (tools/bins_bench.hip).
 #pragma once
 #include "tpc_bins.h"
 
