@@ -127,7 +127,7 @@ def addr_worker(rank, world, port, spec, result_path):
     dist.destroy_process_group()
 
 
-def comm_worker(rank, world, port, result_path):
+def comm_worker(rank, world, port, result_path, p2p=False):
     """The collectives of the address-sharded driver (twopaco_amd/dist.py:_Comm) over gloo on host tensors."""
     import pickle
 
@@ -139,11 +139,20 @@ def comm_worker(rank, world, port, result_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = tdist._Comm(dist, torch.device("cpu"))
+    # p2p: the grouped send/recv form that runs over RCCL, here over gloo, with 16-byte chunks so that every block takes several messages
+    comm = tdist._Comm(dist, torch.device("cpu"), p2p=p2p, chunk=16 if p2p else None)
     out = {}
     # equal blocks: block d of rank r holds (r, d)
     send = torch.stack([torch.full((5,), 16 * rank + d, dtype=torch.uint8) for d in range(world)]).reshape(-1)
     out["equal"] = comm.a2a_equal(send).tolist()
+    # larger equal blocks of 8-byte elements with distinct values: (rank, destination, index)
+    big = torch.stack([torch.arange(40, dtype=torch.int64) + 1000 * d + 100000 * rank for d in range(world)]).reshape(-1)
+    out["equal_big"] = comm.a2a_equal(big).tolist()
+    # variable counts well beyond one chunk: rank r sends 7 r + 3 d elements to d
+    bc = [7 * rank + 3 * d for d in range(world)]
+    bsend = torch.cat([torch.arange(c, dtype=torch.int64) + 1000 * d + 100000 * rank for d, c in enumerate(bc)] + [torch.zeros(0, dtype=torch.int64)])
+    brecv, brc = comm.a2a_var(bsend, bc)
+    out["var_big"] = (brecv.tolist(), brc)
     # variable: rank r sends (r + d) % 3 elements to d, values 100 r + d
     counts = [(rank + d) % 3 for d in range(world)]
     send = torch.cat([torch.full((c,), 100 * rank + d, dtype=torch.int64) for d, c in enumerate(counts)] + [torch.zeros(0, dtype=torch.int64)])

@@ -80,16 +80,18 @@ def test_three_ranks(tmp_path):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_address_sharded_collectives(world, tmp_path):
+def test_address_sharded_collectives(world, tmp_path, p2p=False):
     """Routing primitives of the address-sharded driver (equal-block all_to_all of the level-1 regions,
     variable all_to_all of probe addresses and of the answers coming back, all_gather of the masks)."""
     from dist_worker import comm_worker
     res = str(tmp_path / "res.pkl")
-    mp.spawn(comm_worker, args=(world, free_port(), res), nprocs=world, join=True)
+    mp.spawn(comm_worker, args=(world, free_port(), res, p2p), nprocs=world, join=True)
     with open(res, "rb") as f:
         got = pickle.load(f)
     for r in range(world):
         assert got[r]["equal"] == [16 * s + r for s in range(world) for _ in range(5)]
+        assert got[r]["equal_big"] == [i + 1000 * r + 100000 * s for s in range(world) for i in range(40)]
+        assert got[r]["var_big"] == ([i + 1000 * r + 100000 * s for s in range(world) for i in range(7 * s + 3 * r)], [7 * s + 3 * r for s in range(world)])
         want, rc = [], []
         for s in range(world):
             c = (s + r) % 3
@@ -101,6 +103,13 @@ def test_address_sharded_collectives(world, tmp_path):
         assert got[r]["back"] == ([d + 1 for d in range(world) for _ in range(counts[d])], counts)
         assert got[r]["gather"] == [[10 * s + i for i in range(3)] for s in range(world)]
         assert got[r]["max"] == [world - 1, 7]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_address_sharded_collectives_send_recv_form(world, tmp_path):
+    """The same exchanges in the grouped send/recv form that runs over RCCL (chunked messages per peer), here over gloo with
+    16-byte chunks: only an 8-GPU node runs that form with more than one rank otherwise."""
+    test_address_sharded_collectives(world, tmp_path, p2p=True)
 
 
 def test_bench_gpus_flag_launches_ranks(tmp_path):

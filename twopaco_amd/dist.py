@@ -143,11 +143,16 @@ class _Comm:
     device tensors directly; with "gloo" (tests: several ranks on one GPU) they are staged through
     the host."""
 
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, p2p=None, chunk=None):
         import torch
         self.dist, self.torch, self.device = dist, torch, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.direct = dist.get_backend() == "nccl"
+        # p2p: the grouped send/recv form of the all_to_alls (what runs over RCCL).  Selectable under gloo too, on host
+        # tensors, so that its block / chunk arithmetic is exercised by the CPU tests with several ranks
+        self.p2p = self.direct if p2p is None else bool(p2p)
+        if chunk:
+            self.CHUNK = int(chunk)
         self.bytes_moved = 0
 
     def sync(self):
@@ -168,11 +173,13 @@ class _Comm:
         torch = self.torch
         self.sync()
         self.bytes_moved += send.numel() * send.element_size()
-        if not self.direct:
+        if not self.p2p:
             s = self._in(send)
             r = torch.empty_like(s)
             self.dist.all_to_all_single(r, s)
             return self._out(r)
+        shape, dtype = send.shape, send.dtype
+        send = self._in(send)
         sb = send.contiguous().view(torch.uint8)
         wide = sb.numel() % (8 * self.world) == 0   # 8-byte elements: byte-wise copy kernels are slow
         sb = (sb.view(torch.int64) if wide else sb).view(self.world, -1)
@@ -190,7 +197,7 @@ class _Comm:
             if ops:
                 for w in self.dist.batch_isend_irecv(ops):
                     w.wait()
-        return recv.view(-1).view(torch.uint8).view(send.dtype).view(send.shape)
+        return self._out(recv.view(-1).view(torch.uint8).view(dtype).view(shape))
 
     def a2a_var(self, send, counts):
         """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source)."""
@@ -207,12 +214,13 @@ class _Comm:
             self.dist.all_to_all_single(rc, sc)
         rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in sc.tolist()]
         self.bytes_moved += send.numel() * send.element_size()
-        if not self.direct:
+        if not self.p2p:
             s = self._in(send)
             r = torch.empty(sum(rcl), dtype=send.dtype, device=s.device)
             self.dist.all_to_all_single(r, s, output_split_sizes=rcl, input_split_sizes=scl)
             return self._out(r), rcl
         # RCCL: grouped send/recv, at most CHUNK bytes per peer and message
+        send = self._in(send)
         r = torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
         step = max(1, self.CHUNK // send.element_size())
         so, ro = [0], [0]
@@ -236,7 +244,7 @@ class _Comm:
             if ops:
                 for w in self.dist.batch_isend_irecv(ops):
                     w.wait()
-        return r, rcl
+        return self._out(r), rcl
 
     def all_gather(self, t):
         """[world, *t.shape]"""
