@@ -155,21 +155,22 @@ struct PtRegion { T *base; uint64_t cap; };
 // sentinel) through f(entry): 16 bytes per lane and load, unpredicated, two batches of UNR loads in flight per lane.  n must
 // be uniform over the workgroup.  (One batch at a time with predicated loads left ~32 KB per CU in flight, short of the
 // bandwidth-delay product; the compiler also has to wait with vmcnt(0) after predicated loads.)
-template <int THREADS, int UNR, class T, class F>
-__device__ __forceinline__ void pt_stream_region(const T *__restrict__ src, uint32_t n, F f)
-{
-    constexpr int EPL = 16 / (int)sizeof(T);
-    constexpr T SENT = (T)~(T)0;
-    constexpr uint32_t STEP = UNR * THREADS;
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-    const uint32_t n4 = (n + EPL - 1) / EPL;
-    if (n4 == 0) return;
+template <int THREADS, int UNR, class T>
+struct PtStream {
+    static constexpr int EPL = 16 / (int)sizeof(T);
+    static constexpr T SENT = (T)~(T)0;
+    static constexpr uint32_t STEP = UNR * THREADS;
+    const uint4 *src4;
+    uint32_t n, n4;
     uint4 a[UNR], b[UNR];
-    auto ld = [&](uint4 (&d)[UNR], uint32_t i0) {
+    __device__ __forceinline__ void ld(uint4 (&d)[UNR], uint32_t i0)
+    {
 #pragma unroll
         for (int u = 0; u < UNR; u++) d[u] = src4[min(i0 + u * THREADS + threadIdx.x, n4 - 1u)];
-    };
-    auto use = [&](const uint4 (&d)[UNR], uint32_t i0) {
+    }
+    template <class F>
+    __device__ __forceinline__ void use(const uint4 (&d)[UNR], uint32_t i0, F &f)
+    {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const uint32_t idx = i0 + u * THREADS + threadIdx.x;
@@ -180,18 +181,38 @@ __device__ __forceinline__ void pt_stream_region(const T *__restrict__ src, uint
                 for (int e = 0; e < EPL; e++) if (x.e[e] != SENT && idx * EPL + e < n) f(x.e[e]);
             }
         }
-    };
-    ld(a, 0);
-    for (uint32_t i0 = 0;; i0 += 2 * STEP) {
-        const bool more1 = i0 + STEP < n4;
-        if (more1) ld(b, i0 + STEP);
-        use(a, i0);
-        if (!more1) break;
-        const bool more2 = i0 + 2 * STEP < n4;
-        if (more2) ld(a, i0 + 2 * STEP);
-        use(b, i0 + STEP);
-        if (!more2) break;
     }
+    // issues the loads of the first two batches; other work may follow before finish() consumes them
+    __device__ __forceinline__ void begin(const T *__restrict__ src, uint32_t count)
+    {
+        src4 = reinterpret_cast<const uint4 *>(src);
+        n = count;
+        n4 = (count + EPL - 1) / EPL;
+        if (n4 == 0) return;
+        ld(a, 0);
+        if (STEP < n4) ld(b, STEP);
+    }
+    template <class F>
+    __device__ __forceinline__ void finish(F f)
+    {
+        if (n4 == 0) return;
+        for (uint32_t i0 = 0;; i0 += 2 * STEP) {
+            use(a, i0, f);
+            if (i0 + STEP >= n4) break;
+            if (i0 + 2 * STEP < n4) ld(a, i0 + 2 * STEP);
+            use(b, i0 + STEP, f);
+            if (i0 + 2 * STEP >= n4) break;
+            if (i0 + 3 * STEP < n4) ld(b, i0 + 3 * STEP);
+        }
+    }
+};
+
+template <int THREADS, int UNR, class T, class F>
+__device__ __forceinline__ void pt_stream_region(const T *__restrict__ src, uint32_t n, F f)
+{
+    PtStream<THREADS, UNR, T> st;
+    st.begin(src, n);
+    st.finish(f);
 }
 
 

@@ -413,6 +413,12 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
         if ((uint32_t)(a >> slice_bits) == blockIdx.x) atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
     }
     __syncthreads();
+    // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
+    PtStream<PT_APPLY_THREADS, 2, uint64_t> q0;
+    {
+        const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
+        q0.begin(qbuf2 + qoff2[r0], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+    }
     if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
     else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
     // ---- lookup (k_q_lookup) against the slice still in LDS
@@ -440,8 +446,7 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     };
     for (uint32_t j = 0; j < qwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
-        pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], n, [&](uint64_t v) {
+        auto probe = [&](uint64_t v) {
             const uint32_t a = (uint32_t)v & slice_mask;
             if ((slice[a >> 5] >> (a & 31u)) & 1u) {
                 const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
@@ -451,7 +456,9 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
                     if (o < surv_cap) my_list[o] = v >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
                 }
             }
-        });
+        };
+        if (j == 0) q0.finish(probe);
+        else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]), probe);
         __syncthreads();
         const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
         __syncthreads();
