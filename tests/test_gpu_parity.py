@@ -251,8 +251,10 @@ def test_partitioned_paths_in_batches(capi, tmp_path):
     ctx.close()
 
 
-def test_partitioned_query_adversarial_skew(capi):
-    """Repeats + poly-A: bins, regions and the survivor lists overflow; result equals the direct kernel's."""
+@pytest.mark.parametrize("slice_bits", [12, 6])
+def test_partitioned_query_adversarial_skew(capi, slice_bits):
+    """Repeats + poly-A: bins, regions and the survivor lists overflow; result equals the direct kernel's.
+    slice_bits = 6: 512 bins per level, i.e. the barrier-free rings of the query (k_q_hash / k_q_split<.., RB>) under skew."""
     rng = np.random.default_rng(5)
     unit = rng.integers(0, 4, 700).astype(np.uint8)
     recs = [np.tile(unit, 400), np.zeros(200000, dtype=np.uint8), np.concatenate([unit[:300], unit[350:]])]
@@ -262,7 +264,7 @@ def test_partitioned_query_adversarial_skew(capi):
         ctx = capi.Context(0)
         ctx.set_option("insert_mode", mode)
         ctx.set_option("query_mode", mode)
-        ctx.set_option("slice_bits", 12)
+        ctx.set_option("slice_bits", slice_bits)
         ctx.set_params(25, 24, 5, capi.seed_table(5, 24, seed=3))
         ctx.seq_upload(text)
         ctx.filter_reset()
