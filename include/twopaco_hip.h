@@ -262,9 +262,10 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *   text_window        1: on a sharded context tpc_seq_upload keeps only the words of the tiles this rank hashes (chunk
  *                      rank * ceil(tiles / world) ..., + halo); such a context runs the sharded first pass only (rank 0 of the
  *                      C++ host keeps the whole text for the second pass)
- *   fuse_apply_lookup  1 (default): when the insert and the query of a round both fit one tile batch, the insert stops after its
- *                      level-2 binning and the query's lookup kernel builds each filter slice itself (the filter is written once,
- *                      never read back); TPC_K_INSERT then covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
+ *   fuse_apply_lookup  1 (default): when the insert of a round fits one tile batch and the query is partitioned with the same
+ *                      geometry, the insert stops after its level-2 binning and the lookup kernel of the query's FIRST batch builds
+ *                      each filter slice itself (the filter is written once and not read back by that batch); TPC_K_INSERT then
+ *                      covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
  *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 45 % of the free device
  *                      memory when that is more); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);

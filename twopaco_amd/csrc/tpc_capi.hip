@@ -95,8 +95,12 @@ struct tpc_ctx {
     TpcPartPlan pending_pl;
     void *ikeep[2] = {nullptr, nullptr};  // the insert's level-2 regions and counts while an apply is pending
     size_t ikeep_bytes[2] = {0, 0};
-    uint64_t *ikeep_ovf = nullptr;        // ... and its (few) overflow entries: the query reuses the overflow list
-    uint32_t pending_novf = 0;
+    uint64_t *ikeep_ovf = nullptr;        // ... and its overflow entries (the query reuses the overflow list), [0, n) as
+    uint64_t ikeep_ovf_cap = 0;           //     produced, [cap, cap + n) grouped by slice for the fused kernel
+    uint64_t pending_novf = 0;
+    uint32_t *iovf_cnt = nullptr;         // [2 x slices] count and cursor of the grouping
+    uint64_t *iovf_off = nullptr;         // [slices + 1]
+    uint32_t iovf_slices = 0;
     int64_t stat_fused = 0;
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
@@ -313,6 +317,8 @@ void tpc_ctx_destroy(tpc_ctx *c)
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
     if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
+    if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
+    if (c->iovf_off) (void)hipFree(c->iovf_off);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -518,9 +524,9 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         const bool qpart = plan_query(c, lo, hi, gated, qpl);
         for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
-        // deferred apply: both passes of the round in one batch with the same slice geometry, and room for the insert's level-2
-        // regions beside the query's buffers
-        defer = part && c->opt_fuse && batches == 1 && qpart && pl.b3 == 0 && qpl.b3 == 0 && qpl.n_tiles >= tiles && qpl.slice_bits == pl.slice_bits &&
+        // deferred apply: the insert in one batch, the query partitioned with the same slice geometry (its FIRST batch then
+        // builds the slices), and room for the insert's level-2 regions beside the query's buffers
+        defer = part && c->opt_fuse && batches == 1 && qpart && pl.b3 == 0 && qpl.b3 == 0 && qpl.slice_bits == pl.slice_bits &&
                 qpl.b1 == pl.b1 && qpl.b2 == pl.b2;
         if (defer) {
             const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
@@ -558,11 +564,31 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                         tpc_launch_insert_part_split(make_launch(c), p1)) return fail(c, -1, "partitioned insert launch failed");
                     HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
-                    if (ov[0] <= TPC_FUSE_MAX_OVF && ov[1] == 0) {
-                        if (!c->ikeep_ovf) HIPCHK(c, hipMalloc((void **)&c->ikeep_ovf, TPC_FUSE_MAX_OVF * sizeof(uint64_t)));
-                        if (ov[0]) HIPCHK(c, hipMemcpyAsync(c->ikeep_ovf, pl.ovf, ov[0] * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-                        c->pending_apply = true; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = (uint32_t)ov[0];
-                    } else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
+                    bool keep = ov[0] <= TPC_FUSE_MAX_OVF && ov[1] == 0;
+                    const uint32_t n_slices = 1u << (p1.b1 + p1.b2);
+                    if (keep && ov[0]) {  // the overflow entries wait beside the regions, once as produced and once grouped by slice
+                        if (c->ikeep_ovf_cap < ov[0]) {
+                            if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
+                            c->ikeep_ovf = nullptr; c->ikeep_ovf_cap = 0;
+                            const uint64_t cap = std::max<uint64_t>(4096, ov[0] + ov[0] / 4);
+                            if (hipMalloc((void **)&c->ikeep_ovf, 2 * cap * sizeof(uint64_t)) == hipSuccess) c->ikeep_ovf_cap = cap; else { (void)hipGetLastError(); keep = false; }
+                        }
+                        if (keep && c->iovf_slices < n_slices) {
+                            if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
+                            if (c->iovf_off) (void)hipFree(c->iovf_off);
+                            c->iovf_cnt = nullptr; c->iovf_off = nullptr; c->iovf_slices = 0;
+                            if (hipMalloc((void **)&c->iovf_cnt, 2 * (size_t)n_slices * sizeof(uint32_t)) == hipSuccess &&
+                                hipMalloc((void **)&c->iovf_off, ((size_t)n_slices + 1) * sizeof(uint64_t)) == hipSuccess) c->iovf_slices = n_slices;
+                            else { (void)hipGetLastError(); keep = false; }
+                        }
+                        if (keep) {
+                            HIPCHK(c, hipMemcpyAsync(c->ikeep_ovf, pl.ovf, ov[0] * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+                            if (tpc_launch_ovf_by_slice(make_launch(c), c->ikeep_ovf, ov[0], p1.slice_bits, n_slices, c->iovf_cnt, c->iovf_cnt + n_slices, c->iovf_off,
+                                                        c->ikeep_ovf + c->ikeep_ovf_cap)) return fail(c, -1, "overflow grouping launch failed");
+                        }
+                    }
+                    if (keep) { c->pending_apply = true; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = ov[0]; }
+                    else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
                     break;
                 }
                 if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
@@ -652,7 +678,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (part)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (tpc_qpart_bytes(pl, i)) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
-    const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.n_tiles >= tiles && pl.slice_bits == c->pending_pl.slice_bits &&
+    const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
                        pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2;
     if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     if (part) {
@@ -682,7 +708,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
                 HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
-                if (fused) {
+                if (fused && t0 == 0) {  // the first batch's lookup kernel also builds and writes the filter slices; later batches read them
                     TpcQPlan p1 = pl;
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
                     c->pending_apply = false;
@@ -690,7 +716,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     if (tpc_launch_query_part_hash(make_launch(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                     {
                         Timed tf(c, TPC_K_FUSED);
-                        if (tpc_launch_query_part_fused_lookup(make_launch(c), p1, c->pending_pl, c->pending_fresh, c->ikeep_ovf, c->pending_novf)) return fail(c, -1, "fused lookup launch failed");
+                        if (tpc_launch_query_part_fused_lookup(make_launch(c), p1, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
+                                                               c->pending_novf ? c->iovf_off : nullptr)) return fail(c, -1, "fused lookup launch failed");
                     }
                     if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");
                 } else

@@ -98,8 +98,11 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
 // deferred apply: the insert stops after its level-2 binning (tpc_launch_insert_part_split), the query's lookup builds the slices itself
 int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl);   // level 2 (and 3) only
 int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh);  // k_part_apply + k_part_ovf
-int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, uint32_t n_iovf);
-#define TPC_FUSE_MAX_OVF 4096u  // insert overflow entries the fused kernel still folds in (every workgroup scans the list)  // k_q_split + k_apply_lookup + k_q_ovf
+// iovf_sorted / iovf_off: the insert's overflow entries grouped by slice (tpc_launch_ovf_by_slice), or nullptr when there are none
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf_sorted, const uint64_t *iovf_off);  // k_q_split + k_apply_lookup + k_q_ovf
+int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n, int slice_bits, uint32_t n_slices, uint32_t *cnt, uint32_t *cursor,
+                            uint64_t *off, uint64_t *sorted);
+#define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
 // compacted exchange of the sharded path: off[i] = entries before region i (off[n] = all of them), in 16-byte units of
 // `entry_bytes`-byte entries -- counts written by Bins are whole flush groups, so every region stays 128-byte aligned;

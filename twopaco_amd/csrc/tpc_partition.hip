@@ -346,6 +346,25 @@ __global__ void __launch_bounds__(1024) k_region_offsets(const uint32_t *__restr
     if (threadIdx.x == 0) off[n] = tot;
 }
 
+// The insert's overflow entries (permuted full addresses) in slice order for the fused apply + lookup kernel: count per slice,
+// offsets (k_region_offsets), scatter.  The order inside a slice does not matter (the bits are OR-ed).
+__global__ void __launch_bounds__(256) k_ovf_count(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, uint32_t *cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&cnt[list[i] >> slice_bits], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_ovf_scatter(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, const uint64_t *__restrict__ off,
+                                                     uint32_t *cursor, uint64_t *__restrict__ sorted)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t a = list[i];
+        const uint64_t s = a >> slice_bits;
+        sorted[off[s] + atomicAdd(&cursor[s], 1u)] = a;
+    }
+}
+
 // One workgroup per region: the used prefix (a whole number of 16-byte units) moves to its packed position.
 __global__ void __launch_bounds__(256) k_region_pack(const uint4 *__restrict__ regions, uint64_t cap16, uint32_t per16, const uint32_t *__restrict__ cnt,
                                                      const uint64_t *__restrict__ off, uint4 *__restrict__ packed)
@@ -495,5 +514,19 @@ int tpc_launch_region_pack(const TpcLaunch &a, const void *regions, uint64_t cap
     if (n_regions)
         hipLaunchKernelGGL(k_region_pack, dim3(n_regions), dim3(256), 0, a.stream, (const uint4 *)regions, cap_entries * entry_bytes / 16, 16u / entry_bytes, cnt, off,
                            (uint4 *)packed);
+    return 0;
+}
+
+// list[0..n) -> sorted[0..n) grouped by slice (address >> slice_bits); off[s] .. off[s + 1] = the entries of slice s.
+// cnt and cursor: n_slices words each; off: n_slices + 1.
+int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n, int slice_bits, uint32_t n_slices, uint32_t *cnt, uint32_t *cursor,
+                            uint64_t *off, uint64_t *sorted)
+{
+    if (hipMemsetAsync(cnt, 0, (size_t)n_slices * sizeof(uint32_t), a.stream) != hipSuccess ||
+        hipMemsetAsync(cursor, 0, (size_t)n_slices * sizeof(uint32_t), a.stream) != hipSuccess) return -1;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+    if (n) hipLaunchKernelGGL(k_ovf_count, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, cnt);
+    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, a.stream, cnt, n_slices, off);
+    if (n) hipLaunchKernelGGL(k_ovf_scatter, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, off, cursor, sorted);
     return 0;
 }

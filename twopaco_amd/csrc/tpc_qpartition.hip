@@ -380,7 +380,7 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 // AND tests the query's entries of that slice on the spot: the 2^L / 8 bytes of the filter are not read back.
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
-               const uint64_t *__restrict__ iovf, uint32_t n_iovf, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
+               const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
                uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -407,10 +407,13 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
         pt_stream_region<PT_APPLY_THREADS, 2>(ibuf2 + r * icap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
     }
-    // the insert's few overflow entries (permuted addresses that found a ring or region full): every workgroup picks out its own
-    for (uint32_t i = threadIdx.x; i < n_iovf; i += PT_APPLY_THREADS) {
-        const uint64_t a = iovf[i];
-        if ((uint32_t)(a >> slice_bits) == blockIdx.x) atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+    // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
+    if (iovf_off) {
+        const uint64_t o0 = iovf_off[blockIdx.x], o1 = iovf_off[blockIdx.x + 1];
+        for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
+            const uint64_t a = iovf[i];
+            atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+        }
     }
     __syncthreads();
     // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
@@ -962,7 +965,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 
 // Fused tail of the query when the insert's apply was deferred (see tpc_capi.hip:flush_pending_apply): level-2 binning of
 // the query, then k_apply_lookup over the insert's and the query's level-2 regions, then the overflow probes.
-int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, uint32_t n_iovf)
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, const uint64_t *iovf_off)
 {
     if (pl.b3 || ipl.b3 || pl.world != 1 || ipl.world != 1 || pl.slice_bits != ipl.slice_bits || pl.b1 != ipl.b1 || pl.b2 != ipl.b2) return -1;
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
@@ -977,7 +980,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_apply_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
-                           ipl.cap2, fresh ? 1 : 0, iovf, n_iovf, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
     return 0;
