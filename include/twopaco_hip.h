@@ -266,6 +266,7 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *                      geometry, the insert stops after its level-2 binning and the lookup kernel of the query's FIRST batch builds
  *                      each filter slice itself (the filter is written once and not read back by that batch); TPC_K_INSERT then
  *                      covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
+ *   test_sched_cap     tests only, process-wide: rounds per segment of the split kernels' round schedule (0 = what fits in LDS)
  *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 45 % of the free device
  *                      memory when that is more); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);

@@ -226,6 +226,47 @@ def test_partitioned_query_matches_oracle(capi, tmp_path, name, slice_bits):
     ctx.close()
 
 
+@pytest.mark.parametrize("sched_cap", [1, 3])
+def test_split_round_schedule_in_segments(capi, tmp_path, sched_cap):
+    """The split kernels walk a round schedule kept in LDS; when it does not fit (only on inputs far larger than a test) it
+    is built in segments.  The testing knob test_sched_cap forces segments of 1 / 3 rounds: same filter and mask as the oracle,
+    on a golden case and on 8 x 50 kbp synthetic genomes (many rounds per workgroup)."""
+    from twopaco_amd import synth
+    jobs = []
+    case = [c for c in CASES if c["name"] == "rand6_k25_q3"][0]
+    o1 = _oracle_for(case, tmp_path)
+    jobs.append((capi.PackedText.from_fasta(case_files(case, tmp_path)), case["k"], case["L"], case["q"], case["seed"], 12, o1))
+    recs, _ = synth.workload("m1", scale=0.01)
+    o2 = O.Oracle(25, 26, 5, O.seed_table(11, 5, 26))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o2.add_record(letters[r].tobytes())
+    jobs.append((capi.PackedText.from_codes(recs), 25, 26, 5, 11, 14, o2))
+    try:
+        for text, k, L, q, seed, slice_bits, o in jobs:
+            ctx = capi.Context(0)
+            ctx.set_option("test_sched_cap", sched_cap)
+            ctx.set_option("insert_mode", 2)
+            ctx.set_option("query_mode", 2)
+            ctx.set_option("slice_bits", slice_bits)
+            ctx.set_params(k, L, q, capi.seed_table(q, L, seed=seed))
+            ctx.seq_upload(text)
+            o.fill_only(0, 1 << L)
+            marks = o.check_only(0, 1 << L)
+            ctx.filter_reset()
+            ctx.pass1_insert()
+            assert ctx.pass1_query() == marks
+            assert (ctx.mask_download(False) == o.round_mask).all()
+            assert (ctx.filter_download() == o.filter).all()
+            ctx.set_option("test_sched_cap", 0)
+            ctx.close()
+    finally:
+        c0 = capi.Context(0)
+        c0.set_option("test_sched_cap", 0)  # process-wide
+        c0.close()
+        o1.close(); o2.close()
+
+
 def test_partitioned_paths_in_batches(capi, tmp_path):
     """Tiny buffer budget: insert and query run as several tile batches (later insert batches OR into
     the filter, query batches carry batch-relative positions); same bitmap and mask."""

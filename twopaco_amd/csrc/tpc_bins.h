@@ -108,13 +108,15 @@ __device__ __forceinline__ uint32_t pt_block_excl_scan(uint32_t v, uint32_t *s_w
 
 // Host side of the round schedule below: LDS words for a split workgroup that streams up to ceil(nvw / wpb) regions of at
 // most cap1 entries in rounds of `step` entries.  The whole schedule when it fits beside lds_base bytes, else a segment.
+extern uint32_t tpc_test_sched_cap;  // tpc_partition.hip; > 0 (option "test_sched_cap"): rounds per schedule segment, to exercise the segment path on small inputs
 inline void pt_schedule_dims(uint32_t nvw, uint32_t wpb, uint64_t cap1, uint32_t step, size_t lds_base, uint32_t &nreg_cap, uint32_t &sched_cap, size_t &lds)
 {
     constexpr size_t LDS_MAX = 160 * 1024 - 256;  // gfx950: 160 KB per workgroup
     nreg_cap = (nvw + wpb - 1) / wpb;
     const uint64_t need = (uint64_t)nreg_cap * ((cap1 + step - 1) / step) + 1;
     const size_t fixed = lds_base + (size_t)nreg_cap * 4;
-    const uint64_t room = LDS_MAX > fixed + 1024 ? (LDS_MAX - fixed) / 4 : 256;
+    uint64_t room = LDS_MAX > fixed + 1024 ? (LDS_MAX - fixed) / 4 : 256;
+    if (tpc_test_sched_cap) room = tpc_test_sched_cap;
     sched_cap = (uint32_t)(need < room ? need : room);
     lds = fixed + (size_t)sched_cap * 4;
 }

@@ -337,6 +337,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "part_levels")) { c->opt_part_levels = (int)value; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
+    if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
     return fail(c, -1, "unknown option %s", name);
 }

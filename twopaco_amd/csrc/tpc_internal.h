@@ -104,6 +104,7 @@ int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n
                             uint64_t *off, uint64_t *sorted);
 #define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
+extern uint32_t tpc_test_sched_cap;  // tpc_partition.hip: option "test_sched_cap" (tests: rounds per schedule segment of the split kernels)
 // compacted exchange of the sharded path: off[i] = entries before region i (off[n] = all of them), in 16-byte units of
 // `entry_bytes`-byte entries -- counts written by Bins are whole flush groups, so every region stays 128-byte aligned;
 // pack copies the used prefix of every fixed-capacity region to its offset

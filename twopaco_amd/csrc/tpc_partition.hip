@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cmath>
 
+uint32_t tpc_test_sched_cap = 0;  // see tpc_bins.h:pt_schedule_dims
+
 namespace {
 
 constexpr uint32_t PT_SENT = 0xFFFFFFFFu;
