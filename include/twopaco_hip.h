@@ -108,6 +108,19 @@ int tpc_pass1_query(tpc_ctx *ctx, uint64_t lo, uint64_t hi, uint64_t *n_marks);
  * VE.h:384-386. */
 int tpc_pass2_filter(tpc_ctx *ctx, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
 
+/* The same filter with its table sharded by key hash over `world` ranks (multi-GPU runs whose candidate marks stay on the rank
+ * that hashed them, twopaco_amd/dist.py): tpc_pass2_marks compacts this round's mask into the ordered list of marked positions
+ * (*n_marks of them, kept for the output pass); tpc_pass2_mark_owners copies that list to pos_dev and writes the rank that owns
+ * each position's canonical key -- every occurrence of a k-mer, on either strand, goes to one owner; the host layer routes the
+ * positions (tpc_shard_route / tpc_shard_permute64, a variable all-to-all of 8 bytes per marked position) and
+ * tpc_pass2_filter_positions runs the exact filter over the positions a rank received: complete (prev, next) sets and counts per
+ * key, hence the reference's verdict; it appends this rank's junction keys (to be all-gathered:
+ * tpc_junction_keys_export / _import) and merges the round mask as tpc_pass2_filter does.  Needs the whole text on the rank. */
+int tpc_pass2_marks(tpc_ctx *ctx, uint64_t *n_marks);
+int tpc_pass2_mark_owners(tpc_ctx *ctx, uint32_t world, uint64_t *pos_dev, int32_t *owner_dev);
+int tpc_pass2_filter_positions(tpc_ctx *ctx, const uint64_t *pos_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false,
+                               uint64_t *table_size);
+
 /* BifurcationStorage::Init (bifurcationstorage.h:27-66): sort all junction keys in
  * CompressedString::Less order (compressedstring.h:93-104) and build the id index. */
 int tpc_junctions_finalize(tpc_ctx *ctx, uint64_t *n_junctions);

@@ -53,12 +53,23 @@ def check(spec, o, gathered, world):
             assert int(np.unpackbits(r["mask"].view(np.uint8)).sum()) == marks
     o.enumerate(rounds=1, abundance=spec["abundance"])
     seq, pos, ids = o.records
+    start = np.asarray(o.rec_start, dtype=np.int64)
+    want = sorted((int(start[s] + p), int(i)) for s, p, i in zip(seq.tolist(), pos.tolist(), ids.tolist()) if abs(i) <= len(o.keys))
+    if spec.get("sharded_pass2"):
+        # the exact filter's table is sharded by key hash: every rank knows all junction keys but reports the ids of ITS marked
+        # positions only; together they are the result, the true-junction counts add up, each mark was found by one rank
+        got = []
+        for g in gathered:
+            assert g["junctions"] == len(o.keys)
+            keep = g["ids"] != (1 << 63) - 1
+            got += list(zip(g["g"][keep].tolist(), g["ids"][keep].tolist()))
+        assert sorted(got) == want and len(set(p for p, _ in got)) == len(got)
+        assert sum(g["true"] for g in gathered) == len(o.keys)
+        return
     for g in gathered:  # every rank holds the complete result
         assert g["junctions"] == len(o.keys)
         keep = g["ids"] != (1 << 63) - 1
         got = sorted(zip(g["g"][keep].tolist(), g["ids"][keep].tolist()))
-        start = np.asarray(o.rec_start, dtype=np.int64)
-        want = sorted((int(start[s] + p), int(i)) for s, p, i in zip(seq.tolist(), pos.tolist(), ids.tolist()) if abs(i) <= len(o.keys))
         assert got == want
 
 
@@ -113,6 +124,39 @@ def test_address_sharded_synthetic_batches(world, budget, tmp_path):
     tr = gathered[0]["rounds"][0]["survivors"][0]
     assert len(tr) == 3 and tr[2] <= tr[1] <= tr[0]
     check(spec, o, gathered, world)
+
+
+@pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("rand6_k25_q3", 12, 4), ("c2_k51_r2", 16, 2), ("rand6_k9_a3", 8, 4),
+                                                   ("c2_k125", 14, 2), ("edge_k5", 7, 2)])
+def test_address_sharded_key_sharded_pass2(name, slice_bits, world, tmp_path):
+    """Second pass with the exact filter's table sharded by key hash (tpc_pass2_mark_owners / tpc_pass2_filter_positions): no
+    mask union, 8 bytes per marked position to the key's owner, all-gather of the junction keys.  One- to five-word keys, an
+    abundance cut (the counts must be complete on the owner), sequence ends and N runs."""
+    case = CASES[name]
+    files = case_files(case, tmp_path)
+    spec = {"files": files, "k": case["k"], "L": case["L"], "q": case["q"], "seed": case["seed"], "ranges": [(0, 1 << case["L"])],
+            "abundance": case["abundance"] if case["abundance"] is not None else (1 << 64) - 1, "sharded_pass2": True,
+            "options": {"slice_bits": slice_bits}}
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in files:
+        o.add_fasta(f)
+    gathered = run(spec, world, tmp_path)
+    check(spec, o, gathered, world)
+
+
+def test_key_sharded_pass2_synthetic(tmp_path):
+    """8 x 100 kbp genomes, 4 ranks: many occurrences per junction spread over all ranks."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.02)
+    spec = {"workload": "m1", "scale": 0.02, "k": 25, "L": 28, "q": 5, "seed": 12, "ranges": [(0, 1 << 28)], "abundance": (1 << 64) - 1,
+            "sharded_pass2": True, "options": {"slice_bits": 14}}
+    o = O.Oracle(25, 28, 5, O.seed_table(12, 5, 28))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    gathered = run(spec, 4, tmp_path)
+    check(spec, o, gathered, 4)
+    assert sum(g["step_marks"] for g in gathered) == int(np.unpackbits(gathered[0]["rounds"][0]["mask"].view(np.uint8)).sum())
 
 
 def test_compacted_exchange_moves_fewer_bytes(tmp_path):

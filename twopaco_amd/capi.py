@@ -19,7 +19,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_emit_fetch", "tpc_filter_words", "tpc_filter_download", "tpc_mask_words", "tpc_mask_download",
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
-               "tpc_shard_pack", "tpc_shard_apply_packed",
+               "tpc_shard_pack", "tpc_shard_apply_packed", "tpc_pass2_marks", "tpc_pass2_mark_owners", "tpc_pass2_filter_positions",
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
@@ -83,6 +83,9 @@ def hip():
         L.tpc_shard_overflow_get.argtypes = [p, ci, p, u64]
         L.tpc_shard_overflow_set.argtypes = [p, ci, p, u64]
         L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]
+        L.tpc_pass2_marks.argtypes = [p, p]
+        L.tpc_pass2_mark_owners.argtypes = [p, u32, p, p]
+        L.tpc_pass2_filter_positions.argtypes = [p, p, u64, u64, p, p, p]
         L.tpc_shard_pack.argtypes = [p, ci, p, p, p, p]
         L.tpc_shard_apply_packed.argtypes = [p, ci, u64, p, p, p]
         L.tpc_shard_survivors.argtypes = [p, p]
@@ -281,6 +284,20 @@ class Context:
     def pass2_filter(self, abundance=(1 << 64) - 1):
         a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._ck(hip().tpc_pass2_filter(self._h, abundance, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"true": a.value, "false": b.value, "table": c.value}
+
+    def pass2_marks(self):
+        """Compacts this round's mask; returns the number of marked positions (kept in the context for the output pass)."""
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass2_marks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def pass2_mark_owners(self, world, pos_ptr, owner_ptr):
+        self._ck(hip().tpc_pass2_mark_owners(self._h, world, pos_ptr, owner_ptr))
+
+    def pass2_filter_positions(self, pos_ptr, n, abundance=(1 << 64) - 1):
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass2_filter_positions(self._h, pos_ptr, n, abundance, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"true": a.value, "false": b.value, "table": c.value}
 
     def junctions_finalize(self):

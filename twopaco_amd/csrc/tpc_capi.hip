@@ -762,26 +762,75 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     return 0;
 }
 
+namespace {
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool compact, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
+}
+
 int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
 {
-    if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
-    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
+    return pass2_filter_impl(c, nullptr, 0, true, abundance, n_true, n_false, table_size);
+}
+
+int tpc_pass2_marks(tpc_ctx *c, uint64_t *n_marks)
+{
+    if (!c || !c->have_params || !c->bases || !n_marks) return fail(c, -1, "set_params and seq_upload first");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = compact_mask(c, c->rmask);
     if (rc) return rc;
     c->marks_valid = true;
+    *n_marks = c->n_marks;
+    return 0;
+}
+
+int tpc_pass2_mark_owners(tpc_ctx *c, uint32_t world, uint64_t *pos_dev, int32_t *owner_dev)
+{
+    if (!c || !c->marks_valid || world == 0 || (c->n_marks && (!pos_dev || !owner_dev))) return fail(c, -1, "tpc_pass2_marks first");
+    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_marks) {
+        HIPCHK(c, hipMemcpyAsync(pos_dev, c->marks, c->n_marks * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        if (tpc_launch_mark_owner(make_launch(c), c->C, c->marks, c->n_marks, world, owner_dev)) return fail(c, -1, "owner launch failed");
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_pass2_filter_positions(tpc_ctx *c, const uint64_t *pos_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+{
+    if (n && !pos_dev) return fail(c, -1, "bad arguments");
+    return pass2_filter_impl(c, pos_dev, n, false, abundance, n_true, n_false, table_size);
+}
+
+namespace {
+
+// fmarks == nullptr: the positions marked in this round's mask (compacted here when `compact`); else the given positions
+// (the occurrences whose keys this rank owns, tpc_pass2_mark_owners on every rank + an exchange).  Either way the round's mask is
+// then merged into the run-wide one.
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool compact, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+{
+    if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
+    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (compact) {
+        int rc = compact_mask(c, c->rmask);
+        if (rc) return rc;
+        c->marks_valid = true;
+    }
+    const uint64_t *marks = fmarks ? fmarks : c->marks;
+    const uint64_t n_marks = fmarks ? n_fmarks : c->n_marks;
     // Exact-filter table, a power of two.  Sized first for the usual case -- on many-genome inputs a key is marked dozens
     // of times, so marks / 4 slots hold the distinct keys several times over and the table (and TrueBifurcations' scan of it)
     // stays cache sized; a probe sequence longer than TPC_FILTER2_PROBE_LIMIT flags a table that is too full and the pass
     // is repeated with 2 x marks slots, which always suffices.
     const size_t sb = tpc_table_slot_bytes(c->C);
     TpcLaunch a = make_launch(c);
-    const bool counted = abundance < c->n_marks;  // otherwise no key can exceed the abundance cut
+    const bool counted = abundance < n_marks;  // otherwise no key can exceed the abundance cut
     if (!c->scan_blocks) HIPCHK(c, hipMalloc((void **)&c->scan_blocks, 2 * TPC_SCAN2_BLOCKS * sizeof(uint64_t)));
     uint64_t full = 1024;
-    while (full < 2 * c->n_marks + 2) full <<= 1;
+    while (full < 2 * n_marks + 2) full <<= 1;
     uint64_t cap = 1024;
-    while (cap < c->n_marks / 4 + 2) cap <<= 1;
+    while (cap < n_marks / 4 + 2) cap <<= 1;
     uint64_t tp = 0, used = 0;
     c->stat_filter2_retries = 0;
     for (;;) {
@@ -798,7 +847,7 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
             Timed t(c, TPC_K_FILTER2);
             // key = EMPTY (all ones), meta = 0
             tpc_launch_table_init(c->stream, c->table, cap);
-            if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
+            if (tpc_launch_filter2(a, c->C, marks, n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
         }
         uint64_t too_full = 0;
         {
@@ -821,7 +870,7 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
                     c->keys = nk;
                     c->keys_cap = ncap;
                 }
-                if (tpc_launch_scan2_write(a, c->C, c->marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
+                if (tpc_launch_scan2_write(a, c->C, marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
                     return fail(c, -1, "scan2 launch failed");
                 c->n_keys += tp;
             }
@@ -847,6 +896,8 @@ int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t 
     if (table_size) *table_size = used;
     return 0;
 }
+
+}  // namespace
 
 int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
 {

@@ -143,6 +143,7 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
 // *overflow (device) is set when a probe sequence exceeds TPC_FILTER2_PROBE_LIMIT slots: the table is too small for the
 // number of distinct keys and the pass must be repeated with a larger one
 #define TPC_FILTER2_PROBE_LIMIT 512u
+int tpc_launch_mark_owner(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, int32_t *owner);  // key-hash owner of every mark
 int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
                        unsigned long long *overflow);
 // TrueBifurcations in two atomic-free passes over TPC_SCAN2_BLOCKS chunks of the table.

@@ -287,6 +287,29 @@ k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
     if (COUNTED) atomicAdd(meta, 1ull << META_COUNT_SHIFT);  // CandidateOccurence::Inc, candidateoccurence.h:64-67
 }
 
+// Owner rank of every marked position's key when the exact-filter table is sharded by key hash over `world` ranks (the
+// address-sharded multi-GPU pass, twopaco_amd/dist.py): all occurrences of a k-mer, on either strand, go to one rank, which
+// then sees the complete (prev, next) sets and count of the key.  Uses bits of the key hash the table slot index does not.
+template <int C>
+__global__ void __launch_bounds__(256)
+k_mark_owner(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ marks,
+             uint64_t n_marks, uint32_t world, int32_t *__restrict__ owner)
+{
+    __shared__ uint64_t s_h0[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_marks) return;
+    uint64_t fw[C], rc[C];
+    load_kmer<C>(bases, marks[idx], P.k, fw);
+    revcomp_kmer<C>(fw, P.k, rc);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    uint64_t ck[C];
+#pragma unroll
+    for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
+    owner[idx] = (int32_t)((key_hash<C>(ck) >> 40) % world);
+}
+
 // TrueBifurcations (VE.h:1228-1256) without global atomics: every workgroup owns a contiguous chunk
 // of the table; pass 1 counts (used slots, true junctions) per chunk, a scan turns the counts into
 // offsets, pass 2 walks the same chunk again and writes the junction keys at its offset.
@@ -531,6 +554,19 @@ int TPC_PASS2_FN(tpc_launch_filter2)(const TpcLaunch &a, int C, const uint64_t *
                                     marks, n_marks, (Slot *)table, cap, overflow);                                                       \
     else hipLaunchKernelGGL((k_filter2<C_, false>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, \
                             n_marks, (Slot *)table, cap, overflow)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_mark_owner_long(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, int32_t *owner);
+int TPC_PASS2_FN(tpc_launch_mark_owner)(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, int32_t *owner)
+{
+    if (n_marks == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_mark_owner_long(a, C, marks, n_marks, world, owner);
+#endif
+#define CALL(C_) hipLaunchKernelGGL((k_mark_owner<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, world, owner)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;

@@ -362,7 +362,8 @@ class AddressSharded:
             self._tick("insert_apply", t0)
         return geom
 
-    def query(self, lo=0, hi=None):
+    def query(self, lo=0, hi=None, union=True):
+        """union = False: every rank keeps only the marks of the positions it hashed (for the key-sharded second pass)."""
         torch, ctx, W = self.torch, self.ctx, self.world
         geom = ctx.shard_plan(QUERY, lo, hi)
         survivors = []
@@ -411,6 +412,9 @@ class AddressSharded:
             ctx.shard_mark(sid.data_ptr(), sid.numel())
             self._tick("query_verify", t0)
             survivors.append(trace)
+        self.stats["survivors"] = survivors
+        if not union:
+            return geom
         t0 = time.perf_counter()
         # OR all-reduce of the candidate masks by word ranges: rank r folds chunk r of every rank's mask, the folded
         # chunks are all-gathered (RCCL has no bitwise reduction; an all_gather of whole masks moved W mask sizes per rank)
@@ -434,17 +438,56 @@ class AddressSharded:
         self.query(lo, hi)
         return self.ctx.pass2_filter(abundance)
 
+    def round_sharded_pass2(self, lo=0, hi=None, abundance=(1 << 64) - 1):
+        """The round with the exact filter's table sharded by key hash ("shard the key table by key hash, all-to-all
+        for marked positions only"): no mask union; every rank lists the positions it marked and the owner rank of each
+        position's canonical key (tpc_pass2_mark_owners), the positions travel to the owners (8 bytes each), and each owner
+        runs the exact filter over what it received -- all occurrences of its keys, so the reference's (prev, next) rule and
+        abundance cut see the same sets.  The per-rank junction keys are then all-gathered (HipBackend.union_keys_on_device)."""
+        torch, ctx, W = self.torch, self.ctx, self.world
+        self.insert(lo, hi)
+        self.query(lo, hi, union=False)
+        t0 = time.perf_counter()
+        n = ctx.pass2_marks()
+        pos = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        ctx.pass2_mark_owners(W, pos.data_ptr(), owner.data_ptr())
+        perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        counts = ctx.shard_route(owner.data_ptr(), n, perm.data_ptr(), W)
+        send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        ctx.shard_permute64(pos.data_ptr(), perm.data_ptr(), n, send.data_ptr())
+        recv, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
+        recv = recv.contiguous()
+        self.comm.sync()
+        st = ctx.pass2_filter_positions(recv.data_ptr(), recv.numel(), abundance)
+        st["marks"] = n
+        self.stats["pass2_positions_received"] = recv.numel()
+        self._tick("pass2_sharded", t0)
+        return st
 
-def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False):
-    """One whole enumeration with the filter sharded by address.  After the first pass every rank
-    holds the full candidate mask, so pass 2, the key sort and the id lookup run replicated and
-    every rank ends with the complete result (rank 0 writes it)."""
+
+def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False, sharded_pass2=False):
+    """One whole enumeration with the filter sharded by address.
+    sharded_pass2 = False: after the first pass every rank holds the full candidate mask, so pass 2, the key sort and the id
+    lookup run replicated and every rank ends with the complete result (rank 0 writes it).
+    sharded_pass2 = True: the marks stay where they were found, the exact filter's table is sharded by key hash
+    (round_sharded_pass2), the junction keys are all-gathered and every rank looks up the ids of ITS marked positions; the
+    records of all ranks together (merge_records) are the result."""
     ctx = sharded.ctx
     ctx.run_begin()
-    st = sharded.round(0, None, abundance)
+    if sharded_pass2:
+        st = sharded.round_sharded_pass2(0, None, abundance)
+        if not hasattr(sharded, "_keys_backend"):
+            sharded._keys_backend = HipBackend(ctx)
+            sharded._keys_backend._comm = sharded.comm
+            sharded._keys_backend._cap = 1 << 17
+        sharded._keys_backend.union_keys_on_device(sharded.comm.dist)
+    else:
+        st = sharded.round(0, None, abundance)
     st["junctions"] = ctx.junctions_finalize()
     st["n_marked"], st["n_valid"] = ctx.emit()
-    st["marks"] = st["n_marked"]
+    if not sharded_pass2:
+        st["marks"] = st["n_marked"]
     if fetch:
         st["g"], st["ids"] = ctx.emit_fetch()
     return st
@@ -507,6 +550,7 @@ def bench_main(args, rank, world, local_rank):
     injected = os.environ.get("TPC_BENCH_BACKEND")
     address = getattr(args, "decomposition", "ranges") == "address"
     ctx = None
+    sharded2 = False
     if injected:
         mod, fn = injected.split(":")
         be, n_kmers, p, workload_desc = getattr(importlib.import_module(mod), fn)(args, rank, world)
@@ -532,7 +576,9 @@ def bench_main(args, rank, world, local_rank):
         ctx.seq_upload(text)
         if address:
             sh = AddressSharded(ctx, dist, torch.device("cuda", device))
-            step = lambda: address_sharded_step(sh)
+            # second pass: the exact filter's table sharded by key hash (default), or replicated behind a union of the masks
+            sharded2 = os.environ.get("TPC_REPLICATED_PASS2", "") in ("", "0")
+            step = lambda: address_sharded_step(sh, sharded_pass2=sharded2)
         else:
             be = HipBackend(ctx)
             step = lambda: sharded_step(be, dist, p["L"])
@@ -556,7 +602,7 @@ def bench_main(args, rank, world, local_rank):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
-    if not address:  # address-sharded: every rank already holds the whole result
+    if not address or sharded2:  # (address-sharded with the replicated second pass: every rank already holds the whole result)
         dist.all_reduce(tot)
     dt = float(dt.item())
     if rank == 0:
@@ -573,7 +619,9 @@ def bench_main(args, rank, world, local_rank):
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_desc,
                        "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
-                       "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of level-1 regions per pass, per-function survivor probes, all_gather of the mask" % world)
+                       "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of packed level-1 regions per pass, per-function survivor probes; " % world) +
+                                      ("exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys" if sharded2
+                                       else "OR all-reduce of the candidate mask, replicated second pass")
                        if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
             "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
             "kernel_ms_rank0": kms,
