@@ -763,12 +763,12 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
 }
 
 namespace {
-int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool compact, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
 }
 
 int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
 {
-    return pass2_filter_impl(c, nullptr, 0, true, abundance, n_true, n_false, table_size);
+    return pass2_filter_impl(c, nullptr, 0, false, abundance, n_true, n_false, table_size);
 }
 
 int tpc_pass2_marks(tpc_ctx *c, uint64_t *n_marks)
@@ -799,26 +799,26 @@ int tpc_pass2_mark_owners(tpc_ctx *c, uint32_t world, uint64_t *pos_dev, int32_t
 int tpc_pass2_filter_positions(tpc_ctx *c, const uint64_t *pos_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
 {
     if (n && !pos_dev) return fail(c, -1, "bad arguments");
-    return pass2_filter_impl(c, pos_dev, n, false, abundance, n_true, n_false, table_size);
+    return pass2_filter_impl(c, pos_dev, n, true, abundance, n_true, n_false, table_size);
 }
 
 namespace {
 
-// fmarks == nullptr: the positions marked in this round's mask (compacted here when `compact`); else the given positions
-// (the occurrences whose keys this rank owns, tpc_pass2_mark_owners on every rank + an exchange).  Either way the round's mask is
-// then merged into the run-wide one.
-int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool compact, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+// external = false: the positions marked in this round's mask, compacted here; true: the n_fmarks given positions (possibly
+// none: the occurrences whose keys this rank owns, tpc_pass2_mark_owners on every rank + an exchange; the round's own marks
+// were compacted by tpc_pass2_marks).  Either way the round's mask is then merged into the run-wide one.
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
     if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
     HIPCHK(c, hipSetDevice(c->device));
-    if (compact) {
+    if (!external) {
         int rc = compact_mask(c, c->rmask);
         if (rc) return rc;
         c->marks_valid = true;
-    }
-    const uint64_t *marks = fmarks ? fmarks : c->marks;
-    const uint64_t n_marks = fmarks ? n_fmarks : c->n_marks;
+    } else if (!c->marks_valid) return fail(c, -1, "tpc_pass2_marks first");
+    const uint64_t *marks = external ? fmarks : c->marks;
+    const uint64_t n_marks = external ? n_fmarks : c->n_marks;
     // Exact-filter table, a power of two.  Sized first for the usual case -- on many-genome inputs a key is marked dozens
     // of times, so marks / 4 slots hold the distinct keys several times over and the table (and TrueBifurcations' scan of it)
     // stays cache sized; a probe sequence longer than TPC_FILTER2_PROBE_LIMIT flags a table that is too full and the pass

@@ -18,6 +18,9 @@
 // that are free to proceed (their slot's previous occupant is older still), hence no deadlock.
 // push_batch must be called by whole waves (wave-uniform control flow); lanes without an entry pass
 // ok = false.  No workgroup barrier is needed until flush_final.
+//
+// Where it is used: k_q_hash / k_q_split<.., RB = true> (tpc_qpartition.hip) for levels of 512 bins, where a ring of the
+// barrier bins holds only 32 uint64 entries.  At 256 bins the barrier bins are as fast or faster (tools/bins_bench.hip).
 #pragma once
 #include "tpc_bins.h"
 
@@ -80,7 +83,6 @@ struct RBins {
     template <int N, class Reg, class Lost>
     __device__ __forceinline__ void push_batch(const uint32_t (&b)[N], const T (&val)[N], const bool (&ok)[N], Reg reg, Lost lost)
     {
-        const uint32_t lane = threadIdx.x & 63u;
         uint32_t *wl = wlist + (threadIdx.x >> 6) * LIST;
         uint32_t slot[N];
         uint32_t pend = 0;
