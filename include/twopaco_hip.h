@@ -120,6 +120,15 @@ int tpc_pass2_marks(tpc_ctx *ctx, uint64_t *n_marks);
 int tpc_pass2_mark_owners(tpc_ctx *ctx, uint32_t world, uint64_t *pos_dev, int32_t *owner_dev);
 int tpc_pass2_filter_positions(tpc_ctx *ctx, const uint64_t *pos_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false,
                                uint64_t *table_size);
+/* Text-free variant of the above: what travels is a record of key_words + 1 uint64 per marked position -- the canonical key and
+ * prev | next << 3 as its strand sees them (candidateoccurence.h:25-50) -- so the owner needs none of the text and every rank
+ * can keep just its chunk (option text_window).  tpc_pass2_mark_records writes the records of this rank's marks and their
+ * owners, the host layer routes the rows (tpc_shard_route + tpc_shard_permute_rows, variable all-to-all),
+ * tpc_pass2_filter_records is the exact filter over the received records. */
+int tpc_pass2_mark_records(tpc_ctx *ctx, uint32_t world, uint64_t *records_dev, int32_t *owner_dev);
+int tpc_pass2_filter_records(tpc_ctx *ctx, const uint64_t *records_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false,
+                             uint64_t *table_size);
+int tpc_shard_permute_rows(tpc_ctx *ctx, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, int row_words, uint64_t *dst_dev);
 
 /* BifurcationStorage::Init (bifurcationstorage.h:27-66): sort all junction keys in
  * CompressedString::Less order (compressedstring.h:93-104) and build the id index. */

@@ -104,9 +104,16 @@ def addr_worker(rank, world, port, spec, result_path):
         ctx = capi.Context(0)
         for opt, val in sp.get("options", {}).items():
             ctx.set_option(opt, val)
+        windowed = bool(sp.get("text_window"))
+        if windowed:  # every rank keeps only its chunk of the packed text: the sharding must be known before the upload
+            ctx.set_option("text_window", 1)
+            ctx.shard_config(rank, world)
         ctx.set_params(sp["k"], sp["L"], sp["q"], capi.seed_table(sp["q"], sp["L"], seed=sp["seed"]))
         ctx.seq_upload(text)
-        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True))
+        if windowed:
+            if world > 1 and len(text.bases) > 8 * 512 * world:  # (a window is whole 512-word tiles + a halo: only meaningful on texts of many tiles)
+                assert ctx.stat("text_words") < len(text.bases) * (1.0 / world + 0.25) + 600, (ctx.stat("text_words"), len(text.bases))
+        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True), configure=not windowed)
         out = {"rounds": []}
         for lo, hi in sp["ranges"]:
             geom = sh.insert(lo, hi)

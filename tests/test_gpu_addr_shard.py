@@ -144,6 +144,38 @@ def test_address_sharded_key_sharded_pass2(name, slice_bits, world, tmp_path):
     check(spec, o, gathered, world)
 
 
+@pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("rand6_k25_q3", 12, 4), ("c2_k51_r2", 16, 2), ("rand6_k9_a3", 8, 4),
+                                                   ("c2_k125", 14, 2), ("edge_k5", 7, 4), ("example_k11", 8, 4)])
+def test_address_sharded_text_free_pass2(name, slice_bits, world, tmp_path):
+    """The whole enumeration with the text sharded as well: every rank uploads only its chunk of the packed text (option
+    text_window), (key, prev | next) records travel to the key owners (tpc_pass2_mark_records / tpc_pass2_filter_records), the
+    junction keys are all-gathered and each rank looks up the ids of its own positions."""
+    case = CASES[name]
+    files = case_files(case, tmp_path)
+    spec = {"files": files, "k": case["k"], "L": case["L"], "q": case["q"], "seed": case["seed"], "ranges": [(0, 1 << case["L"])],
+            "abundance": case["abundance"] if case["abundance"] is not None else (1 << 64) - 1, "sharded_pass2": "records", "text_window": True,
+            "options": {"slice_bits": slice_bits}}
+    o = O.Oracle(case["k"], case["L"], case["q"], O.seed_table(case["seed"], case["q"], case["L"]))
+    for f in files:
+        o.add_fasta(f)
+    gathered = run(spec, world, tmp_path)
+    check(spec, o, gathered, world)
+
+
+def test_text_free_pass2_synthetic(tmp_path):
+    """8 x 100 kbp genomes on 4 ranks, text windows + records."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.02)
+    spec = {"workload": "m1", "scale": 0.02, "k": 25, "L": 28, "q": 5, "seed": 12, "ranges": [(0, 1 << 28)], "abundance": (1 << 64) - 1,
+            "sharded_pass2": "records", "text_window": True, "options": {"slice_bits": 14}}
+    o = O.Oracle(25, 28, 5, O.seed_table(12, 5, 28))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    gathered = run(spec, 4, tmp_path)
+    check(spec, o, gathered, 4)
+
+
 def test_key_sharded_pass2_synthetic(tmp_path):
     """8 x 100 kbp genomes, 4 ranks: many occurrences per junction spread over all ranks."""
     from twopaco_amd import synth

@@ -16,7 +16,7 @@ def test_two_ranks_on_gpu(name, tmp_path):
     check_against_single(case, files, run_world(case, files, 2, tmp_path, use_gpu=True))
 
 
-@pytest.mark.parametrize("decomposition", ["ranges", "address", "address+replicated_pass2"])
+@pytest.mark.parametrize("decomposition", ["ranges", "address", "address+positions", "address+replicated"])
 def test_bench_single_rank_over_rccl(decomposition):
     """bench.py's distributed path with the real backend ("nccl" = RCCL) and one rank: the collectives
     of both decompositions run on device tensors; the result equals the plain single-GPU bench's."""
@@ -29,9 +29,8 @@ def test_bench_single_rank_over_rccl(decomposition):
             "--no-cpu-baseline"]
     env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     env.pop("TPC_DIST_BACKEND", None)
-    if decomposition.endswith("+replicated_pass2"):  # the second pass behind a mask union instead of the key-sharded exact filter
-        decomposition = decomposition.split("+")[0]
-        env["TPC_REPLICATED_PASS2"] = "1"
+    if "+" in decomposition:  # the other two forms of the second pass (default: key-sharded, records, text windows)
+        decomposition, env["TPC_PASS2"] = decomposition.split("+")
     out = subprocess.run(base + ["--decomposition", decomposition], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     dist_line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

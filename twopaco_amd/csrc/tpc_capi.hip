@@ -763,7 +763,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
 }
 
 namespace {
-int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size);
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size,
+                      bool records = false);
 }
 
 int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
@@ -802,15 +803,43 @@ int tpc_pass2_filter_positions(tpc_ctx *c, const uint64_t *pos_dev, uint64_t n, 
     return pass2_filter_impl(c, pos_dev, n, true, abundance, n_true, n_false, table_size);
 }
 
+int tpc_pass2_mark_records(tpc_ctx *c, uint32_t world, uint64_t *records_dev, int32_t *owner_dev)
+{
+    if (!c || !c->marks_valid || world == 0 || (c->n_marks && (!records_dev || !owner_dev))) return fail(c, -1, "tpc_pass2_marks first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_marks && tpc_launch_mark_records(make_launch(c), c->C, c->marks, c->n_marks, world, records_dev, owner_dev)) return fail(c, -1, "record launch failed");
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_pass2_filter_records(tpc_ctx *c, const uint64_t *records_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+{
+    if (n && !records_dev) return fail(c, -1, "bad arguments");
+    return pass2_filter_impl(c, records_dev, n, true, abundance, n_true, n_false, table_size, true);
+}
+
+int tpc_shard_permute_rows(tpc_ctx *c, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, int row_words, uint64_t *dst_dev)
+{
+    if (!c || row_words < 1 || (n && (!src_dev || !perm_dev || !dst_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    tpc_launch_permute_rows(c->stream, src_dev, perm_dev, n, row_words, dst_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 namespace {
 
 // external = false: the positions marked in this round's mask, compacted here; true: the n_fmarks given positions (possibly
 // none: the occurrences whose keys this rank owns, tpc_pass2_mark_owners on every rank + an exchange; the round's own marks
 // were compacted by tpc_pass2_marks).  Either way the round's mask is then merged into the run-wide one.
-int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+// records: the external list holds records of C + 1 words (tpc_pass2_mark_records) instead of positions: no text access at all.
+int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size,
+                      bool records)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
-    if (c->text_windowed) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
+    if (c->text_windowed && !records) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
     HIPCHK(c, hipSetDevice(c->device));
     if (!external) {
         int rc = compact_mask(c, c->rmask);
@@ -847,7 +876,8 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
             Timed t(c, TPC_K_FILTER2);
             // key = EMPTY (all ones), meta = 0
             tpc_launch_table_init(c->stream, c->table, cap);
-            if (tpc_launch_filter2(a, c->C, marks, n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
+            if (records ? tpc_launch_filter2_rec(a, c->C, marks, n_marks, c->table, cap, counted, c->counters + 6)
+                        : tpc_launch_filter2(a, c->C, marks, n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
         }
         uint64_t too_full = 0;
         {
@@ -870,7 +900,8 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
                     c->keys = nk;
                     c->keys_cap = ncap;
                 }
-                if (tpc_launch_scan2_write(a, c->C, marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
+                if (records ? tpc_launch_scan2_write_rec(a, c->C, marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C)
+                            : tpc_launch_scan2_write(a, c->C, marks, c->table, cap, abundance, counted, c->scan_blocks, c->keys + c->n_keys * c->C))
                     return fail(c, -1, "scan2 launch failed");
                 c->n_keys += tp;
             }

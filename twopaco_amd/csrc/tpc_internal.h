@@ -144,6 +144,12 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
 // number of distinct keys and the pass must be repeated with a larger one
 #define TPC_FILTER2_PROBE_LIMIT 512u
 int tpc_launch_mark_owner(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, int32_t *owner);  // key-hash owner of every mark
+// text-free variant: records of C + 1 words (canonical key, prev | next << 3) instead of positions
+int tpc_launch_mark_records(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, uint64_t *records, int32_t *owner);
+int tpc_launch_filter2_rec(const TpcLaunch &a, int C, const uint64_t *records, uint64_t n, void *table, uint64_t cap, bool counted, unsigned long long *overflow);
+int tpc_launch_scan2_write_rec(const TpcLaunch &a, int C, const uint64_t *records, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                               const uint64_t *block_off, uint64_t *keys_out);
+int tpc_launch_permute_rows(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, int row_words, uint64_t *dst);  // dst row perm[i] = src row i
 int tpc_launch_filter2(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, void *table, uint64_t cap, bool counted,
                        unsigned long long *overflow);
 // TrueBifurcations in two atomic-free passes over TPC_SCAN2_BLOCKS chunks of the table.

@@ -310,6 +310,117 @@ k_mark_owner(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *
     owner[idx] = (int32_t)((key_hash<C>(ck) >> 40) % world);
 }
 
+// The same, text-free on the owner: every marked position becomes a record of C + 1 words -- the canonical key and
+// prev | next << 3 as the canonical strand sees them (candidateoccurence.h:25-50) -- so that the rank that owns the key needs
+// none of the text (records travel instead of positions: each rank then holds only its chunk of the packed text).
+template <int C>
+__global__ void __launch_bounds__(256)
+k_mark_records(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+               const uint64_t *__restrict__ marks, uint64_t n_marks, uint32_t world, uint64_t *__restrict__ records, int32_t *__restrict__ owner)
+{
+    __shared__ uint64_t s_h0[4];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_marks) return;
+    const uint64_t g = marks[idx];
+    uint64_t fw[C], rc[C];
+    load_kmer<C>(bases, g, P.k, fw);
+    revcomp_kmer<C>(fw, P.k, rc);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    int prev = tpc_text_char(bases, nmask, g - 1);
+    int next = tpc_text_char(bases, nmask, g + P.k);
+    if (!fwd) {  // candidateoccurence.h:43-45
+        const int t = prev;
+        prev = tpc_rc(next);
+        next = tpc_rc(t);
+    }
+    uint64_t ck[C];
+#pragma unroll
+    for (int w = 0; w < C; w++) { ck[w] = fwd ? fw[w] : rc[w]; records[idx * (C + 1) + w] = ck[w]; }
+    records[idx * (C + 1) + C] = (uint64_t)prev | ((uint64_t)next << 3);
+    owner[idx] = (int32_t)((key_hash<C>(ck) >> 40) % world);
+}
+
+// k_filter2 over records instead of (position, text): C == 1: slot key = the key; C > 1: slot key = index of the record that
+// claimed the slot, equality decided on the records (already canonical: no reverse complement needed).
+template <int C, bool COUNTED>
+__global__ void __launch_bounds__(256)
+k_filter2_rec(const uint64_t *__restrict__ records, uint64_t n, Slot *table, uint64_t cap, unsigned long long *overflow)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint64_t ck[C];
+#pragma unroll
+    for (int w = 0; w < C; w++) ck[w] = records[idx * (C + 1) + w];
+    const uint64_t pn = records[idx * (C + 1) + C];
+    const int prev = (int)(pn & 7), next = (int)((pn >> 3) & 7);
+    const uint64_t mask = cap - 1;
+    uint64_t slot = key_hash<C>(ck) & mask;
+    bool claimed = false;
+    uint64_t seen_meta = 0;
+    for (uint32_t probes = 0;; probes++) {
+        if (probes >= TPC_FILTER2_PROBE_LIMIT) { *overflow = 1ull; return; }
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&table[slot]);
+        uint64_t cur = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+        seen_meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
+        if (cur == EMPTY) {
+            cur = atomicCAS((unsigned long long *)&table[slot].key, (unsigned long long)EMPTY, (unsigned long long)(C == 1 ? ck[0] : idx));
+            seen_meta = 0;
+            if (cur == EMPTY) { claimed = true; break; }
+        }
+        if (C == 1) {
+            if (cur == ck[0]) break;
+        } else {
+            uint64_t ok[C];
+#pragma unroll
+            for (int w = 0; w < C; w++) ok[w] = records[cur * (C + 1) + w];
+            if (keys_equal<C>(ok, ck)) break;
+        }
+        slot = (slot + 1) & mask;
+    }
+    unsigned long long *meta = (unsigned long long *)&table[slot].meta;
+    uint64_t want = (1ull << prev) | (1ull << (META_NEXT_SHIFT + next));
+    if (!COUNTED && !claimed) want |= META_MULTI;
+    if ((seen_meta & want) != want) atomicOr(meta, (unsigned long long)want);
+    if (COUNTED) atomicAdd(meta, 1ull << META_COUNT_SHIFT);
+}
+
+__device__ __forceinline__ bool slot_is_junction(const Slot &sl, uint64_t abundance, bool counted);
+
+// k_scan2_write over a table built by k_filter2_rec
+template <int C>
+__global__ void __launch_bounds__(256)
+k_scan2_write_rec(const uint64_t *__restrict__ records, const Slot *__restrict__ table, uint64_t cap, uint64_t chunk, uint64_t abundance, int counted,
+                  const uint64_t *__restrict__ block_off, uint64_t *keys_out)
+{
+    __shared__ uint32_t s_w[4];
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(cap, lo + chunk);
+    uint64_t base = block_off[blockIdx.x];
+    for (uint64_t s0 = lo; s0 < hi; s0 += 256) {
+        const uint64_t s = s0 + threadIdx.x;
+        Slot sl;
+        sl.key = EMPTY; sl.meta = 0;
+        if (s < hi) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(&table[s]);
+            sl.key = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+            sl.meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
+        }
+        const bool tp = sl.key != EMPTY && slot_is_junction(sl, abundance, counted != 0);
+        uint32_t total;
+        const uint32_t ex = block_excl_scan256(tp ? 1u : 0u, s_w, total);
+        if (tp) {
+            const uint64_t o = base + ex;
+            if (C == 1) keys_out[o] = sl.key;
+            else {
+#pragma unroll
+                for (int w = 0; w < C; w++) keys_out[o * C + w] = records[sl.key * (C + 1) + w];
+            }
+        }
+        base += total;
+    }
+}
+
 // TrueBifurcations (VE.h:1228-1256) without global atomics: every workgroup owns a contiguous chunk
 // of the table; pass 1 counts (used slots, true junctions) per chunk, a scan turns the counts into
 // offsets, pass 2 walks the same chunk again and writes the junction keys at its offset.
@@ -567,6 +678,51 @@ int TPC_PASS2_FN(tpc_launch_mark_owner)(const TpcLaunch &a, int C, const uint64_
     if (C > 2) return tpc_launch_mark_owner_long(a, C, marks, n_marks, world, owner);
 #endif
 #define CALL(C_) hipLaunchKernelGGL((k_mark_owner<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, n_marks, world, owner)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_mark_records_long(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, uint64_t *records, int32_t *owner);
+int TPC_PASS2_FN(tpc_launch_mark_records)(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, uint64_t *records, int32_t *owner)
+{
+    if (n_marks == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_mark_records_long(a, C, marks, n_marks, world, records, owner);
+#endif
+#define CALL(C_) hipLaunchKernelGGL((k_mark_records<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, n_marks, world, records, owner)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_filter2_rec_long(const TpcLaunch &a, int C, const uint64_t *records, uint64_t n, void *table, uint64_t cap, bool counted, unsigned long long *overflow);
+int TPC_PASS2_FN(tpc_launch_filter2_rec)(const TpcLaunch &a, int C, const uint64_t *records, uint64_t n, void *table, uint64_t cap, bool counted,
+                                         unsigned long long *overflow)
+{
+    if (n == 0) return 0;
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_filter2_rec_long(a, C, records, n, table, cap, counted, overflow);
+#endif
+#define CALL(C_)                                                                                                                                  \
+    if (counted) hipLaunchKernelGGL((k_filter2_rec<C_, true>), dim3(nblk(n, 256)), dim3(256), 0, a.stream, records, n, (Slot *)table, cap, overflow); \
+    else hipLaunchKernelGGL((k_filter2_rec<C_, false>), dim3(nblk(n, 256)), dim3(256), 0, a.stream, records, n, (Slot *)table, cap, overflow)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+uint64_t TPC_PASS2_FN(tpc_scan2_chunk)(uint64_t cap);
+int tpc_launch_scan2_write_rec_long(const TpcLaunch &a, int C, const uint64_t *records, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                                    const uint64_t *block_off, uint64_t *keys_out);
+int TPC_PASS2_FN(tpc_launch_scan2_write_rec)(const TpcLaunch &a, int C, const uint64_t *records, const void *table, uint64_t cap, uint64_t abundance, bool counted,
+                                             const uint64_t *block_off, uint64_t *keys_out)
+{
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_scan2_write_rec_long(a, C, records, table, cap, abundance, counted, block_off, keys_out);
+#endif
+    const uint64_t chunk = TPC_PASS2_FN(tpc_scan2_chunk)(cap);
+#define CALL(C_) hipLaunchKernelGGL((k_scan2_write_rec<C_>), dim3(TPC_SCAN2_BLOCKS), dim3(256), 0, a.stream, records, (const Slot *)table, cap, chunk, abundance, counted ? 1 : 0, block_off, keys_out)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;

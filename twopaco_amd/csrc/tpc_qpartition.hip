@@ -730,6 +730,15 @@ __global__ void k_permute64(const uint64_t *__restrict__ src, const uint32_t *__
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[perm[i]] = src[i];
 }
 
+__global__ void k_permute_rows(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n, int row_words, uint64_t *__restrict__ dst)
+{   // one thread per word: dst row perm[i] = src row i
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, total = n * (uint64_t)row_words;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const uint64_t i = j / (uint64_t)row_words, w = j - i * (uint64_t)row_words;
+        dst[(uint64_t)perm[i] * (uint64_t)row_words + w] = src[j];
+    }
+}
+
 // survivors whose fn_count answers (in send order: hit[perm[...]]) are all 1; order of the output is not significant
 __global__ void __launch_bounds__(256)
 k_select(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8_t *__restrict__ hit, const uint32_t *__restrict__ perm,
@@ -1085,6 +1094,12 @@ int tpc_launch_route(hipStream_t s, const int32_t *owner, uint64_t n, unsigned l
 int tpc_launch_permute64(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, uint64_t *dst)
 {
     if (n) hipLaunchKernelGGL(k_permute64, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, src, perm, n, dst);
+    return 0;
+}
+
+int tpc_launch_permute_rows(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, int row_words, uint64_t *dst)
+{
+    if (n) hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)std::min<uint64_t>((n * row_words + 255) / 256, 8192)), dim3(256), 0, s, src, perm, n, row_words, dst);
     return 0;
 }
 

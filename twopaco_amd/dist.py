@@ -285,14 +285,15 @@ class AddressSharded:
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
     list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
 
-    def __init__(self, ctx, dist, device, compact=True):
+    def __init__(self, ctx, dist, device, compact=True, configure=True):
         import torch
         self.ctx, self.torch = ctx, torch
         self.compact = compact  # exact-size exchange of the level-1 regions (tpc_shard_pack) instead of equal blocks
         self.comm = _Comm(dist, device)
         self.device = device
         self.rank, self.world = self.comm.rank, self.comm.world
-        ctx.shard_config(self.rank, self.world)
+        if configure:  # False: the caller did it before tpc_seq_upload (needed for option text_window to take effect)
+            ctx.shard_config(self.rank, self.world)
         self._bufs = {}
         self.stats = {}
         self.t = {}   # seconds per phase, accumulated (host clock; every phase ends synchronised)
@@ -438,17 +439,36 @@ class AddressSharded:
         self.query(lo, hi)
         return self.ctx.pass2_filter(abundance)
 
-    def round_sharded_pass2(self, lo=0, hi=None, abundance=(1 << 64) - 1):
+    def round_sharded_pass2(self, lo=0, hi=None, abundance=(1 << 64) - 1, records=False):
         """The round with the exact filter's table sharded by key hash ("shard the key table by key hash, all-to-all
         for marked positions only"): no mask union; every rank lists the positions it marked and the owner rank of each
         position's canonical key (tpc_pass2_mark_owners), the positions travel to the owners (8 bytes each), and each owner
         runs the exact filter over what it received -- all occurrences of its keys, so the reference's (prev, next) rule and
-        abundance cut see the same sets.  The per-rank junction keys are then all-gathered (HipBackend.union_keys_on_device)."""
+        abundance cut see the same sets.  The per-rank junction keys are then all-gathered (HipBackend.union_keys_on_device).
+        records = True: (key, prev | next) records travel instead of positions, the owner reads no text: every rank can hold
+        just its chunk of the packed text (option text_window)."""
         torch, ctx, W = self.torch, self.ctx, self.world
         self.insert(lo, hi)
         self.query(lo, hi, union=False)
         t0 = time.perf_counter()
         n = ctx.pass2_marks()
+        if records:
+            rw = ctx.key_words() + 1
+            rec = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
+            owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            ctx.pass2_mark_records(W, rec.data_ptr(), owner.data_ptr())
+            perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            counts = ctx.shard_route(owner.data_ptr(), n, perm.data_ptr(), W)
+            send = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
+            ctx.shard_permute_rows(rec.data_ptr(), perm.data_ptr(), n, rw, send.data_ptr())
+            recv, _ = self.comm.a2a_var(send[:n * rw].contiguous(), [c * rw for c in counts])
+            recv = recv.contiguous()
+            self.comm.sync()
+            st = ctx.pass2_filter_records(recv.data_ptr(), recv.numel() // rw, abundance)
+            st["marks"] = n
+            self.stats["pass2_positions_received"] = recv.numel() // rw
+            self._tick("pass2_sharded", t0)
+            return st
         pos = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         ctx.pass2_mark_owners(W, pos.data_ptr(), owner.data_ptr())
@@ -467,6 +487,7 @@ class AddressSharded:
 
 
 def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False, sharded_pass2=False):
+    # sharded_pass2: False, True / "positions", or "records" (text-free: see AddressSharded.round_sharded_pass2)
     """One whole enumeration with the filter sharded by address.
     sharded_pass2 = False: after the first pass every rank holds the full candidate mask, so pass 2, the key sort and the id
     lookup run replicated and every rank ends with the complete result (rank 0 writes it).
@@ -476,7 +497,7 @@ def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False, sharded_
     ctx = sharded.ctx
     ctx.run_begin()
     if sharded_pass2:
-        st = sharded.round_sharded_pass2(0, None, abundance)
+        st = sharded.round_sharded_pass2(0, None, abundance, records=sharded_pass2 == "records")
         if not hasattr(sharded, "_keys_backend"):
             sharded._keys_backend = HipBackend(ctx)
             sharded._keys_backend._comm = sharded.comm
@@ -572,13 +593,21 @@ def bench_main(args, rank, world, local_rank):
             args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"])
         text = capi.PackedText.from_codes(recs)
         ctx = capi.Context(device)
+        # second pass of the address decomposition (TPC_PASS2): "records" (default) = exact filter's table sharded by key hash,
+        # (key, prev | next) records travel, every rank holds only its chunk of the text; "positions" = the same with 8-byte
+        # positions and the whole text on every rank; "replicated" = union of the masks, every rank runs the whole second pass
+        pass2 = os.environ.get("TPC_PASS2", "records") if address else "replicated"
+        if pass2 not in ("records", "positions", "replicated"):
+            raise RuntimeError("TPC_PASS2 must be records, positions or replicated")
+        sharded2 = pass2 != "replicated"
+        if address and pass2 == "records":
+            ctx.set_option("text_window", 1)
+            ctx.shard_config(rank, world)  # before the upload: the window depends on it
         ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=20240229))
         ctx.seq_upload(text)
         if address:
-            sh = AddressSharded(ctx, dist, torch.device("cuda", device))
-            # second pass: the exact filter's table sharded by key hash (default), or replicated behind a union of the masks
-            sharded2 = os.environ.get("TPC_REPLICATED_PASS2", "") in ("", "0")
-            step = lambda: address_sharded_step(sh, sharded_pass2=sharded2)
+            sh = AddressSharded(ctx, dist, torch.device("cuda", device), configure=pass2 != "records")
+            step = lambda: address_sharded_step(sh, sharded_pass2=pass2 if sharded2 else False)
         else:
             be = HipBackend(ctx)
             step = lambda: sharded_step(be, dist, p["L"])
@@ -620,8 +649,9 @@ def bench_main(args, rank, world, local_rank):
             "config": {"workload": workload_desc,
                        "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
                        "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of packed level-1 regions per pass, per-function survivor probes; " % world) +
-                                      ("exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys" if sharded2
-                                       else "OR all-reduce of the candidate mask, replicated second pass")
+                                      ({"records": "text sharded too; exact-filter table sharded by key hash ((key, prev|next) records to the key's owner), all_gather of the junction keys",
+                                        "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
+                                        "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
                        if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
             "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
             "kernel_ms_rank0": kms,
