@@ -165,6 +165,12 @@ int tpc_emit(tpc_ctx *ctx, uint64_t *n_marked, uint64_t *n_valid);
 /* Copy the emit lists to the host: g_host[n_marked], id_host[n_marked]. */
 int tpc_emit_fetch(tpc_ctx *ctx, uint64_t *g_host, int64_t *id_host);
 
+/* The (position, id) lists tpc_emit left on the device, out to / in from device buffers: a multi-GPU host whose ranks each looked up
+ * the ids of their own marked positions gathers the lists (in rank order = position order) on the rank that formats the
+ * output and installs them there before tpc_emit_stream. */
+int tpc_emit_export(tpc_ctx *ctx, uint64_t *g_dev, int64_t *id_dev);
+int tpc_emit_import(tpc_ctx *ctx, const uint64_t *g_dev, const int64_t *id_dev, uint64_t n);
+
 /* The output file's bytes, built on the device after tpc_emit: FlushEdgeResults (VE.h:837-854) +
  * JunctionPositionWriter::WriteJunction (junctionapi.h:118-132).  12-byte little-endian records
  * (u32 position in its sequence, i64 id) in (sequence, position) order; the first / last k-mer of

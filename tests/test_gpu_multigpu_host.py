@@ -123,6 +123,20 @@ def test_emulated_ranks_equal_block_exchange(capi, tmp_path, name, ranks, monkey
     e.close()
 
 
+@pytest.mark.parametrize("name,ranks", [("rand6_k9_fp_r4", 2), ("c2_k51_r2", 4), ("m2_small", 4)])
+def test_emulated_ranks_replicated_second_pass(capi, tmp_path, name, ranks, monkeypatch):
+    """TWOPACO_REPLICATED_PASS2: union of the candidate masks + the single-GPU second pass on rank 0 (which then keeps the whole
+    text) instead of the default key-sharded second pass; same bytes."""
+    monkeypatch.setenv("TWOPACO_REPLICATED_PASS2", "1")
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    e.close()
+
+
 def test_cli_gpus_flag(tmp_path):
     case = CASES["rand6_k9_fp_r4"]
     exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")

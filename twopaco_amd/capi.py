@@ -20,7 +20,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_pack", "tpc_shard_apply_packed", "tpc_pass2_marks", "tpc_pass2_mark_owners", "tpc_pass2_filter_positions",
-               "tpc_pass2_mark_records", "tpc_pass2_filter_records", "tpc_shard_permute_rows",
+               "tpc_pass2_mark_records", "tpc_pass2_filter_records", "tpc_shard_permute_rows", "tpc_emit_export", "tpc_emit_import",
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",

@@ -1173,6 +1173,41 @@ int tpc_emit_fetch(tpc_ctx *c, uint64_t *g_host, int64_t *id_host)
     return 0;
 }
 
+int tpc_emit_export(tpc_ctx *c, uint64_t *g_dev, int64_t *id_dev)
+{
+    if (!c || (c->n_emit && (!g_dev || !id_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_emit) {
+        HIPCHK(c, hipMemcpyAsync(g_dev, c->marks, c->n_emit * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(id_dev, c->emit_id, c->n_emit * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_emit_import(tpc_ctx *c, const uint64_t *g_dev, const int64_t *id_dev, uint64_t n)
+{
+    if (!c || !c->finalized || (n && (!g_dev || !id_dev))) return fail(c, -1, "junctions_finalize first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure(c, c->marks, c->marks_cap, n);
+    if (rc) return rc;
+    if (n > c->emit_cap || !c->emit_id) {
+        if (c->emit_id) (void)hipFree(c->emit_id);
+        c->emit_id = nullptr; c->emit_cap = 0;
+        const uint64_t cap = n + n / 8 + 16;
+        HIPCHK(c, hipMalloc((void **)&c->emit_id, cap * sizeof(int64_t)));
+        c->emit_cap = cap;
+    }
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->marks, g_dev, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->emit_id, id_dev, n * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_marks = n; c->n_emit = n;
+    c->marks_valid = false;  // the list no longer is this rank's round list
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ address-sharded filter
 int tpc_shard_config(tpc_ctx *c, uint32_t rank, uint32_t world)
 {

@@ -303,7 +303,7 @@ namespace TwoPaCo
 	void ShardedRank::Release()
 	{
 		(void)hipSetDevice(device);
-		for (int i = 0; i < 13; i++)
+		for (int i = 0; i < 16; i++)
 		{
 			if (buf[i]) (void)hipFree(buf[i]);
 			buf[i] = 0;
@@ -314,7 +314,7 @@ namespace TwoPaCo
 	// ------------------------------------------------------------------------------------------ the pass
 	namespace
 	{
-		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED };
+		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED, REC, REC2, GATHER };
 
 		// hash -> exchange -> (overflow lists) ; returns the receive buffers in r.buf[RECV_R], r.buf[RECV_C]
 		void HashAndExchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, uint64_t batch, uint64_t lo, uint64_t hi)
@@ -479,6 +479,7 @@ namespace TwoPaCo
 			LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");
 		}
 
+		if (r.shardedSecondPass) return;  // the marks stay on the rank that found them (ShardedSecondPass)
 		// ---- union of the candidate masks: OR all-reduce by word ranges
 		const uint64_t words = tpc_mask_words(r.ctx);
 		const uint64_t chunk = (words + W - 1) / W;
@@ -490,5 +491,83 @@ namespace TwoPaCo
 		LibCheck(r.ctx, tpc_mask_or_blocks(r.ctx, parts, uint32_t(W), chunk, folded), "mask_or_blocks");
 		net.AllGather(r.rank, folded, mine, chunk * 4);
 		LibCheck(r.ctx, tpc_mask_import(r.ctx, mine), "mask_import");
+	}
+	void ShardedSecondPass(ShardedRank & r, Transport & net, uint64_t abundance, uint64_t counters[4])
+	{
+		const int W = net.Ranks();
+		uint64_t n = 0;
+		LibCheck(r.ctx, tpc_pass2_marks(r.ctx, &n), "pass2_marks");
+		const int rowWords = tpc_key_words(r.ctx) + 1;
+		const size_t rowBytes = size_t(rowWords) * 8;
+		uint64_t * records = static_cast<uint64_t*>(r.Ensure(REC, std::max<uint64_t>(n, 1) * rowBytes));
+		int32_t * owner = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(n, 1) * 4));
+		LibCheck(r.ctx, tpc_pass2_mark_records(r.ctx, uint32_t(W), records, owner), "pass2_mark_records");
+		uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(n, 1) * 4));
+		uint64_t counts[64];
+		LibCheck(r.ctx, tpc_shard_route(r.ctx, owner, n, perm, counts), "shard_route");
+		uint64_t * send = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(n, 1) * rowBytes));
+		LibCheck(r.ctx, tpc_shard_permute_rows(r.ctx, records, perm, n, rowWords, send), "shard_permute_rows");
+		std::vector<uint64_t> all;
+		net.ExchangeHost(r.rank, counts, W, all);
+		std::vector<uint64_t> recvCounts(W);
+		uint64_t arriving = 0;
+		for (int s = 0; s < W; s++)
+		{
+			recvCounts[s] = all[size_t(s) * W + r.rank];
+			arriving += recvCounts[s];
+		}
+
+		uint64_t * mine = static_cast<uint64_t*>(r.Ensure(REC2, std::max<uint64_t>(arriving, 1) * rowBytes));
+		net.AllToAllV(r.rank, send, counts, mine, recvCounts.data(), rowBytes);
+		uint64_t truePositives = 0, falsePositives = 0, tableSize = 0;
+		LibCheck(r.ctx, tpc_pass2_filter_records(r.ctx, mine, arriving, abundance, &truePositives, &falsePositives, &tableSize), "pass2_filter_records");
+		counters[0] = truePositives; counters[1] = falsePositives; counters[2] = tableSize; counters[3] = n;
+	}
+
+	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions)
+	{
+		const int W = net.Ranks();
+		const size_t keyBytes = size_t(tpc_key_words(r.ctx)) * 8;
+		// ---- all junction keys on every rank
+		uint64_t mineKeys = 0;
+		LibCheck(r.ctx, tpc_junction_keys_export(r.ctx, 0, 0, &mineKeys), "junction_keys_export");
+		std::vector<uint64_t> all;
+		net.ExchangeHost(r.rank, &mineKeys, 1, all);
+		const uint64_t most = std::max<uint64_t>(1, *std::max_element(all.begin(), all.end()));
+		uint64_t * block = static_cast<uint64_t*>(r.Ensure(MISC_A, most * keyBytes));
+		uint64_t * gathered = static_cast<uint64_t*>(r.Ensure(GATHER, size_t(W) * most * keyBytes));
+		LibCheck(r.ctx, tpc_junction_keys_export(r.ctx, block, most, &mineKeys), "junction_keys_export");
+		net.AllGather(r.rank, block, gathered, most * keyBytes);
+		for (int s = 0; s < W; s++)
+		{
+			LibCheck(r.ctx, tpc_junction_keys_import(r.ctx, reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(gathered) + size_t(s) * most * keyBytes), all[s], s > 0 ? 1 : 0),
+				"junction_keys_import");
+		}
+
+		LibCheck(r.ctx, tpc_junctions_finalize(r.ctx, junctions), "junctions_finalize");
+		// ---- ids of this rank's positions, then every list to rank 0 (rank order = position order)
+		uint64_t marked = 0, valid = 0;
+		LibCheck(r.ctx, tpc_emit(r.ctx, &marked, &valid), "emit");
+		uint64_t * g = static_cast<uint64_t*>(r.Ensure(REC, std::max<uint64_t>(marked, 1) * 8));
+		int64_t * id = static_cast<int64_t*>(r.Ensure(REC2, std::max<uint64_t>(marked, 1) * 8));
+		LibCheck(r.ctx, tpc_emit_export(r.ctx, g, id), "emit_export");
+		net.ExchangeHost(r.rank, &marked, 1, all);
+		std::vector<uint64_t> sendCounts(W, 0), recvCounts(W, 0);
+		sendCounts[0] = marked;
+		uint64_t total = 0;
+		if (r.rank == 0)
+		{
+			for (int s = 0; s < W; s++)
+			{
+				recvCounts[s] = all[s];
+				total += all[s];
+			}
+		}
+
+		uint64_t * gAll = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(total, 1) * 8));
+		int64_t * idAll = static_cast<int64_t*>(r.Ensure(GATHER, std::max<uint64_t>(total, 1) * 8));
+		net.AllToAllV(r.rank, g, sendCounts.data(), gAll, recvCounts.data(), 8);
+		net.AllToAllV(r.rank, id, sendCounts.data(), idAll, recvCounts.data(), 8);
+		if (r.rank == 0) LibCheck(r.ctx, tpc_emit_import(r.ctx, gAll, idAll, total), "emit_import");
 	}
 }

@@ -78,17 +78,32 @@ namespace TwoPaCo
 		int device;
 		tpc_ctx * ctx;
 		// device scratch owned by the rank (grown on demand, freed by Release)
-		void * buf[13];
-		size_t cap[13];
+		void * buf[16];
+		size_t cap[16];
 		// exact-size exchange of the level-1 regions (tpc_shard_pack / tpc_shard_apply_packed); false: equal blocks
 		bool compactExchange;
+		// second pass with the exact filter's table sharded by key hash (ShardedSecondPass; the text is then sharded on every
+		// rank); false: union of the candidate masks, the single-GPU second pass on rank 0, which keeps the whole text
+		bool shardedSecondPass;
 		uint64_t regionBytesSent;
-		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), regionBytesSent(0) { for (int i = 0; i < 13; i++) { buf[i] = 0; cap[i] = 0; } }
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};
 
 	void ShardedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi);
+
+	// The round's second pass when r.shardedSecondPass (CandidateFinalFilteringWorker + TrueBifurcations, reference
+	// vertexenumerator.h:708-829, 1228-1256, with the key table cut over the ranks by key hash): every rank turns its own marks
+	// into (canonical key, prev | next) records, the records travel to the key owners, each owner runs the exact filter over all
+	// occurrences of its keys.  counters = {true junctions, false junctions, table size, marks} of THIS rank: the round's
+	// figures are their sums over the ranks.
+	void ShardedSecondPass(ShardedRank & r, Transport & net, uint64_t abundance, uint64_t counters[4]);
+
+	// After the last round: every rank learns all junction keys (all-gather), sorts them (tpc_junctions_finalize: the same ids
+	// everywhere), looks up the ids of its own marked positions, and the (position, id) lists are gathered on rank 0 in rank
+	// order = position order, where they replace rank 0's list (tpc_emit_import) for the output stream.
+	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions);
 }
 
 #endif

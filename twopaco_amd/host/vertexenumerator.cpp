@@ -108,6 +108,10 @@ namespace TwoPaCo
 				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : autoGb) * double(1ull << 30));
 				const int gpus = std::max(1, options.gpus);
 				const bool sharded = gpus > 1 || options.forceSharded;
+				// several GPUs: the second pass's exact-filter table is sharded by key hash and the text stays sharded (multigpu.h:
+				// ShardedSecondPass / ShardedFinish); TWOPACO_REPLICATED_PASS2=1: union of the candidate masks, then the single-GPU
+				// second pass on rank 0, which then keeps the whole text
+				const bool shardedPass2 = sharded && std::getenv("TWOPACO_REPLICATED_PASS2") == 0;
 				// filter slices of 2^20 bits (128 KiB of LDS) unless the filter is too small to give every rank its level-1 buckets:
 				// the fan-out 2^(L - slice_bits) is split over two levels and the first must have at least `gpus` buckets
 				int logGpus = 0;
@@ -163,6 +167,8 @@ namespace TwoPaCo
 						if (sharded)
 						{
 							Check(tpc_set_option(ctx_, "slice_bits", shardSliceBits), "set_option");
+							// with the second pass sharded by key hash no rank needs more than its chunk of the text, rank 0 included
+							if (shardedPass2) Check(tpc_set_option(ctx_, "text_window", 1), "set_option");
 							Check(tpc_shard_config(ctx_, 0, uint32_t(gpus)), "shard_config");
 						}
 
@@ -230,7 +236,11 @@ namespace TwoPaCo
 					peers_[0].rank = 0; peers_[0].device = devices[0]; peers_[0].ctx = ctx_;
 					// testing knob: TWOPACO_EQUAL_EXCHANGE=1 moves the level-1 regions as equal fixed-capacity blocks instead of packed
 					const bool compact = std::getenv("TWOPACO_EQUAL_EXCHANGE") == 0;
-					for (int r = 0; r < gpus; r++) peers_[r].compactExchange = compact;
+					for (int r = 0; r < gpus; r++)
+					{
+						peers_[r].compactExchange = compact;
+						peers_[r].shardedSecondPass = shardedPass2;
+					}
 					std::vector<std::string> errors(gpus);
 					std::vector<std::thread> pool;
 					for (int r = 1; r < gpus; r++)
@@ -323,11 +333,13 @@ namespace TwoPaCo
 					PhaseTimer sub;
 					uint64_t kmers = 0;
 					uint64_t marks = 0;
+					std::vector<uint64_t> roundCounters;  // sharded second pass: {true, false, table, marks} per rank
 					if (net)
 					{
 						// every rank runs the same round; rank 0 is this thread's context
 						std::vector<std::string> errors(gpus);
 						std::vector<std::thread> pool;
+						roundCounters.assign(size_t(gpus) * 4, 0);
 						for (int r = 0; r < gpus; r++)
 						{
 							pool.emplace_back([&, r]()
@@ -335,6 +347,7 @@ namespace TwoPaCo
 								try
 								{
 									ShardedFirstPass(peers_[r], *net, int(hashFunctions), low, high);
+									if (shardedPass2) ShardedSecondPass(peers_[r], *net, abundance, &roundCounters[size_t(r) * 4]);
 								}
 								catch (std::exception & e)
 								{
@@ -366,8 +379,22 @@ namespace TwoPaCo
 					mark = time(0);
 					logStream << "2\t";
 					uint64_t truePositives = 0, falsePositives = 0, hashTableSize = 0;
-					if (!nothing) Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
-					if (net) marks = uint64_t(std::max<int64_t>(0, tpc_get_stat(ctx_, "round_marks")));
+					if (net && shardedPass2)
+					{
+						// the ranks ran it (ShardedSecondPass above): keys and marks are disjoint over the ranks, the round's figures are sums
+						for (int r = 0; r < gpus; r++)
+						{
+							truePositives += roundCounters[size_t(r) * 4];
+							falsePositives += roundCounters[size_t(r) * 4 + 1];
+							hashTableSize += roundCounters[size_t(r) * 4 + 2];
+							marks += roundCounters[size_t(r) * 4 + 3];
+						}
+					}
+					else
+					{
+						if (!nothing) Check(tpc_pass2_filter(ctx_, abundance, &truePositives, &falsePositives, &hashTableSize), "pass2_filter");
+						if (net) marks = uint64_t(std::max<int64_t>(0, tpc_get_stat(ctx_, "round_marks")));
+					}
 					sub.Lap("  round: exact filter");
 					logStream << time(0) - mark << "\t";
 					mark = time(0);
@@ -384,13 +411,39 @@ namespace TwoPaCo
 				timer.Lap("rounds (insert, query, exact filter)");
 				mark = time(0);
 				uint64_t junctions = 0;
-				if (!nothing) Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
+				if (net && shardedPass2)
+				{
+					// key union, key sort, id lookup of every rank's own positions, (position, id) lists gathered on rank 0
+					std::vector<std::string> errors(gpus);
+					std::vector<uint64_t> perRank(gpus, 0);
+					std::vector<std::thread> pool;
+					for (int r = 0; r < gpus; r++)
+					{
+						pool.emplace_back([&, r]()
+						{
+							try
+							{
+								ShardedFinish(peers_[r], *net, &perRank[r]);
+							}
+							catch (std::exception & e)
+							{
+								errors[r] = e.what();
+								net->Barrier().Fail(e.what());
+							}
+						});
+					}
+
+					for (std::thread & th : pool) th.join();
+					for (const std::string & e : errors) if (!e.empty()) throw std::runtime_error(e);
+					junctions = perRank[0];
+				}
+				else if (!nothing) Check(tpc_junctions_finalize(ctx_, &junctions), "junctions_finalize");
 				vertices_ = junctions;
 				logStream << "Reallocating bifurcations time: " << time(0) - mark << std::endl;
 
 				mark = time(0);
 				uint64_t marked = 0, valid = 0;
-				if (!nothing) Check(tpc_emit(ctx_, &marked, &valid), "emit");
+				if (!nothing && !(net && shardedPass2)) Check(tpc_emit(ctx_, &marked, &valid), "emit");
 				// EdgeConstructionWorker + FlushEdgeResults + JunctionPositionWriter (reference vertexenumerator.h:837-854,
 				// 927-958, junctionapi.h:118-132): the device formats the whole junction stream -- records in
 				// (sequence, position) order, stub ids for sequence ends, one separator per sequence-id step
