@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end CLI timing on a synthetic workload: writes the FASTA files, runs bin/twopaco, prints
-wall time and junction occurrences per second.  python tools/e2e_cli.py [m1|m2] [threads]"""
+wall time and junction occurrences per second.  python tools/e2e_cli.py [m1|m2] [threads]
+E2E_EXTRA="--gpus 2 --emulate-ranks": extra CLI flags (e.g. the multi-GPU host with its ranks emulated on one device)."""
 import os, re, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +27,7 @@ for rep in range(int(os.environ.get("E2E_RUNS", "3"))):
     time.sleep(pause)
     out = os.path.join(tmp, "out%d.bin" % rep)  # a fresh file each time (truncating a cached 500 MB file costs ~90 ms)
     t0 = time.time()
-    res = subprocess.run([exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", "20240229", "-o", out] + files,
+    res = subprocess.run([exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", "20240229", "-o", out] + os.environ.get("E2E_EXTRA", "").split() + files,
                          env=dict(os.environ, TWOPACO_TIMING="1"), capture_output=True, text=True)
     wall = time.time() - t0
     occ = int(re.search(r"True marks count: (\d+)", res.stdout).group(1))
