@@ -178,6 +178,7 @@ int read_counter(tpc_ctx *c, int i, uint64_t *out)
 }
 
 int flush_pending_apply(tpc_ctx *c);
+bool ensure_pbuf(tpc_ctx *c, int i, size_t need);
 
 int materialize_reset(tpc_ctx *c)
 {   // a pending tpc_filter_reset becomes a real zero fill before anything reads the filter
@@ -194,7 +195,14 @@ int flush_pending_apply(tpc_ctx *c)
     if (!c->pending_apply) return 0;
     c->pending_apply = false;
     Timed t(c, TPC_K_FUSED);
-    // the insert's overflow entries were set aside (the list buffer is shared with the query): put them back for k_part_ovf
+    // the insert's overflow entries were set aside (the list buffer is shared with the query): put them back for k_part_ovf.
+    // The shared buffers may have been reallocated since the insert (ensure_pbuf for a query plan of another size): take the
+    // pointers from the context as it is now, never the ones saved with the plan
+    const size_t ovf_need = std::max<size_t>((size_t)c->pending_novf * sizeof(uint64_t), sizeof(uint64_t));
+    if (!ensure_pbuf(c, 4, ovf_need) || !ensure_pbuf(c, 5, 32 * sizeof(unsigned long long))) return fail(c, -10, "out of device memory for the deferred apply's overflow list");
+    c->pending_pl.ovf = (uint64_t *)c->pbuf[4];
+    c->pending_pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+    c->pending_pl.ovf_cap = std::min<uint64_t>(c->pending_pl.ovf_cap, c->pbytes[4] / sizeof(uint64_t));
     const unsigned long long cur[2] = {c->pending_novf, 0};
     if (c->pending_novf) HIPCHK(c, hipMemcpyAsync(c->pending_pl.ovf, c->ikeep_ovf, c->pending_novf * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pending_pl.ovf_cur, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));

@@ -248,7 +248,7 @@ k_query(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__res
 template <int Q>
 __global__ void __launch_bounds__(TPC_TILE_THREADS)
 k_split(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
-        const uint32_t *__restrict__ nmask, const uint32_t *__restrict__ todo_in, uint32_t *__restrict__ todo_out, int phase, uint64_t n_text,
+        const uint32_t *__restrict__ nmask, const uint32_t *todo_in, uint32_t *todo_out, int phase, uint64_t n_text,
         uint32_t *__restrict__ filter, uint32_t *__restrict__ bins, uint64_t bin_size)
 {
     __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];

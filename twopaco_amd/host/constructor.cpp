@@ -5,7 +5,10 @@
 // -o/--outfile ("de_bruijn.bin"), --test, and the FASTA file names.  Extra flags that do not
 // exist in the reference: --seed S (pin the hash tables, see seed.h), --device N,
 // --test-first (test-then-set insert), --gpus N (Bloom filter sharded by bit address over N GPUs of the node,
-// RCCL between them; --no-rccl: device-to-device copies; --emulate-ranks: N ranks on one device, for testing).  Errors go to stderr as "\nError: <what>\n", exit code 1
+// RCCL between them; --no-rccl: device-to-device copies; --emulate-ranks: N ranks on one device, for testing),
+// --save-filter F / --load-filter F (checkpoint of the Bloom filter after each round's first-pass insert, the reference's
+// commented-out ReloadBloomFilter, vertexenumerator.h:29,113-121; a run that loads skips the insert), and with --test,
+// --seed makes the trials reproducible (the reference's are not, test.cpp:169).  Errors go to stderr as "\nError: <what>\n", exit code 1
 // (reference constructor.cpp:179-188).
 #include <cmath>
 #include <cstdint>
@@ -56,6 +59,7 @@ namespace
 		std::cout << "USAGE: twopaco {-f <integer>|--filtermemory <float>} [-k <oddc>] [-q <integer>] [-r <integer>]" << std::endl
 			<< "               [-t <integer>] [-a <integer>] [--tmpdir <directory name>] [-o <file name>] [--test]" << std::endl
 			<< "               [--seed <integer>] [--device <integer>] [--test-first] [--gpus <power of two>] [--no-rccl]" << std::endl
+			<< "               [--save-filter <file>] [--load-filter <file>]" << std::endl
 			<< "               <fasta files with genomes> ..." << std::endl
 			<< "       -q: 1..16 hash functions (the reference takes any number; 9..16 run on the direct kernels)" << std::endl;
 	}
@@ -128,6 +132,8 @@ int main(int argc, char * argv[])
 			else if (Match(a, 0, "gpus")) { options.gpus = int(Parse<unsigned int>(value("(--gpus)"), "(--gpus)")); optionsSet = true; }
 			else if (Match(a, 0, "no-rccl")) { options.rccl = false; optionsSet = true; }
 			else if (Match(a, 0, "emulate-ranks")) { options.emulateRanks = true; optionsSet = true; }
+			else if (Match(a, 0, "save-filter")) { options.saveFilter = value("(--save-filter)"); optionsSet = true; }
+			else if (Match(a, 0, "load-filter")) { options.loadFilter = value("(--load-filter)"); optionsSet = true; }
 			else if (Match(a, "h", "help")) { Usage(); return 0; }
 			else if (a == "--version") { std::cout << argv[0] << "  version: 1.1.0" << std::endl; return 0; }
 			else if (a.size() > 1 && a[0] == '-') throw ArgError("Couldn't find match for argument", "(" + a + ")");
@@ -148,6 +154,12 @@ int main(int argc, char * argv[])
 		{
 			size_t trials = 10;
 			if (const char * t = std::getenv("TWOPACO_SELFTEST_TRIALS")) trials = size_t(std::atoi(t));
+			// reference constructor.cpp:164 runs the trials off std::random_device; --seed makes them (and a failure) reproducible
+			if (options.pinnedSeed)
+			{
+				return TwoPaCo::RunTestsSeeded(options.seed, trials, 20, 9000, 6, TwoPaCo::Range(3, 11), TwoPaCo::Range(1, 2), TwoPaCo::Range(1, 5), TwoPaCo::Range(4, 5), 0.05, 0.1, tmpDirName) ? 0 : 1;
+			}
+
 			return TwoPaCo::RunTests(trials, 20, 9000, 6, TwoPaCo::Range(3, 11), TwoPaCo::Range(1, 2), TwoPaCo::Range(1, 5), TwoPaCo::Range(4, 5), 0.05, 0.1, tmpDirName) ? 0 : 1;
 		}
 

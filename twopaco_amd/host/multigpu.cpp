@@ -209,6 +209,7 @@ namespace TwoPaCo
 
 			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
 			{
+				Agree();
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
 				for (size_t c0 = 0; c0 < blockBytes; c0 += CHUNK)
 				{
@@ -229,6 +230,7 @@ namespace TwoPaCo
 
 			void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes)
 			{
+				Agree();
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
 				uint64_t most = 0, total = 0;
 				for (int p = 0; p < ranks_; p++) { most = std::max(most, std::max(sendCounts[p], recvCounts[p])); total += sendCounts[p]; }
@@ -256,12 +258,18 @@ namespace TwoPaCo
 
 			void AllGather(int rank, const void * send, void * recv, size_t bytes)
 			{
+				Agree();
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
 				Check(api_.AllGather(send, recv, bytes, ncclUint8, comms_[rank], streams_[rank]), "ncclAllGather");
 				HipCheck(hipStreamSynchronize(streams_[rank]), "all-gather");
 			}
 
 		private:
+			// Every rank agrees that nobody has failed before it enters a collective: a rank that threw between two collectives
+			// (a library call returning an error on one rank only: a full survivor list, hipMalloc) never arrives here, its
+			// Fail() wakes the ones that wait, and they leave with an exception instead of blocking forever in ncclGroupEnd.
+			void Agree() { barrier_.Wait(); }
+
 			void Check(ncclResult_t r, const char * what)
 			{
 				if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + api_.GetErrorString(r));

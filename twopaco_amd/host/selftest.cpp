@@ -1,6 +1,7 @@
 #include "selftest.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -84,15 +85,27 @@ namespace TwoPaCo
 	bool RunTests(size_t tests, size_t filterBits, size_t length, size_t chrNumber, Range vertexSize, Range hashFunctions,
 		Range rounds, Range threads, double changeRate, double indelRate, const std::string & temporaryDir)
 	{
+		std::random_device rd;  // reference test.cpp:169: an unseeded run; the seed drawn here is printed if a trial fails
+		const uint64_t seed = (uint64_t(rd()) << 32) ^ uint64_t(rd());
+		return RunTestsSeeded(seed, tests, filterBits, length, chrNumber, vertexSize, hashFunctions, rounds, threads, changeRate, indelRate, temporaryDir);
+	}
+
+	bool RunTestsSeeded(uint64_t seed, size_t tests, size_t filterBits, size_t length, size_t chrNumber, Range vertexSize, Range hashFunctions,
+		Range rounds, Range threads, double changeRate, double indelRate, const std::string & temporaryDir)
+	{
 		const std::string temporaryFasta = temporaryDir + "/test.fa";
 		const std::string temporaryEdge = temporaryDir + "/out.bin";
 		std::vector<std::string> fileName(1, temporaryFasta);
-		std::random_device rd;
-		std::mt19937_64 rng(rd());
 		std::uniform_real_distribution<> unit(0, 1);
 		const std::string alphabet("ACGT");
 		for (size_t t = 0; t < tests; t++)
 		{
+			const uint64_t trialSeed = seed + t;
+			std::mt19937_64 rng(trialSeed);
+			EnumeratorOptions options;
+			options.pinnedSeed = true;  // the hash tables of this trial's runs (seed.h): part of what a replay must reproduce
+			options.seed = trialSeed;
+			if (const char * d = std::getenv("TWOPACO_DEVICE")) options.device = std::atoi(d);
 			// chr0 random with N at rate 1/500, the others = chr0 with substitutions/indels (reference test.cpp:20-67)
 			std::vector<std::string> chr(chrNumber);
 			for (size_t i = 0; i < length; i++) chr[0].push_back(rng() % 500 == 0 ? 'N' : alphabet[rng() % 4]);
@@ -125,7 +138,7 @@ namespace TwoPaCo
 				for (size_t thr = threads.first; thr < threads.second; ++thr)
 				{
 					std::stringstream null;
-					std::unique_ptr<VertexEnumerator> vid = CreateEnumerator(fileName, k, filterBits, hf, r, thr, UINT32_MAX, temporaryDir, temporaryEdge, null);
+					std::unique_ptr<VertexEnumerator> vid = CreateEnumerator(fileName, k, filterBits, hf, r, thr, UINT32_MAX, temporaryDir, temporaryEdge, null, options);
 					for (size_t i = 0; i < chrNumber; i++) fastMarks[i].assign(chr[i].size(), false);
 					JunctionPositionReader reader(temporaryEdge);
 					reader.RestoreAllVectors(fastMarks);
@@ -141,7 +154,7 @@ namespace TwoPaCo
 					for (const std::string & vertex : junctions) ok = ok && vid->GetId(vertex) != INVALID_VERTEX;
 					if (!ok)
 					{
-						std::cerr << "Test # " << t << " FAILED" << std::endl;
+						std::cerr << "Test # " << t << " FAILED (k = " << k << ", q = " << hf << ", rounds = " << r << "; replay: --test --seed " << trialSeed << ")" << std::endl;
 						return false;
 					}
 				}

@@ -41,6 +41,35 @@ namespace TwoPaCo
 			}
 		};
 
+		// ---- Bloom filter checkpoint (EnumeratorOptions::saveFilter / loadFilter; the reference's commented-out
+		// ReloadBloomFilter, reference vertexenumerator.h:29,113-121 -- there the dump was ConcurrentBitVector::WriteToFile of
+		// the whole vector, concurrentbitvector.cpp:59-67).  One file per round: header, q x 5 hash table, filter words.
+		struct FilterFileHeader
+		{
+			char magic[8];       // "TPCBLOOM"
+			uint32_t version, k, bits, q, round, rounds;
+			uint64_t low, high, words;
+		};
+
+		std::string FilterFileName(const std::string & base, size_t round)
+		{
+			return round == 0 ? base : base + "." + std::to_string(round);
+		}
+
+		void ReadFilterHeader(std::FILE * f, const std::string & name, FilterFileHeader & h, std::vector<uint64_t> & table)
+		{
+			if (std::fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, "TPCBLOOM", 8) != 0 || h.version != 1 || h.q == 0 || h.q > 64)
+			{
+				throw std::runtime_error("Not a Bloom filter checkpoint: " + name);
+			}
+
+			table.resize(size_t(h.q) * 5);
+			if (std::fread(table.data(), sizeof(uint64_t), table.size(), f) != table.size())
+			{
+				throw std::runtime_error("Truncated Bloom filter checkpoint: " + name);
+			}
+		}
+
 		class HipVertexEnumerator : public VertexEnumerator
 		{
 		public:
@@ -141,7 +170,31 @@ namespace TwoPaCo
 				}
 
 				PhaseTimer timer;
-				std::vector<uint64_t> table = MakeSeedTable(hashFunctions, filterSize, options.pinnedSeed, options.seed);
+				std::vector<uint64_t> table;
+				if ((!options.saveFilter.empty() || !options.loadFilter.empty()) && sharded)
+				{
+					throw std::runtime_error("--save-filter / --load-filter need the whole filter on one GPU (not available with --gpus)");
+				}
+
+				if (!options.loadFilter.empty())
+				{
+					// the filter's bits mean something only under the hash tables they were set with: those come from the file
+					std::FILE * f = std::fopen(options.loadFilter.c_str(), "rb");
+					if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + options.loadFilter);
+					FilterFileHeader h;
+					try { ReadFilterHeader(f, options.loadFilter, h, table); } catch (...) { std::fclose(f); throw; }
+					std::fclose(f);
+					if (h.k != vertexLength || h.bits != filterSize || h.q != hashFunctions || h.rounds != rounds)
+					{
+						throw std::runtime_error("The Bloom filter checkpoint was made with other parameters (k = " + std::to_string(h.k) + ", f = " + std::to_string(h.bits) +
+							", q = " + std::to_string(h.q) + ", r = " + std::to_string(h.rounds) + ")");
+					}
+				}
+				else
+				{
+					table = MakeSeedTable(hashFunctions, filterSize, options.pinnedSeed, options.seed);
+				}
+
 				seed_ = VertexRollingHashSeed(hashFunctions, vertexLength, filterSize, table);
 
 				// the device context and the filter allocation (HIP start-up, 2^L/8 bytes of hipMalloc) do not depend
@@ -366,8 +419,17 @@ namespace TwoPaCo
 					}
 					else
 					{
-						if (!nothing) Check(tpc_filter_reset(ctx_), "filter_reset");
-						if (!nothing) Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+						if (!options.loadFilter.empty())
+						{
+							if (!nothing) LoadFilter(FilterFileName(options.loadFilter, round), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table);
+						}
+						else
+						{
+							if (!nothing) Check(tpc_filter_reset(ctx_), "filter_reset");
+							if (!nothing) Check(tpc_pass1_insert(ctx_, low, high, &kmers), "pass1_insert");
+							if (!nothing && !options.saveFilter.empty()) SaveFilter(FilterFileName(options.saveFilter, round), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table);
+						}
+
 						sub.Lap("  round: insert");
 						logStream << time(0) - mark << "\t";
 						mark = time(0);
@@ -535,6 +597,50 @@ namespace TwoPaCo
 			}
 
 		private:
+			void SaveFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table)
+			{
+				FilterFileHeader h;
+				std::memset(&h, 0, sizeof(h));
+				std::memcpy(h.magic, "TPCBLOOM", 8);
+				h.version = 1; h.k = uint32_t(k); h.bits = uint32_t(bits); h.q = uint32_t(q); h.round = uint32_t(round); h.rounds = uint32_t(rounds);
+				h.low = low; h.high = high; h.words = tpc_filter_words(ctx_);
+				std::vector<uint32_t> words(h.words);
+				Check(tpc_filter_download(ctx_, words.data()), "filter_download");
+				std::FILE * f = std::fopen(name.c_str(), "wb");
+				if (!f) throw std::runtime_error("Can't create the Bloom filter checkpoint " + name);
+				const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(table.data(), sizeof(uint64_t), table.size(), f) == table.size() &&
+					std::fwrite(words.data(), sizeof(uint32_t), words.size(), f) == words.size();
+				if (std::fclose(f) != 0 || !ok) throw std::runtime_error("Can't write the Bloom filter checkpoint " + name);
+			}
+
+			void LoadFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table)
+			{
+				std::FILE * f = std::fopen(name.c_str(), "rb");
+				if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + name);
+				try
+				{
+					FilterFileHeader h;
+					std::vector<uint64_t> fileTable;
+					ReadFilterHeader(f, name, h, fileTable);
+					if (h.k != k || h.bits != bits || h.q != q || h.round != round || h.rounds != rounds || h.low != low || h.high != high || fileTable != table ||
+						h.words != tpc_filter_words(ctx_))
+					{
+						throw std::runtime_error("The Bloom filter checkpoint " + name + " does not belong to this round (parameters, hash tables or the round's range differ)");
+					}
+
+					std::vector<uint32_t> words(h.words);
+					if (std::fread(words.data(), sizeof(uint32_t), words.size(), f) != words.size()) throw std::runtime_error("Truncated Bloom filter checkpoint: " + name);
+					Check(tpc_filter_upload(ctx_, words.data()), "filter_upload");
+				}
+				catch (...)
+				{
+					std::fclose(f);
+					throw;
+				}
+
+				std::fclose(f);
+			}
+
 			tpc_ctx * ctx_;
 			size_t vertices_;
 			VertexRollingHashSeed seed_;

@@ -53,6 +53,13 @@ namespace TwoPaCo
 		bool rccl;            // transport between the GPUs: RCCL (default) or device-to-device copies
 		bool emulateRanks;    // testing: all `gpus` ranks on ONE device (copies instead of RCCL, which refuses duplicate devices)
 		bool forceSharded;    // testing: take the sharded path (and its transport) even with gpus == 1
+		// Checkpoint of the most expensive state of a run, the Bloom filter after a round's first-pass insert (the reference
+		// kept this as the commented-out ReloadBloomFilter, reference vertexenumerator.h:29,113-121).  saveFilter: every round
+		// writes its filter to this file (round r > 0: "<file>.<r>") with the parameters and hash tables it was built with.
+		// loadFilter: every round reads its filter from there instead of running the insert; the hash tables come from the
+		// file (pinnedSeed / seed are ignored) and k, filter size, hash functions and the round's range must match.  Single GPU.
+		std::string saveFilter;
+		std::string loadFilter;
 		EnumeratorOptions() : pinnedSeed(false), seed(0), device(0), insertTestFirst(false), gpus(1), rccl(true), emulateRanks(false), forceSharded(false) {}
 	};
 
