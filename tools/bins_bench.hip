@@ -3,7 +3,9 @@
 // entry counts of the M2 workload and verifies that every entry reaches its region exactly once.
 //   hipcc --offload-arch=gfx950 -O3 -Itwopaco_amd/csrc -Iinclude tools/bins_bench.hip -o tools/bins_bench
 #include "tpc_rbins.h"
+#include "tpc_bins3.h"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -88,6 +90,47 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
 }
 
 template <class T> __global__ void k_check(const T *buf, const uint32_t *cnt, uint64_t cap, int NB, unsigned long long *sums);
+// Bins3 (tpc_bins3.h): every wave flushes the ring groups it owns
+template <class T, int N, int THREADS, int DEBUG>
+__global__ void __launch_bounds__(THREADS) k_bins3(int LOG_NB, int steps, int ppr, int filler, T *buf, uint32_t *cnt, uint64_t cap, unsigned long long *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    const uint32_t wg = blockIdx.x;
+    unsigned lost_n = 0;
+    auto lost = [&lost_n](uint32_t, T) { lost_n++; };
+    uint32_t rng = (blockIdx.x * THREADS + threadIdx.x) * 2654435761u + 12345u;
+    unsigned long long sum = 0;
+    Bins3<T, THREADS, DEBUG> bins;
+    bins.carve(smem, LOG_NB);
+    bins.init(buf, [=](uint32_t b) { return make_uint2((uint32_t)((((uint64_t)wg * NB + b) * cap) / Bins3<T, THREADS>::GROUP), (uint32_t)cap); });
+    __syncthreads();
+    for (int s0 = 0; s0 < steps; s0 += ppr) {
+        for (int s = s0; s < min(steps, s0 + ppr); s++) {
+            uint32_t b[N];
+            T val[N];
+            bool ok[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                uint32_t r = lcg(rng);
+                for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);
+                b[i] = ((r ^ (r >> 15)) * 0x2c1b3c6du >> 12) & (uint32_t)(NB - 1);
+                val[i] = make_val<T>(r, (uint32_t)s);
+                ok[i] = true;
+                sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
+            }
+            bins.template push_batch<N>(b, val, ok, lost);
+        }
+        bins.template flush<false>(lost);
+    }
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt + (uint64_t)wg * NB, [](uint32_t b) { return b; });
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
+    if (lost_n) atomicAdd(&sums[2], (unsigned long long)lost_n);
+}
+
+
 // two workgroups per CU: 512 threads, 64 KiB of rings, 64-byte flush granules
 template <class T, int N>
 __global__ void __launch_bounds__(512) k_bins_half(int LOG_NB, int steps, T *buf, uint32_t *cnt, uint64_t cap, unsigned long long *sums)
@@ -96,8 +139,8 @@ __global__ void __launch_bounds__(512) k_bins_half(int LOG_NB, int steps, T *buf
     const int NB = 1 << LOG_NB;
     const uint32_t wg = blockIdx.x;
     auto reg = [buf, cap, wg, NB](uint32_t b) { return PtRegion<T>{buf + ((uint64_t)wg * NB + b) * cap, cap}; };
-    unsigned long long *lostc = sums + 2;
-    auto lost = [lostc](uint32_t, T) { atomicAdd(lostc, 1ull); };
+    unsigned lost_n = 0;
+    auto lost = [&lost_n](uint32_t, T) { lost_n++; };
     uint32_t rng = (blockIdx.x * 512 + threadIdx.x) * 2654435761u + 12345u;
     unsigned long long sum = 0;
     Bins<T, 512, 65536, 64> bins;
@@ -123,6 +166,7 @@ __global__ void __launch_bounds__(512) k_bins_half(int LOG_NB, int steps, T *buf
     bins.store_counts(cnt + (uint64_t)wg * NB, reg, [](uint32_t b) { return b; });
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
+    if (lost_n) atomicAdd(&sums[2], (unsigned long long)lost_n);
 }
 
 template <class T, int N>
@@ -212,8 +256,68 @@ int run(const char *name, int log_nb, int steps, int ppr, int filler)
     return 0;
 }
 
+template <class T, int N, int DEBUG = 0>
+int run3(const char *name, int log_nb, int steps, int ppr, int filler)
+{
+    constexpr int THREADS = 1024;
+    const int nwg = 256, NB = 1 << log_nb;
+    const uint64_t per_bin = (uint64_t)steps * THREADS * N / NB;
+    const uint64_t cap = ((uint64_t)(per_bin * 1.2) + 256 + 31) & ~31ull;
+    T *buf; uint32_t *cnt; unsigned long long *sums;
+    CK(hipMalloc(&buf, (size_t)nwg * NB * cap * sizeof(T)));
+    CK(hipMalloc(&cnt, (size_t)nwg * NB * 4));
+    CK(hipMalloc(&sums, 256));
+    const size_t lds = Bins3<T, THREADS>::lds_bytes(log_nb);
+    CK(hipFuncSetAttribute((const void *)k_bins3<T, N, THREADS, DEBUG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemset(sums, 0, 256));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_bins3<T, N, THREADS, DEBUG>), dim3(nwg), dim3(THREADS), lds, 0, log_nb, steps, ppr, filler, buf, cnt, cap, sums);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    hipLaunchKernelGGL((k_check<T>), dim3(nwg * NB), dim3(256), 0, 0, buf, cnt, cap, NB, sums);
+    unsigned long long h[32];
+    CK(hipMemcpy(h, sums, 256, hipMemcpyDeviceToHost));
+    const double n = (double)nwg * THREADS * steps * N;
+    printf("%-28s NB %3d N %d ppr %d filler %2d: %8.3f ms %8.1f G entries/s %6.2f TB/s written   %s (entries %.0f, found %llu, lost %llu)\n", name, NB, N, ppr, filler, ms,
+           n / ms / 1e6, n * sizeof(T) / ms / 1e9, (h[0] == h[1] + 0 && h[4] + h[2] == (unsigned long long)n) ? (h[2] ? "count OK (some lost)" : "OK") : "MISMATCH", n, h[4], h[2]);
+    CK(hipFree(buf)); CK(hipFree(cnt)); CK(hipFree(sums));
+    return 0;
+}
+
 int main()
 {
+    if (getenv("BINS3_ONLY")) {
+        for (int filler : {0, 40}) {
+            run<uint64_t, 6, false>("Bins  u64 (flush/round)", 8, 1184, 1, filler);
+            run3<uint64_t, 6>("Bins3 u64", 8, 1184, 1, filler);
+            run<uint32_t, 5, false>("Bins  u32 (flush/3 steps)", 8, 1184, 3, filler);
+            run3<uint32_t, 5>("Bins3 u32", 8, 1184, 3, filler);
+        }
+        run3<uint64_t, 6, 1>("Bins3 u64 stores->L2", 8, 1184, 1, 0);
+        run3<uint64_t, 6, 2>("Bins3 u64 no copy", 8, 1184, 1, 0);
+        run3<uint32_t, 5, 1>("Bins3 u32 stores->L2", 8, 1184, 3, 0);
+        run3<uint32_t, 5, 2>("Bins3 u32 no copy", 8, 1184, 3, 0);
+        run3<uint32_t, 5, 2>("Bins3 u32 no copy", 8, 1184, 2, 0);
+        run<uint64_t, 4, false>("Bins  u64 split-like", 8, 1776, 1, 0);
+        run3<uint64_t, 4>("Bins3 u64 split-like", 8, 1776, 1, 0);
+        run3<uint32_t, 5>("Bins3 u32 64 bins", 6, 1184, 4, 0);
+        run3<uint32_t, 5>("Bins3 u32 16 bins", 4, 1184, 4, 0);
+        run3<uint32_t, 5>("Bins3 u32 2 bins (multi)", 1, 1184, 2, 0);
+        run3<uint64_t, 6>("Bins3 u64 4 bins (multi)", 2, 1184, 1, 0);
+        run3<uint64_t, 6>("Bins3 u64 128 bins", 7, 1184, 1, 0);
+        run3<uint64_t, 6>("Bins3 u64 128 bins", 7, 1184, 2, 0);
+        run3<uint32_t, 5>("Bins3 u32 512 bins", 9, 1184, 1, 0);
+        run3<uint32_t, 5>("Bins3 u32 256 bins", 8, 1184, 2, 0);
+        run3<uint32_t, 5>("Bins3 u32 256 bins", 8, 1184, 4, 0);
+        run3<uint64_t, 6>("Bins3 u64 512 bins", 9, 1184, 1, 0);
+        return 0;
+    }
     run_half<uint64_t, 6>("Bins u64 half-size WGs", 8, 1184);
     run_half<uint32_t, 5>("Bins u32 half-size WGs", 8, 1184);
     // M2: query 1.86 G uint64 entries (6 per position), insert 1.55 G uint32 entries (5 per position)

@@ -1,0 +1,208 @@
+// tpc_bins3.h -- LDS write-combining bins whose flush is done by every wave on its own.
+//
+// Why.  The SQ counters of the binning kernels (profiles/r03a_sq.csv) show SIMDs that are 60-77 % busy issuing VALU
+// instructions and waves that spend the rest parked at barriers: a flush of tpc_bins.h:Bins is four workgroup barriers
+// around phases in which all 16 waves do the same thing (push -> scan -> item list -> copy), so hashing arithmetic, LDS
+// atomics and the region stores never overlap, and ~330 of the ~660 VALU instructions per wave and round are bookkeeping.
+//
+// Here the 1024 ring groups (128 KiB of rings / 128-byte groups) are owned one per LANE: lane l of wave w owns ring group
+// w * 64 + l for the whole kernel, hence a fixed bin (ring groups of a bin are consecutive) and a fixed LDS address.  A flush:
+//   B1  barrier: every push of the round is in its ring
+//       each lane reads the tail of its bin (a snapshot: no push is in flight)
+//   B2  barrier: nobody pushes before every snapshot is taken
+//   then, per wave and with no further workgroup synchronisation:
+//       every lane decides from (head, snapshot) whether its ring group is complete; ballot + mbcnt compact the complete
+//       groups into the wave's own item list; 8 lanes per group copy them out (16 bytes per lane); the bin's limit
+//       (head + CAP) moves forward once the ring reads have landed; the wave goes on to hash and push the next round.
+// Between B2 and the next B1 the waves drift apart: one still copies while another hashes and a third pushes, so the
+// three resources overlap.  A push that finds its ring full while the ring's owner has not finished its copy yet waits
+// for it (the owner never waits for anybody between B2 and B1, so this cannot deadlock); a ring that is full although its
+// owner is done is genuinely full (address skew) and the entry goes to lost(), as before.
+// Semantics are those of Bins: only whole GROUP-entry groups leave the workgroup, leftovers stay in the ring, the final
+// flush pads every bin's last group with the all-ones sentinel, full regions hand their entries to lost().
+#pragma once
+#include "tpc_bins.h"
+
+template <class T, int THREADS = 1024, int DEBUG = 0>
+struct Bins3 {
+    static_assert(THREADS == 1024, "one lane per ring group");
+    static constexpr int LOG_T = sizeof(T) == 4 ? 2 : 3;
+    static constexpr int GROUP = PT_LINE / (int)sizeof(T);
+    static constexpr int LOG_GROUP = sizeof(T) == 4 ? 5 : 4;
+    static constexpr int LOG_ENTRIES = 17 - LOG_T;  // entries in PT_BIN_BYTES = 128 KiB of rings
+    static constexpr int NB_MAX = 512;
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr T SENT = (T)~(T)0;
+    static constexpr uint32_t OFF_LIST = PT_BIN_BYTES, OFF_TAIL = OFF_LIST + WAVES * 64 * 8, OFF_LIMIT = OFF_TAIL + NB_MAX * 4,
+                              OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_END = OFF_DONE + 64;
+    static_assert(PT_BIN_BYTES == 131072 && PT_LINE == 128, "layout constants");
+
+    unsigned char *base;   // LDS: rings at 0, then the waves' item lists, tail, limit, done
+    unsigned char *gbase;  // the global buffer all regions live in + this lane's 16-byte column of a line
+    uint32_t LOG_NB, LOG_CAP, CAP, LOG_GPB;  // GPB = ring groups per bin
+    uint32_t my_bin, my_slot;     // the bin and the ring-group slot inside it that this lane owns
+    uint32_t my_unit0, my_cap;    // first 128-byte unit of that bin's region in the global buffer; its capacity in entries
+    uint32_t my_pending;          // bins that span several waves: groups flushed by the last flush, not yet released
+    uint32_t flushes;             // flushes done so far (uniform)
+
+    static size_t lds_bytes(int) { return OFF_END; }
+
+    __device__ __forceinline__ uint32_t *tail() const { return reinterpret_cast<uint32_t *>(base + OFF_TAIL); }
+    __device__ __forceinline__ uint32_t *limit() const { return reinterpret_cast<uint32_t *>(base + OFF_LIMIT); }
+    __device__ __forceinline__ uint32_t *done() const { return reinterpret_cast<uint32_t *>(base + OFF_DONE); }
+    __device__ __forceinline__ bool multi() const { return LOG_GPB > 6u; }  // a bin's ring groups span more than one wave
+
+    __device__ __forceinline__ unsigned char *carve(unsigned char *p, int log_nb)
+    {
+        base = p;
+        LOG_NB = (uint32_t)log_nb;
+        LOG_CAP = (uint32_t)(LOG_ENTRIES - log_nb);
+        CAP = 1u << LOG_CAP;
+        LOG_GPB = LOG_CAP - LOG_GROUP;
+        my_bin = threadIdx.x >> LOG_GPB;
+        my_slot = threadIdx.x & ((1u << LOG_GPB) - 1u);
+        my_unit0 = 0; my_cap = 0; my_pending = 0; flushes = 0;
+        return p + OFF_END;
+    }
+
+    // global: the buffer every region lives in.  region(b) -> uint2{first 128-byte unit of bin b's private region (offset from
+    // `global` in GROUP-entry units), capacity in entries}.
+    template <class Region>
+    __device__ __forceinline__ void init(T *global, Region region)
+    {
+        gbase = reinterpret_cast<unsigned char *>(global) + (threadIdx.x & 7u) * 16u;
+        const uint2 r = region(my_bin);
+        my_unit0 = r.x; my_cap = r.y;
+        for (uint32_t b = threadIdx.x; b < (uint32_t)NB_MAX; b += THREADS) { tail()[b] = 0; limit()[b] = CAP; }
+        if (threadIdx.x < 16) done()[threadIdx.x] = 0;
+    }
+
+    // N entries per lane at once: all ring slots are claimed (N independent LDS atomics in flight) before any entry is
+    // stored.  lost(b, val) receives the entries that found their ring genuinely full.
+    template <int N, class Lost>
+    __device__ __forceinline__ void push_batch(const uint32_t (&b)[N], const T (&val)[N], const bool (&ok)[N], Lost lost)
+    {
+        uint32_t slot[N], lim[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            slot[i] = 0; lim[i] = 0;
+            if (ok[i]) {
+                slot[i] = atomicAdd(&tail()[b[i]], 1u);
+                lim[i] = limit()[b[i]];
+            }
+        }
+        uint32_t pend = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (ok[i]) {
+                if (slot[i] < lim[i]) *reinterpret_cast<T *>(base + (((b[i] << LOG_CAP) | (slot[i] & (CAP - 1u))) << LOG_T)) = val[i];
+                else pend |= 1u << i;
+            }
+        }
+        // A ring that looked full: its owner may still be copying the previous round out (it releases the space right after
+        // its ring reads and never waits for anybody before that, so waiting here cannot deadlock).  Full although the owner
+        // is done with this flush: genuinely full (address skew), the entry goes to lost().  One loop for all N entries.
+        while (__ballot(pend != 0u) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if ((pend >> i) & 1u) {
+                    // (the empty asm keeps this rare path's address arithmetic inside the branch: the compiler otherwise hoists it,
+                    //  ~13 instructions per entry, in front of the loop, where every push pays for it)
+                    uint32_t bi = b[i], si = slot[i];
+                    T vi = val[i];
+                    asm volatile("" : "+v"(bi), "+v"(si), "+v"(vi));
+                    const uint32_t owner = multi() ? 0u : (bi << LOG_GPB) >> 6;  // wave that owns the bin's ring groups
+                    const uint32_t d = __hip_atomic_load(&done()[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t l2 = __hip_atomic_load(&limit()[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (si < l2) {
+                        *reinterpret_cast<T *>(base + (((bi << LOG_CAP) | (si & (CAP - 1u))) << LOG_T)) = vi;
+                        pend &= ~(1u << i);
+                    } else if (multi() || d == flushes) {  // d is read BEFORE the limit: a finished owner's limit is the final one
+                        lost(bi, vi);
+                        pend &= ~(1u << i);
+                    }
+                }
+            }
+            if (pend) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+
+    template <bool FINAL, class Lost>
+    __device__ __forceinline__ void flush(Lost lost)
+    {
+        pt_barrier_lds();  // B1: every push of the round is in its ring
+        if (multi()) {  // bins that span several waves: release what the previous flush copied (every wave has long finished that copy)
+            if (my_slot == 0 && my_pending) limit()[my_bin] += my_pending << LOG_GROUP;
+            my_pending = 0;
+            pt_barrier_lds();
+        }
+        uint32_t t = tail()[my_bin];
+        const uint32_t lim = limit()[my_bin];
+        const uint32_t h = lim - CAP;
+        if (t - h > CAP) {  // the ring overflowed: the slot numbers beyond CAP were handed to lost() by push_batch
+            t = h + CAP;
+            if (my_slot == 0) tail()[my_bin] = t;
+        }
+        pt_barrier_lds();  // B2: no push of the next round before every snapshot is taken
+        const uint32_t n = t - h;
+        const uint32_t nfull = FINAL ? (n + GROUP - 1u) >> LOG_GROUP : n >> LOG_GROUP;
+        const uint32_t gmask = (1u << LOG_GPB) - 1u;
+        const uint32_t rel = (my_slot - (h >> LOG_GROUP)) & gmask;  // my ring group is the rel-th group after the head
+        const bool ready = rel < nfull;
+        const uint32_t pos = h + (rel << LOG_GROUP);  // position of the group in the bin's region
+        const unsigned long long m = __ballot(ready);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, l = lane & 7u;
+        uint2 *list = reinterpret_cast<uint2 *>(base + OFF_LIST) + (wave << 6);
+        if (ready) {
+            const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t valid = FINAL ? min(n - (rel << LOG_GROUP), (uint32_t)GROUP) : (uint32_t)GROUP;
+            const uint32_t over = pos + GROUP > my_cap ? 0x80000000u : 0u;  // the region is full: the group's entries go to lost()
+            list[idx] = make_uint2(lane | (valid << 8) | over, my_unit0 + (pos >> LOG_GROUP));
+        }
+        // copy-out: 8 lanes per 128-byte group, 16 bytes per lane
+        constexpr int EPL = 16 / (int)sizeof(T);
+        const unsigned char *ring = base + (wave << 13) + l * 16u;  // this wave's 64 ring groups
+        for (uint32_t i = lane >> 3; i < (DEBUG == 2 ? 0u : cnt); i += 8u) {
+            uint2 it = list[i];
+            if (DEBUG == 1) it.y &= 1023u;
+            union { uint4 q; T e[EPL]; } u;
+            u.q = *reinterpret_cast<const uint4 *>(ring + ((it.x & 63u) << 7));
+            unsigned char *dst = gbase + (uint64_t)it.y * (uint64_t)PT_LINE;
+            if ((it.x >> 8) == (uint32_t)GROUP) {
+                *reinterpret_cast<uint4 *>(dst) = u.q;
+            } else {  // a padded last group (final flush) or a full region
+                uint32_t x = it.x;
+                asm volatile("" : "+v"(x));  // keep the decoding below out of the common path
+                const uint32_t valid = (x >> 8) & 63u, owner_lane = x & 63u;
+                const bool over = (x >> 31) != 0;
+                const uint32_t b = ((wave << 6) + owner_lane) >> LOG_GPB;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    if (l * EPL + e >= valid) u.e[e] = SENT;
+                    else if (over) lost(b, u.e[e]);
+                }
+                if (!over) *reinterpret_cast<uint4 *>(dst) = u.q;
+            }
+        }
+        // release the ring space: only after this wave's ring reads have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flushes++;
+        if (multi()) my_pending = my_slot == 0 ? nfull : 0u;
+        else if (my_slot == 0) limit()[my_bin] = lim + (nfull << LOG_GROUP);
+        if (FINAL && my_slot == 0 && !multi()) tail()[my_bin] = h + (nfull << LOG_GROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&done()[wave], flushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    // idx(b): position of bin b's count in `out` (call after the final flush, by all threads)
+    template <class Idx>
+    __device__ __forceinline__ void store_counts(uint32_t *out, Idx idx)
+    {
+        pt_barrier_lds();
+        if (my_slot == 0) {
+            const uint32_t head = limit()[my_bin] - CAP + (multi() ? my_pending << LOG_GROUP : 0u);
+            out[idx(my_bin)] = min(head, my_cap);
+        }
+    }
+};

@@ -21,7 +21,7 @@
 // The filter contents are identical to the direct path's (bitwise OR is order independent).
 // HBM traffic per address: 4 B written + 4 B read per level, plus one sequential pass over the
 // filter -- versus one 64-byte read-for-ownership and write-back per address for the atomics.
-#include "tpc_bins.h"
+#include "tpc_bins3.h"
 #include "tpc_insert_step.h"
 #include "tpc_internal.h"
 #include <algorithm>
@@ -47,7 +47,7 @@ struct Overflow {
 
 // ------------------------------------------------------------------------------------------ level 1
 struct HashEmit {
-    Bins<uint32_t, 1024> *bins;  // k_part_hash's bins (PH_THREADS)
+    Bins3<uint32_t, 1024> *bins;  // k_part_hash's bins (PH_THREADS)
     const Overflow *ovf;
     int shift;          // L - B1
     uint32_t remmask;   // 2^(L-B1) - 1
@@ -80,13 +80,12 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
-    Bins<uint32_t, PH_THREADS> bins;
+    Bins3<uint32_t, PH_THREADS> bins;
     uint64_t *s_b2 = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));  // [2][TW]
     uint64_t *s_h = s_b2 + 2 * TW;
     uint64_t *s_hk = s_h + Q * 5;
     uint32_t *s_n2 = reinterpret_cast<uint32_t *>(s_hk + Q * 5);              // [2][TW]
     uint32_t *s_w = s_n2 + 2 * TW;  // 16 words
-    bins.init();
     const int tid = threadIdx.x, half = tid >> 9, lt = tid & (PT_THREADS - 1);
     const uint64_t *s_b = s_b2 + half * TW;
     const uint32_t *s_n = s_n2 + half * TW;
@@ -96,7 +95,7 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     const uint32_t wg = blockIdx.x, nwg = gridDim.x;
     // one rank: a workgroup's regions are contiguous ([w][b1]); sharded: destination-major (pt_r1_send)
     auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
-    auto reg = [buf1, cap1, ridx](uint32_t b) { return PtRegion<uint32_t>{buf1 + ridx(b) * cap1, cap1}; };
+    bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 5), (uint32_t)cap1); });  // 32 entries = one 128-byte unit
     auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
     const int xw = (P.k + 1) / 32 + 2;
     unsigned hashed = 0;
@@ -121,11 +120,11 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
             if (active)
                 for (int s = s0; s < min(s0 + pos_per_round, TPC_RUN); s++)  // any round length: the last round of a run may be short
                     hashed += tpc_insert_step<Q, GATED>(r, P, s_h, s_hk, s_b, s_n, g0 + s, wbase, lo, hi, emit);
-            bins.flush(false, reg, lost);
+            bins.template flush<false>(lost);
         }
     }
-    bins.flush(true, reg, lost);
-    bins.store_counts(cnt1, reg, ridx);
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt1, ridx);
     if (n_kmers) {
         for (int off = 32; off > 0; off >>= 1) hashed += __shfl_down(hashed, off, 64);
         if ((tid & 63) == 0) s_w[tid >> 6] = hashed;
@@ -150,9 +149,8 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 16;  // upper bound; `loads` of them are used
-    Bins<uint32_t, PS_THREADS> bins;
+    Bins3<uint32_t, PS_THREADS> bins;
     unsigned char *s_free = bins.carve(smem, LOG_NB2);
-    bins.init();
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
     const uint32_t b1 = prev_wpb ? (sh.world > 1 ? ((((bl >> log_prev_nb2) * sh.world + sh.rank) << log_prev_nb2) | (bl & ((1u << log_prev_nb2) - 1u))) : bl)
@@ -164,23 +162,26 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     };
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     const int shift1 = L - LOG_NB1;
-    uint32_t *region = buf2 + (uint64_t)blockIdx.x * NB2 * cap2;
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
     auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
-    auto reg = [region, cap2](uint32_t b) { return PtRegion<uint32_t>{region + (uint64_t)b * cap2, cap2}; };
+    {
+        const uint64_t first = (uint64_t)blockIdx.x * NB2 * cap2;  // this workgroup's regions in buf2, entries
+        bins.init(buf2, [first, cap2](uint32_t b) { return make_uint2((uint32_t)((first + (uint64_t)b * cap2) >> 5), (uint32_t)cap2); });
+    }
     __syncthreads();
     // rounds of `loads` x PS_THREADS entries over the regions (w, b1), w = j, j + wpb, ..., taken from the round schedule;
     // the next round's loads are issued before the current round is binned and flushed.  The loads are unpredicated (lanes
     // past the end read entry 0 and are masked when the round is consumed) and the two buffers alternate by name.
     const uint32_t nreg = j < nvw ? (nvw - j + wpb - 1) / wpb : 0;
     const uint32_t step = (uint32_t)loads * PS_THREADS;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_free);  // [nreg_cap]
+    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_free);  // [32] scratch of the schedule's block scan
+    uint32_t *s_cnt = s_scan + 32;                            // [nreg_cap]
     uint32_t *s_sched = s_cnt + nreg_cap;                    // [sched_cap]
     struct Round { uint32_t t, base, n; };  // region (j + t * wpb), first entry of the round, entries in the region; all scalar
     uint32_t va[LOADS], vb[LOADS];
     for (uint32_t skip = 0;; skip += sched_cap) {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<PS_THREADS>(
-            nreg, step, skip, sched_cap, s_cnt, s_sched, bins.scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
         const uint32_t n_seg = min(total - min(total, skip), sched_cap);
         auto round_at = [&](uint32_t r) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
@@ -202,12 +203,16 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
             auto round = [&](uint32_t (&cur)[LOADS], uint32_t (&pre)[LOADS]) {
                 const Round x1 = round_at(r + 1);
                 load(pre, x1);
-                uint32_t bb[LOADS], val[LOADS];
-                bool ok[LOADS];
+                // two batches of 8: the claims of a batch (and what a full ring's retry loop keeps live) fit the register file
 #pragma unroll
-                for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != PT_SENT; bb[i] = cur[i] >> slice_bits; val[i] = cur[i] & slice_mask; }
-                bins.template push_batch<LOADS>(bb, val, ok, lost);
-                bins.flush(false, reg, lost);
+                for (int h = 0; h < LOADS; h += LOADS / 2) {
+                    uint32_t bb[LOADS / 2], val[LOADS / 2];
+                    bool ok[LOADS / 2];
+#pragma unroll
+                    for (int i = 0; i < LOADS / 2; i++) { ok[i] = valid(x0, h + i) && cur[h + i] != PT_SENT; bb[i] = cur[h + i] >> slice_bits; val[i] = cur[h + i] & slice_mask; }
+                    bins.template push_batch<LOADS / 2>(bb, val, ok, lost);
+                }
+                bins.template flush<false>(lost);
                 x0 = x1; r++;
             };
             while (true) {
@@ -220,8 +225,8 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         if (total <= skip + sched_cap) break;
         pt_barrier_lds();  // every wave is done with this segment of the schedule
     }
-    bins.flush(true, reg, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, [](uint32_t b) { return b; });
 }
 
 // ------------------------------------------------------------------------------------------ level 3
@@ -275,7 +280,7 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds = Bins<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 5 * 16 + 64;
+    const size_t lds = Bins3<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 5 * 16 + 64;
 #define TPC_HASH_GO(G, S)                                                                                                                   \
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_part_hash<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
@@ -299,7 +304,7 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds_base = Bins<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3));
+    const size_t lds_base = Bins3<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + 128;
     const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
     const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
     uint32_t nreg_cap, sched_cap;

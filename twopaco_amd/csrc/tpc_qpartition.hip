@@ -22,6 +22,8 @@
 // count 1 each, so "inCount > 1 || outCount > 1" (VE.h:656) holds exactly when one more edge passes
 // all q probes.  The mask is bit-identical to k_query's (tests/test_gpu_parity.py).
 #include "tpc_rbins.h"
+#include "tpc_bins3.h"
+#include "tpc_lean.h"
 #include "tpc_internal.h"
 #include <algorithm>
 #include <type_traits>
@@ -72,12 +74,11 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;  // a tile is still 512 packed words
-    typename std::conditional<RB, RBins<uint64_t, QH_THREADS>, Bins<uint64_t, QH_THREADS>>::type bins;
+    typename std::conditional<RB, RBins<uint64_t, QH_THREADS>, Bins3<uint64_t, QH_THREADS>>::type bins;
     uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));
     uint64_t *s_h = s_b + TW;
     uint64_t *s_hk = s_h + 5;
     uint32_t *s_n = reinterpret_cast<uint32_t *>(s_hk + 5);
-    bins.init();
     const int tid = threadIdx.x;
     if (tid < 5) { s_h[tid] = tab[tid]; s_hk[tid] = tab[TPC_TAB_HK + tid]; }  // function 0, letters A C G T N
     const int shift = P.L - LOG_NB;
@@ -86,6 +87,8 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
     auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
     auto reg = [buf1, cap1, ridx](uint32_t b) { return PtRegion<uint64_t>{buf1 + ridx(b) * cap1, cap1}; };
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
+    if constexpr (RB) bins.init();
+    else bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 4), (uint32_t)cap1); });  // 16 entries = one 128-byte unit
     const int xw = (P.k + 1) / 32 + 2;
     uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
     // function 0's table entries of the four letters, as scalars (uniform loads): the eight candidate edges of a
@@ -202,15 +205,172 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
                     c_first = c_first_nx;
                 }
             }
-            bins.flush(false, reg, lost);
+            bins.template flush<false>(lost);
         }
         rmask16[(wfirst * 2) + tid] = (uint16_t)word;  // N-neighbour marks (16 positions per thread); k_q_verify ORs the rest
     }
-    bins.flush(true, reg, lost);
-    bins.store_counts(cnt1, reg, ridx);
-#ifdef TPC_PROFILE_PHASES
-    if constexpr (!RB) bins.dump(ovf.cursor + 16);
-#endif
+    if constexpr (RB) { bins.flush(true, reg, lost); bins.store_counts(cnt1, reg, ridx); }
+    else { bins.template flush<true>(lost); bins.store_counts(cnt1, ridx); }
+}
+
+// ------------------------------------------------------------------------------------------ A, instruction-lean
+// The same level-1 pass as k_q_hash<.., RB = false>, rebuilt around the VALU instruction count (tpc_lean.h): the 16 first and
+// 16 next characters of a thread's run sit in two registers, rotations and the address split work on 32-bit halves, the run
+// is seeded from a table of pre-rotated letter hashes (one 16-byte LDS read per character: H(w) = XOR_t rotl(h[w_t], k-1-t),
+// H'(w) = XOR_t rotl(h[rc w_t], t); cyclichash.h:106-109 folded), the roll reads {h[c], hk[rc c]} / {hk[c], h[rc c]} as
+// 16-byte pairs, and the bins are Bins3.  Used whenever the geometry allows (launch_qhash); entries, masks and overflow
+// entries are those of k_q_hash (order inside a region differs: nothing downstream depends on it).
+constexpr int QT_MAXK = 64;  // seed table: k x 5 letters x 16 bytes
+
+__device__ __forceinline__ uint64_t q_rotl_n(uint64_t x, int L, int r)
+{   // fastleftshiftn (cyclichash.h:42-44 applied r times)
+    if (r == 0) return x;
+    return ((x & ((1ull << (L - r)) - 1ull)) << r) | (x >> (L - r));
+}
+
+// every mask bit doubled: bit i -> bits 2i, 2i+1
+__device__ __forceinline__ uint64_t q_spread2(uint32_t m)
+{
+    uint64_t x = m;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
+}
+
+template <bool GATED, bool SHARDED>
+__global__ void __launch_bounds__(QH_THREADS)
+k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+          const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round,
+          uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
+          uint64_t gbase, uint32_t *__restrict__ rmask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;  // a tile is 512 packed words
+    Bins3<uint64_t, QH_THREADS> bins;
+    uint64_t *s_b = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));  // [TW] bases, N positions cleared to code 0
+    uint64_t *s_roll = s_b + TW;                   // [2][5][2]: as next character {h[c], hk[rc c]}, as first character {hk[c], h[rc c]}
+    uint64_t *s_seed = s_roll + 20;                // [k][5][2] (k <= QT_MAXK): {rotl(h[c], k-1-t), rotl(h[rc c], t)}
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_seed + QT_MAXK * 10);  // [TW]
+    const uint32_t tid = threadIdx.x;
+    const int k = P.k, L = P.L;
+    if (tid < 5) {  // function 0, letters A C G T N
+        const uint32_t c = tid, rc = c == 4 ? 4u : 3u - c;
+        s_roll[c * 2] = tab[c]; s_roll[c * 2 + 1] = tab[TPC_TAB_HK + rc];
+        s_roll[10 + c * 2] = tab[TPC_TAB_HK + c]; s_roll[10 + c * 2 + 1] = tab[rc];
+    }
+    if (k <= QT_MAXK)
+        for (uint32_t i = tid; i < 5u * (uint32_t)k; i += QH_THREADS) {
+            const uint32_t t = i / 5u, c = i % 5u, rc = c == 4 ? 4u : 3u - c;
+            s_seed[2 * i] = q_rotl_n(tab[c], L, (k - 1 - (int)t) % L);
+            s_seed[2 * i + 1] = q_rotl_n(tab[rc], L, (int)t % L);
+        }
+    const int shift = L - LOG_NB;
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
+    auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
+    bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 4), (uint32_t)cap1); });  // 16 entries = one 128-byte unit
+    LeanRot R;
+    R.set(L);
+    LeanSplit S;
+    S.set(perm, LOG_NB);
+    const int xw = (k + 1) / 32 + 2;
+    uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
+    // function 0's table entries of the four letters as scalars: the eight candidate edges use them with constant letters
+    uint64_t h0[4], hk0[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { h0[c] = tab[c]; hk0[c] = tab[TPC_TAB_HK + c]; }
+    const uint32_t ppr_mask = (uint32_t)pos_per_round - 1u;  // a power of two <= 16
+    const uint32_t p0 = 32u + tid * (uint32_t)QH_RUN;        // my first position, relative to the first staged word (the one before the tile)
+    for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        const uint64_t wfirst = tile * PT_THREADS;
+        for (int i = (int)tid; i < PT_THREADS + 1 + xw; i += QH_THREADS) {
+            const int64_t w = (int64_t)wfirst - 1 + i;
+            uint64_t b = w >= 0 ? bases[w] : 0ull;
+            const uint32_t m = w >= 0 ? nmask[w] : 0xFFFFFFFFu;
+            if (m) b &= ~q_spread2(m);  // an N has code 0 in the staged word: code = c | isN << 2 below
+            s_b[i] = b;
+            s_n[i] = m;
+        }
+        __syncthreads();
+        // The text is padded with N to whole tiles (tpc_seq_upload), so runs past its end find no vertex and need no guard.
+        const uint32_t cw = lean_chars16(s_b, p0), nw = lean_nbits32(s_n, p0);                            // first characters of my 16 windows
+        const uint32_t cx = lean_chars16(s_b, p0 + (uint32_t)k), nx = lean_nbits32(s_n, p0 + (uint32_t)k);  // the characters after them
+        uint32_t cp = lean_char(s_b, s_n, p0 - 1u);  // character before the window
+        int ncnt = 0;                                // N characters inside the window
+        for (int t = 0; t < k; t += 32) {
+            uint32_t bits = lean_nbits32(s_n, p0 + (uint32_t)t);
+            if (k - t < 32) bits &= (1u << (k - t)) - 1u;
+            ncnt += __popc(bits);
+        }
+        uint64_t pos = 0, neg = 0;  // VertexRollingHash ctor (vertexrollinghash.h:79-102), function 0
+        if (k <= QT_MAXK) {
+            for (int t0 = 0; t0 < k; t0 += 16) {
+                uint32_t ch = lean_chars16(s_b, p0 + (uint32_t)t0), nb = lean_nbits32(s_n, p0 + (uint32_t)t0);
+                const int m = min(16, k - t0);
+                const uint4 *row = reinterpret_cast<const uint4 *>(s_seed) + t0 * 5;
+                for (int j = 0; j < m; j++) {
+                    const uint32_t c = (ch & 3u) | ((nb & 1u) << 2);
+                    ch >>= 2; nb >>= 1;
+                    const uint4 e = row[j * 5 + c];
+                    pos ^= ((uint64_t)e.y << 32) | e.x;
+                    neg ^= ((uint64_t)e.w << 32) | e.z;
+                }
+            }
+        } else {
+            for (int t = 0; t < k; t++) {
+                const uint32_t c = lean_char(s_b, s_n, p0 + (uint32_t)t), cr = lean_char(s_b, s_n, p0 + (uint32_t)(k - 1 - t));
+                pos = R.rotl1(pos) ^ s_roll[c * 2];
+                neg = R.rotl1(neg) ^ s_roll[10 + cr * 2 + 1];
+            }
+        }
+        const uint32_t sid0 = ((uint32_t)(wfirst * TPC_RUN + (uint64_t)tid * QH_RUN - gbase) | (SHARDED ? sh.rank << (30u - sh.log_world()) : 0u)) << 2;
+        uint32_t word = 0;
+#pragma unroll 1
+        for (int s = 0; s < QH_RUN; s++) {  // not unrolled: one copy of the push and flush code (the loop body is ~600 instructions)
+            const uint32_t cf = ((cw >> (2 * s)) & 3u) | (((nw >> s) & 1u) << 2);  // first character of the window
+            const uint32_t cn = ((cx >> (2 * s)) & 3u) | (((nx >> s) & 1u) << 2);  // the character after it
+            const uint64_t r1p = R.rotl1(pos), r1n = R.rotl1(neg);
+            bool check = ncnt == 0;
+            if (GATED) check = check && within(tpc_min(pos, neg), lo, hi);  // VE.h:638
+            const bool nadj = (cp | cn) >= 4u;
+            if (check && nadj) word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
+            if (check && !nadj) {
+                const uint32_t hi_s = sid0 + (uint32_t)(s << 2);  // (survivor id >> 1) without the edge: position << 2
+                uint32_t eb[8];
+                uint64_t ev[8];
+                bool eok[8];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    uint32_t rem;
+                    // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200): survivor id edge = c
+                    S.split(tpc_min(hk0[c] ^ pos, r1n ^ h0[3 - c]), eb[c], rem);
+                    ev[c] = ((uint64_t)(hi_s | (uint32_t)(c >> 1)) << 32) | (rem | ((uint32_t)(c & 1) << 31));
+                    eok[c] = (uint32_t)c != cp;
+                    // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184): edge = 4 + c
+                    S.split(tpc_min(r1p ^ h0[c], neg ^ hk0[3 - c]), eb[4 + c], rem);
+                    ev[4 + c] = ((uint64_t)(hi_s | (uint32_t)((4 + c) >> 1)) << 32) | (rem | ((uint32_t)(c & 1) << 31));
+                    eok[4 + c] = (uint32_t)c != cn;
+                }
+                bins.template push_batch<8>(eb, ev, eok, lost);
+            }
+            if (s + 1 < QH_RUN) {  // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113), function 0
+                const uint4 en = reinterpret_cast<const uint4 *>(s_roll)[cn], ef = reinterpret_cast<const uint4 *>(s_roll)[5 + cf];
+                pos = r1p ^ (((uint64_t)en.y << 32) | en.x) ^ (((uint64_t)ef.y << 32) | ef.x);
+                neg = R.rotr1(neg ^ (((uint64_t)en.w << 32) | en.z) ^ (((uint64_t)ef.w << 32) | ef.z));
+                ncnt += (int)(cn >> 2) - (int)(cf >> 2);
+                cp = cf;
+            }
+            if ((((uint32_t)s + 1u) & ppr_mask) == 0u) bins.template flush<false>(lost);
+        }
+        rmask16[(wfirst * 2) + tid] = (uint16_t)word;  // N-neighbour marks (16 positions per thread); k_q_verify ORs the rest
+    }
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt1, ridx);
 }
 
 // ------------------------------------------------------------------------------------------ B
@@ -225,9 +385,13 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 4;
     constexpr uint64_t SENT = ~0ull;
-    typename std::conditional<RB, RBins<uint64_t, QS_THREADS>, Bins<uint64_t, QS_THREADS>>::type bins;  // RB: see k_q_hash
+    typename std::conditional<RB, RBins<uint64_t, QS_THREADS>, Bins3<uint64_t, QS_THREADS>>::type bins;  // RB: see k_q_hash
     uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
-    bins.init();
+    if constexpr (RB) bins.init();
+    else {
+        const uint64_t *o2 = off2 + (uint64_t)blockIdx.x * NB2;
+        bins.init(buf2, [o2](uint32_t b) { const uint64_t o = o2[b]; return make_uint2((uint32_t)(o >> 4), (uint32_t)(o2[b + 1] - o)); });
+    }
     for (uint32_t i = threadIdx.x; i <= NB2; i += QS_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
@@ -286,8 +450,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 #pragma unroll
                 for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != SENT; bb[i] = (uint32_t)((cur[i] & rem_mask) >> slice_bits); }
                 if constexpr (RB) bins.template push_batch<LOADS>(bb, cur, ok, reg, lost);
-                else bins.template push_batch<LOADS>(bb, cur, ok, lost);
-                bins.flush(false, reg, lost);
+                else { bins.template push_batch<LOADS>(bb, cur, ok, lost); bins.template flush<false>(lost); }
                 x0 = x1; x1 = x2; r++;
             };
             while (true) {
@@ -302,11 +465,8 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         if (total <= skip + sched_cap) break;
         pt_barrier_lds();  // every wave is done with this segment of the schedule
     }
-    bins.flush(true, reg, lost);
-    bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; });
-#ifdef TPC_PROFILE_PHASES
-    if constexpr (!RB) bins.dump(ovf.cursor + 8);
-#endif
+    if constexpr (RB) { bins.flush(true, reg, lost); bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; }); }
+    else { bins.template flush<true>(lost); bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, [](uint32_t b) { return b; }); }
 }
 
 // ------------------------------------------------------------------------------------------ C
@@ -770,7 +930,23 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const bool rb = q_use_rbins(pl.b1);
-    const size_t lds = (rb ? RBins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) : Bins<uint64_t, QH_THREADS>::lds_bytes(pl.b1)) +
+    // the instruction-lean kernel: flush-per-round bins, whole rounds, a 24-bit slice index
+    const bool lean = !rb && pl.sub_rounds == 1 && perm.F <= 24 && !getenv("TPC_NO_LEAN");
+    if (lean) {
+        const size_t lds = Bins3<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + 160 + (size_t)QT_MAXK * 80 + 64;
+#define TPC_QHASH2_GO(G, S)                                                                                                                 \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        hipLaunchKernelGGL((k_q_hash2<G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
+                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
+    } while (0)
+        if (pl.world > 1) { if (gated) TPC_QHASH2_GO(true, true); else TPC_QHASH2_GO(false, true); }
+        else { if (gated) TPC_QHASH2_GO(true, false); else TPC_QHASH2_GO(false, false); }
+#undef TPC_QHASH2_GO
+        return;
+    }
+    const size_t lds = (rb ? RBins<uint64_t, QH_THREADS>::lds_bytes(pl.b1) : Bins3<uint64_t, QH_THREADS>::lds_bytes(pl.b1)) +
                        (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + (size_t)5 * 16 + 64;
 #define TPC_QHASH_GO(G, S, R)                                                                                                               \
     do {                                                                                                                                    \
@@ -795,7 +971,7 @@ void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, i
                    uint32_t prev_wpb, int log_prev_nb2, const uint64_t *off1, unsigned grid)
 {
     const bool rb = q_use_rbins(log_nb2);
-    const size_t lds_base = (rb ? RBins<uint64_t, QS_THREADS>::lds_bytes(log_nb2) : Bins<uint64_t, QS_THREADS>::lds_bytes(log_nb2)) + ((size_t)8 << log_nb2) + 64 + 128;
+    const size_t lds_base = (rb ? RBins<uint64_t, QS_THREADS>::lds_bytes(log_nb2) : Bins3<uint64_t, QS_THREADS>::lds_bytes(log_nb2)) + ((size_t)8 << log_nb2) + 64 + 128;
     if (rb) loads = 4;  // the barrier-free rings have no round to outgrow
     uint32_t nreg_cap, sched_cap;
     size_t lds;
