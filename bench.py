@@ -39,14 +39,14 @@ GOLDEN_SEED = 20240229  # tests/golden/make_golden.py: the seed the reference go
 PMC_PROFILE = "r02_pmc_traffic.json"
 
 
-def launch_ranks(args):
+def launch_ranks(args, script=None):
     """bench.py --gpus N, N > 1, no launcher: become the parent of torch.distributed.run (child process)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), script or os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd).returncode
 
 
@@ -209,8 +209,8 @@ def main():
     ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
                     help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
                          "power-of-two N), or vertex-hash ranges (the reference's rounds side by side, no data-path exchange).  auto: "
-                         "address from 8 GPUs up, where every GPU spreads its all-to-all over 7 xGMI links; ranges below, where one or "
-                         "three links would carry 16 B per k-mer (DESIGN.md section 5)")
+                         "address at every power-of-two N (the scaling curve is one decomposition); below 8 GPUs the range "
+                         "decomposition is timed as well and reported under the key 'ranges' (DESIGN.md section 5)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -218,12 +218,18 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.decomposition == "auto":
-        args.decomposition = "address" if (world >= 8 and world & (world - 1) == 0) else "ranges"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("TPC_FORCE_DIST"):  # TPC_FORCE_DIST: exercise the distributed path with one rank
         from twopaco_amd import dist as tdist
-        return tdist.bench_main(args, rank, world, local_rank)
+        base = None
+        if not args.no_cpu_baseline and args.cpu_baseline != "none":
+            def base(recs, p):
+                tmp = tempfile.mkdtemp(prefix="tpc_bench_")
+                try:
+                    return cpu_baseline(recs, p, tmp, args.cpu_baseline)
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
+        return tdist.bench_main(args, rank, world, local_rank, golden=golden_case(args.workload, args.scale), cpu_baseline=base)
 
     import torch
     from twopaco_amd import capi, synth

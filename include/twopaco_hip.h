@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct tpc_ctx tpc_ctx;
 
-#define TPC_MAX_Q 16                   /* hash functions supported by the kernels (9..16: direct kernels only) */
+#define TPC_MAX_Q 16                   /* hash functions supported by the kernels (direct and partitioned)    */
 #define TPC_MAX_K 600                  /* CAPACITY < 20 words, VE.h:4                    */
 #define TPC_INVALID_VERTEX INT64_MAX   /* graphconstructor/common.cpp:5                  */
 

@@ -113,19 +113,19 @@ def test_address_sharded_collectives_send_recv_form(world, tmp_path):
 
 
 def test_bench_gpus_flag_launches_ranks(tmp_path):
-    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks by itself (torch.distributed.run as
-    a child process) and rank 0 prints one JSON line with n_gpus = ranks = 2.  The ranks run the oracle backend over
-    gloo (TPC_BENCH_BACKEND, test only): what is under test is the launch path the driver's scaling run depends on."""
+    """`bench.py --gpus 2` with no launcher in the environment starts two ranks by itself (bench.launch_ranks:
+    torch.distributed.run as a child process) and rank 0 prints one JSON line with n_gpus = ranks = 2, checked against the
+    golden counters.  tests/bench_injected.py composes the product's launcher and dist.bench_main with the oracle as the rank
+    backend over gloo: what is under test is the launch / timing / reporting path the driver's scaling run depends on."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TPC_DIST_BACKEND="gloo", TPC_BENCH_BACKEND="dist_worker:bench_backend",
-               PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root)
+    env = dict(os.environ, TPC_DIST_BACKEND="gloo", PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
-                       capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, os.path.join(root, "tests", "bench_injected.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -133,4 +133,23 @@ def test_bench_gpus_flag_launches_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2 and out["backend"] == "injected"
     assert out["config"]["decomposition"] == "ranges"
     case = CASES["rand6_k9_fp"]
-    assert out["result"]["junctions"] == case["distinct"] and out["result"]["junction_occurrences"] > 0
+    assert out["result"]["junctions"] == case["distinct"] and out["result"]["junction_occurrences"] == case["true_marks"]
+    assert out["result_equals_reference_golden"] is True
+    for key in ("metric", "value", "unit", "ms_per_step", "scaling", "kernel_ms_rank0", "phase_ms_rank0_per_step", "all_to_all_GBs_rank0",
+                "exchange_bytes_rank0_per_step", "roofline", "result"):
+        assert key in out, key
+    # a result that differs from the reference's counters: no line, non-zero exit
+    r = subprocess.run(cmd + ["--golden-junctions", str(case["distinct"] + 1)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "differs from the reference golden" in r.stderr
+
+
+def test_product_has_no_injected_backend_seam():
+    """The seam that lets a test backend (the oracle) stand behind a bench line lives under tests/ only: the product's
+    distributed driver never names the oracle, and no environment variable swaps the rank backend."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "twopaco_amd", "dist.py")) as f:
+        text = f.read()
+    assert "TPC_BENCH_BACKEND" not in text and "oracle" not in text.lower()
+    with open(os.path.join(root, "bench.py")) as f:
+        assert "TPC_BENCH_BACKEND" not in f.read()

@@ -124,9 +124,10 @@ def test_enumerator_matches_reference_golden(capi, tmp_path, case):
     e.close()
 
 
-@pytest.mark.parametrize("name", ["rand6_k9_fp_r4", "c2_k51_r2", "rand6_k9_a3", "edge_k5"])
+@pytest.mark.parametrize("name", ["rand6_k9_fp_r4", "c2_k51_r2", "rand6_k9_a3", "edge_k5", "rand6_k9_q12"])
 def test_all_passes_forced_partitioned(capi, tmp_path, name):
-    """Whole run with both first-pass kernels forced onto the partitioned paths == oracle records."""
+    """Whole run with both first-pass kernels forced onto the partitioned paths == oracle records (q = 12: the
+    reference takes any -q, constructor.cpp:83-90; 9..16 functions run on the partitioned kernels too)."""
     case = [c for c in CASES if c["name"] == name][0]
     abundance = case["abundance"] if case["abundance"] is not None else MAXU
     o = _oracle_for(case, tmp_path)
@@ -143,6 +144,7 @@ def test_all_passes_forced_partitioned(capi, tmp_path, name):
         ctx.filter_reset()
         ctx.pass1_insert(st["low"], st["high"])
         assert ctx.pass1_query(st["low"], st["high"]) == st["marks"]
+        assert ctx.stat("insert_path") % 10 in (2, 3) and ctx.stat("query_path") % 10 in (2, 3)  # really the partitioned kernels
         assert ctx.pass2_filter(abundance) == {"true": st["true"], "false": st["false"], "table": st["table"]}
     J = ctx.junctions_finalize()
     assert (ctx.junction_keys() == o.keys).all()
@@ -175,7 +177,7 @@ def test_test_first_variant_same_filter(capi, tmp_path):
 
 @pytest.mark.parametrize("name,slice_bits", [("rand6_k9_fp", 8), ("rand6_k9_fp", 10), ("rand6_k9_q8", 9), ("rand6_k9_q1", 12),
                                              ("rand6_k25_q3", 12), ("rand6_k9_L33", 20), ("c2_k51_r2", 16), ("edge_k5", 7),
-                                             ("rand6_k9_fp_r4", 9)])
+                                             ("rand6_k9_fp_r4", 9), ("rand6_k9_q12", 8)])
 def test_partitioned_insert_matches_oracle(capi, tmp_path, name, slice_bits):
     """The LDS write-combining insert (tpc_partition.hip) builds the same filter bitmap as the
     oracle's FilterFillerWorker, for the whole range and for a gated round range."""

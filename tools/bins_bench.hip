@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 uint32_t r = lcg(rng);
-                for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);  // stands in for the hashing
+                for (int f = 0; f < (filler >= 1000 ? 0 : filler); f++) r = r * 1664525u + (r >> 13);  // stands in for the hashing
                 b[i] = (r >> 8) & (uint32_t)(NB - 1);
                 val[i] = make_val<T>(r, (uint32_t)s);
                 ok[i] = true;
@@ -70,8 +70,9 @@ __global__ void __launch_bounds__(THREADS) k_bins(int LOG_NB, int steps, int ppr
 #pragma unroll
                 for (int i = 0; i < N; i++) {
                     uint32_t r = lcg(rng);
-                    for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);
+                    for (int f = 0; f < (filler >= 1000 ? 0 : filler); f++) r = r * 1664525u + (r >> 13);
                     b[i] = (r >> 8) & (uint32_t)(NB - 1);
+                    if (filler >= 1000 && ((s >> 4) & 1)) b[i] = (uint32_t)((i * 5 + (s >> 5)) % 3) & (uint32_t)(NB - 1);
                     val[i] = make_val<T>(r, (uint32_t)s);
                     ok[i] = true;
                     sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
@@ -113,8 +114,9 @@ __global__ void __launch_bounds__(THREADS) k_bins3(int LOG_NB, int steps, int pp
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 uint32_t r = lcg(rng);
-                for (int f = 0; f < filler; f++) r = r * 1664525u + (r >> 13);
+                for (int f = 0; f < (filler >= 1000 ? 0 : filler); f++) r = r * 1664525u + (r >> 13);
                 b[i] = ((r ^ (r >> 15)) * 0x2c1b3c6du >> 12) & (uint32_t)(NB - 1);
+                if (filler >= 1000 && ((s >> 4) & 1)) b[i] = (uint32_t)((i * 5 + (s >> 5)) % 3) & (uint32_t)(NB - 1);  // poly-A-like: every lane hits the same few bins for 16 steps
                 val[i] = make_val<T>(r, (uint32_t)s);
                 ok[i] = true;
                 sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 40);
@@ -299,6 +301,16 @@ int main()
             run<uint32_t, 5, false>("Bins  u32 (flush/3 steps)", 8, 1184, 3, filler);
             run3<uint32_t, 5>("Bins3 u32", 8, 1184, 3, filler);
         }
+        run<uint64_t, 6, false>("Bins  u64 8 bins skew", 3, 1184, 1, 1000);
+        run3<uint64_t, 6>("Bins3 u64 8 bins skew", 3, 1184, 1, 1000);
+        run<uint32_t, 2, false>("Bins  u32 8 bins skew", 3, 1184, 9, 1000);
+        run3<uint32_t, 2>("Bins3 u32 8 bins skew", 3, 1184, 9, 1000);
+        run<uint64_t, 6, false>("Bins  u64 64 bins skew", 6, 1184, 1, 1000);
+        run3<uint64_t, 6>("Bins3 u64 64 bins skew", 6, 1184, 1, 1000);
+        run<uint32_t, 2, false>("Bins  u32 8 bins ppr9", 3, 1184, 9, 0);
+        run3<uint32_t, 2>("Bins3 u32 8 bins ppr9 (waits)", 3, 1184, 9, 0);
+        run3<uint32_t, 2>("Bins3 u32 8 bins ppr10 (waits)", 3, 1184, 10, 0);
+        run3<uint32_t, 4>("Bins3 u32 16 bins ppr9 (waits)", 4, 1184, 9, 0);
         run3<uint64_t, 6, 1>("Bins3 u64 stores->L2", 8, 1184, 1, 0);
         run3<uint64_t, 6, 2>("Bins3 u64 no copy", 8, 1184, 1, 0);
         run3<uint32_t, 5, 1>("Bins3 u32 stores->L2", 8, 1184, 3, 0);
@@ -310,6 +322,8 @@ int main()
         run3<uint32_t, 5>("Bins3 u32 16 bins", 4, 1184, 4, 0);
         run3<uint32_t, 5>("Bins3 u32 2 bins (multi)", 1, 1184, 2, 0);
         run3<uint64_t, 6>("Bins3 u64 4 bins (multi)", 2, 1184, 1, 0);
+        run3<uint64_t, 6>("Bins3 u64 8 bins (multi)", 3, 1184, 1, 0);
+        run3<uint32_t, 5>("Bins3 u32 8 bins (multi)", 3, 1184, 3, 0);
         run3<uint64_t, 6>("Bins3 u64 128 bins", 7, 1184, 1, 0);
         run3<uint64_t, 6>("Bins3 u64 128 bins", 7, 1184, 2, 0);
         run3<uint32_t, 5>("Bins3 u32 512 bins", 9, 1184, 1, 0);

@@ -33,23 +33,25 @@ struct Bins3 {
     static constexpr int NB_MAX = 512;
     static constexpr int WAVES = THREADS / 64;
     static constexpr T SENT = (T)~(T)0;
-    static constexpr uint32_t OFF_LIST = PT_BIN_BYTES, OFF_TAIL = OFF_LIST + WAVES * 64 * 8, OFF_LIMIT = OFF_TAIL + NB_MAX * 4,
-                              OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_END = OFF_DONE + 64;
+    static constexpr uint32_t OFF_TAIL = PT_BIN_BYTES, OFF_LIMIT = OFF_TAIL + NB_MAX * 4, OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_CNTDOWN = OFF_DONE + 64, OFF_END = OFF_CNTDOWN + 64;
     static_assert(PT_BIN_BYTES == 131072 && PT_LINE == 128, "layout constants");
 
-    unsigned char *base;   // LDS: rings at 0, then the waves' item lists, tail, limit, done
+    unsigned char *base;   // LDS: rings at 0, then tail, limit, done, cntdown
     unsigned char *gbase;  // the global buffer all regions live in + this lane's 16-byte column of a line
     uint32_t LOG_NB, LOG_CAP, CAP, LOG_GPB;  // GPB = ring groups per bin
     uint32_t my_bin, my_slot;     // the bin and the ring-group slot inside it that this lane owns
     uint32_t my_unit0, my_cap;    // first 128-byte unit of that bin's region in the global buffer; its capacity in entries
-    uint32_t my_pending;          // bins that span several waves: groups flushed by the last flush, not yet released
     uint32_t flushes;             // flushes done so far (uniform)
+#ifdef TPC_BINS3_DEBUG
+    unsigned long long *dbg = nullptr;  // [0] ring-full entries lost, [1] region-full entries lost, [2] retry-loop iterations, [3] entries that waited and were stored
+#endif
 
     static size_t lds_bytes(int) { return OFF_END; }
 
     __device__ __forceinline__ uint32_t *tail() const { return reinterpret_cast<uint32_t *>(base + OFF_TAIL); }
     __device__ __forceinline__ uint32_t *limit() const { return reinterpret_cast<uint32_t *>(base + OFF_LIMIT); }
     __device__ __forceinline__ uint32_t *done() const { return reinterpret_cast<uint32_t *>(base + OFF_DONE); }
+    __device__ __forceinline__ uint32_t *cntdown() const { return reinterpret_cast<uint32_t *>(base + OFF_CNTDOWN); }  // bins that span several waves: owners still copying
     __device__ __forceinline__ bool multi() const { return LOG_GPB > 6u; }  // a bin's ring groups span more than one wave
 
     __device__ __forceinline__ unsigned char *carve(unsigned char *p, int log_nb)
@@ -61,7 +63,7 @@ struct Bins3 {
         LOG_GPB = LOG_CAP - LOG_GROUP;
         my_bin = threadIdx.x >> LOG_GPB;
         my_slot = threadIdx.x & ((1u << LOG_GPB) - 1u);
-        my_unit0 = 0; my_cap = 0; my_pending = 0; flushes = 0;
+        my_unit0 = 0; my_cap = 0; flushes = 0;
         return p + OFF_END;
     }
 
@@ -111,18 +113,29 @@ struct Bins3 {
                     uint32_t bi = b[i], si = slot[i];
                     T vi = val[i];
                     asm volatile("" : "+v"(bi), "+v"(si), "+v"(vi));
-                    const uint32_t owner = multi() ? 0u : (bi << LOG_GPB) >> 6;  // wave that owns the bin's ring groups
-                    const uint32_t d = __hip_atomic_load(&done()[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // the wave(s) that own the bin's ring groups: done with this flush?  (read BEFORE the limit: a finished owner's limit is final)
+                    const uint32_t w0 = (bi << LOG_GPB) >> 6, nw = multi() ? 1u << (LOG_GPB - 6u) : 1u;
+                    bool owners_done = true;
+                    for (uint32_t w = w0; w < w0 + nw; w++) owners_done = owners_done && __hip_atomic_load(&done()[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == flushes;
                     const uint32_t l2 = __hip_atomic_load(&limit()[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (si < l2) {
                         *reinterpret_cast<T *>(base + (((bi << LOG_CAP) | (si & (CAP - 1u))) << LOG_T)) = vi;
                         pend &= ~(1u << i);
-                    } else if (multi() || d == flushes) {  // d is read BEFORE the limit: a finished owner's limit is the final one
+#ifdef TPC_BINS3_DEBUG
+                        if (dbg) atomicAdd(dbg + 3, 1ull);
+#endif
+                    } else if (owners_done) {
                         lost(bi, vi);
                         pend &= ~(1u << i);
+#ifdef TPC_BINS3_DEBUG
+                        if (dbg) atomicAdd(dbg + 0, 1ull);
+#endif
                     }
                 }
             }
+#ifdef TPC_BINS3_DEBUG
+            if (dbg && pend) atomicAdd(dbg + 2, 1ull);
+#endif
             if (pend) __builtin_amdgcn_s_sleep(2);
         }
     }
@@ -131,11 +144,6 @@ struct Bins3 {
     __device__ __forceinline__ void flush(Lost lost)
     {
         pt_barrier_lds();  // B1: every push of the round is in its ring
-        if (multi()) {  // bins that span several waves: release what the previous flush copied (every wave has long finished that copy)
-            if (my_slot == 0 && my_pending) limit()[my_bin] += my_pending << LOG_GROUP;
-            my_pending = 0;
-            pt_barrier_lds();
-        }
         uint32_t t = tail()[my_bin];
         const uint32_t lim = limit()[my_bin];
         const uint32_t h = lim - CAP;
@@ -143,6 +151,7 @@ struct Bins3 {
             t = h + CAP;
             if (my_slot == 0) tail()[my_bin] = t;
         }
+        if (multi() && my_slot == 0) cntdown()[my_bin] = 1u << (LOG_GPB - 6u);  // owner waves that have to finish their copy before the ring space is released
         pt_barrier_lds();  // B2: no push of the next round before every snapshot is taken
         const uint32_t n = t - h;
         const uint32_t nfull = FINAL ? (n + GROUP - 1u) >> LOG_GROUP : n >> LOG_GROUP;
@@ -153,19 +162,28 @@ struct Bins3 {
         const unsigned long long m = __ballot(ready);
         const uint32_t cnt = (uint32_t)__popcll(m);
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, l = lane & 7u;
-        uint2 *list = reinterpret_cast<uint2 *>(base + OFF_LIST) + (wave << 6);
-        if (ready) {
-            const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        // The complete groups of the wave, compacted: lane r < cnt receives the descriptor of the r-th complete ring group.  A
+        // full permutation (the other lanes take the ranks cnt, cnt + 1, ...) through the LDS crossbar (ds_permute), no LDS
+        // memory: the 8 KiB of per-wave item lists this replaced are what lets the hash kernels keep their seed tables in LDS.
+        uint32_t dx, dy;
+        {
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));  // complete groups in lower lanes
+            const uint32_t rank = ready ? below : cnt + (lane - below);
             const uint32_t valid = FINAL ? min(n - (rel << LOG_GROUP), (uint32_t)GROUP) : (uint32_t)GROUP;
             const uint32_t over = pos + GROUP > my_cap ? 0x80000000u : 0u;  // the region is full: the group's entries go to lost()
-            list[idx] = make_uint2(lane | (valid << 8) | over, my_unit0 + (pos >> LOG_GROUP));
+            dx = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)(lane | (valid << 8) | over));
+            dy = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)(my_unit0 + (pos >> LOG_GROUP)));
         }
         // copy-out: 8 lanes per 128-byte group, 16 bytes per lane
         constexpr int EPL = 16 / (int)sizeof(T);
         const unsigned char *ring = base + (wave << 13) + l * 16u;  // this wave's 64 ring groups
-        for (uint32_t i = lane >> 3; i < (DEBUG == 2 ? 0u : cnt); i += 8u) {
-            uint2 it = list[i];
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 8u) {  // uniform trip count: the crossbar reads need every SOURCE lane active
+            const uint32_t i = i0 + (lane >> 3);
+            uint2 it;
+            it.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)dx);
+            it.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i << 2), (int)dy);
             if (DEBUG == 1) it.y &= 1023u;
+            if (i >= cnt) continue;
             union { uint4 q; T e[EPL]; } u;
             u.q = *reinterpret_cast<const uint4 *>(ring + ((it.x & 63u) << 7));
             unsigned char *dst = gbase + (uint64_t)it.y * (uint64_t)PT_LINE;
@@ -180,7 +198,12 @@ struct Bins3 {
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
                     if (l * EPL + e >= valid) u.e[e] = SENT;
-                    else if (over) lost(b, u.e[e]);
+                    else if (over) {
+                        lost(b, u.e[e]);
+#ifdef TPC_BINS3_DEBUG
+                        if (dbg) atomicAdd(dbg + 1, 1ull);
+#endif
+                    }
                 }
                 if (!over) *reinterpret_cast<uint4 *>(dst) = u.q;
             }
@@ -188,9 +211,17 @@ struct Bins3 {
         // release the ring space: only after this wave's ring reads have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         flushes++;
-        if (multi()) my_pending = my_slot == 0 ? nfull : 0u;
-        else if (my_slot == 0) limit()[my_bin] = lim + (nfull << LOG_GROUP);
-        if (FINAL && my_slot == 0 && !multi()) tail()[my_bin] = h + (nfull << LOG_GROUP);
+        if (!multi()) {
+            if (my_slot == 0) {
+                limit()[my_bin] = lim + (nfull << LOG_GROUP);
+                if (FINAL) tail()[my_bin] = h + (nfull << LOG_GROUP);
+            }
+        } else if (lane == 0) {  // the wave's 64 ring groups belong to one bin: the last owner wave to finish releases the space
+            if (atomicSub(&cntdown()[my_bin], 1u) == 1u) {
+                limit()[my_bin] = lim + (nfull << LOG_GROUP);
+                if (FINAL) tail()[my_bin] = h + (nfull << LOG_GROUP);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&done()[wave], flushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -201,7 +232,7 @@ struct Bins3 {
     {
         pt_barrier_lds();
         if (my_slot == 0) {
-            const uint32_t head = limit()[my_bin] - CAP + (multi() ? my_pending << LOG_GROUP : 0u);
+            const uint32_t head = limit()[my_bin] - CAP;
             out[idx(my_bin)] = min(head, my_cap);
         }
     }

@@ -257,7 +257,6 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
 {
     const uint64_t tiles = text_tiles512(c);
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
-    if (c->P.q > 8) return false;  // the partitioned kernels are instantiated for q <= 8
     const int64_t budget = part_budget(c);
     for (uint64_t batches = 1;; batches *= 2) {
         const uint64_t per = (tiles + batches - 1) / batches;
@@ -509,7 +508,8 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     uint64_t batches = 1;
     bool defer = false;
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
-    if (c->P.q > 8) part = false;  // the partitioned kernels are instantiated for q <= 8
+    // 9..16 hash functions run on the instruction-lean hash kernel only (tpc_partition.hip), which takes a 24-bit slice index
+    if (c->P.q > 8 && c->P.L - c->opt_slice_bits > 24) part = false;
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);
@@ -610,6 +610,9 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         c->filter_zero_pending = false;
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (getenv("TPC_DEBUG_OVF"))
+            fprintf(stderr, "[ovf] insert: %llu overflow entries (cap %llu, flag %llu) b1=%d b2=%d ppr=%d cap1=%llu cap2=%llu nwg1=%u\n", ov[0], (unsigned long long)pl.ovf_cap, ov[1], pl.b1,
+                    pl.b2, pl.pos_per_round, (unsigned long long)pl.cap1, (unsigned long long)pl.cap2, pl.nwg1);
         overflowed = overflowed || ov[1] != 0;
         c->stat_path[0] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_batches[0] = (int64_t)((tiles + per_batch - 1) / per_batch);
@@ -744,6 +747,14 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         overflowed = overflowed || f1[1] != 0 || f2 != 0;
         c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
+        if (getenv("TPC_DEBUG_OVF")) {
+            unsigned long long sc[65];
+            (void)hipMemcpy(sc, pl.surv_cur, sizeof sc, hipMemcpyDeviceToHost);
+            unsigned long long tot = 0, most = 0;
+            for (int i = 0; i < 64; i++) { tot += sc[i]; most = std::max(most, sc[i]); }
+            fprintf(stderr, "[ovf] query: %llu overflow entries (cap %llu, flag %llu), survivors %llu (fullest list %llu of %llu, flag %llu) b1=%d b2=%d ppr=%d loads=%d\n", f1[0],
+                    (unsigned long long)pl.ovf_cap, f1[1], tot, most, (unsigned long long)pl.surv_cap, f2, pl.b1, pl.b2, pl.pos_per_round, pl.loads);
+        }
         if (getenv("TPC_PROFILE_PHASES")) {
             unsigned long long pr[32];
             (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
@@ -1326,6 +1337,13 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
             if (tpc_launch_insert_part_hash(make_launch(c), pl, lo, hi, gated, nullptr)) return fail(c, -1, "hash launch failed");
         }
         HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+#ifdef TPC_BINS3_DEBUG
+        {
+            unsigned long long d[12];
+            (void)hipMemcpy(d, pl.ovf_cur, sizeof d, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[bins3] insert hash: ring-lost %llu region-lost %llu retry-iterations %llu waited-and-stored %llu (overflow list %llu) ppr=%d cap1=%llu\n", d[8], d[9], d[10], d[11], d[0], pl.pos_per_round, (unsigned long long)pl.cap1);
+        }
+#endif
     } else {
         TpcQPlan pl = c->sh_qpl;
         pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t0;  // positions in the entries are relative to this rank's batch
@@ -1470,7 +1488,12 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
     HIPCHK(c, hipMemcpyAsync(cur, pl.surv_cur, sizeof cur, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ov[1] || cur[64]) return fail(c, -20, "overflow or survivor list overflowed (address skew beyond what the sharded path handles)");
+    if (ov[1] || cur[64]) {
+        unsigned long long most = 0;
+        for (int i = 0; i < 64; i++) most = std::max(most, cur[i]);
+        return fail(c, -20, "overflow or survivor list overflowed (address skew beyond what the sharded path handles): %llu overflow entries of %llu, fullest survivor list %llu of %llu",
+                    ov[0], (unsigned long long)pl.ovf_cap, most, (unsigned long long)pl.surv_cap);
+    }
     uint64_t ns = 0;
     for (int i = 0; i < 64; i++) ns += std::min<uint64_t>(cur[i], pl.surv_cap);
     c->sh_nsurv = ns;

@@ -22,6 +22,7 @@
 // HBM traffic per address: 4 B written + 4 B read per level, plus one sequential pass over the
 // filter -- versus one 64-byte read-for-ownership and write-back per address for the atomics.
 #include "tpc_bins3.h"
+#include "tpc_lean.h"
 #include "tpc_insert_step.h"
 #include "tpc_internal.h"
 #include <algorithm>
@@ -82,6 +83,9 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
     Bins3<uint32_t, PH_THREADS> bins;
     uint64_t *s_b2 = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));  // [2][TW]
+#ifdef TPC_BINS3_DEBUG
+    bins.dbg = ovf.cursor + 8;
+#endif
     uint64_t *s_h = s_b2 + 2 * TW;
     uint64_t *s_hk = s_h + Q * 5;
     uint32_t *s_n2 = reinterpret_cast<uint32_t *>(s_hk + Q * 5);              // [2][TW]
@@ -121,6 +125,223 @@ k_part_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const
                 for (int s = s0; s < min(s0 + pos_per_round, TPC_RUN); s++)  // any round length: the last round of a run may be short
                     hashed += tpc_insert_step<Q, GATED>(r, P, s_h, s_hk, s_b, s_n, g0 + s, wbase, lo, hi, emit);
             bins.template flush<false>(lost);
+        }
+    }
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt1, ridx);
+    if (n_kmers) {
+        for (int off = 32; off > 0; off >>= 1) hashed += __shfl_down(hashed, off, 64);
+        if ((tid & 63) == 0) s_w[tid >> 6] = hashed;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t = 0;
+            for (int i = 0; i < PH_THREADS / 64; i++) t += s_w[i];
+            if (t) atomicAdd(n_kmers, (unsigned long long)t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ level 1, instruction-lean
+// k_part_hash rebuilt around the VALU instruction count (the SQ counters put it at 76 % VALU issue; tpc_lean.h): the 32 first
+// and 32 next characters of a thread's run sit in registers; every function's roll reads {h[c], hk[rc c]} and {hk[c], h[rc c]}
+// as two 16-byte LDS pairs; rotations and the address split run on 32-bit halves; the run is seeded from a table of
+// pre-rotated letter hashes when that fits LDS (H(w) = XOR_t rotl(h[w_t], k-1-t), H'(w) = XOR_t rotl(h[rc w_t], t)).
+// Same addresses, same regions and overflow entries as k_part_hash (FilterFillerWorker, reference VE.h:1035-1083).
+__device__ __forceinline__ uint64_t p_rotl_n(uint64_t x, int L, int r)
+{   // fastleftshiftn (cyclichash.h:42-44)
+    if (r == 0) return x;
+    return ((x & ((1ull << (L - r)) - 1ull)) << r) | (x >> (L - r));
+}
+
+__device__ __forceinline__ uint64_t p_spread2(uint32_t m)
+{   // every mask bit doubled: bit i -> bits 2i, 2i+1
+    uint64_t x = m;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
+}
+
+__device__ __forceinline__ uint64_t p_lo(const uint4 &e) { return ((uint64_t)e.y << 32) | e.x; }
+__device__ __forceinline__ uint64_t p_hi(const uint4 &e) { return ((uint64_t)e.w << 32) | e.z; }
+
+template <int Q, bool GATED, bool SHARDED>
+__global__ void __launch_bounds__(PH_THREADS)
+k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
+             const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
+             uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NB = 1 << LOG_NB;
+    constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
+    Bins3<uint32_t, PH_THREADS> bins;
+    uint64_t *s_b2 = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB));  // [2][TW] bases, N positions cleared to code 0
+    uint4 *s_roll = reinterpret_cast<uint4 *>(s_b2 + 2 * TW);                // [2][5][Q]: as next character {h_i[c], hk_i[rc c]}, as first {hk_i[c], h_i[rc c]}
+    uint4 *s_seed = s_roll + 10 * Q;                                         // [seed_rows][5][Q]: {rotl(h_i[c], k-1-t), rotl(h_i[rc c], t)}
+    uint32_t *s_n2 = reinterpret_cast<uint32_t *>(s_seed + (size_t)seed_rows * 5 * Q);  // [2][TW]
+    uint32_t *s_w = s_n2 + 2 * TW;  // 16 words
+    const int tid = threadIdx.x, half = tid >> 9, lt = tid & (PT_THREADS - 1);
+    const int k = P.k, L = P.L;
+    const uint64_t *s_b = s_b2 + half * TW;
+    const uint32_t *s_n = s_n2 + half * TW;
+    for (int i = tid; i < 5 * Q; i += PH_THREADS) {
+        const int c = i / Q, f = i % Q, rc = c == 4 ? 4 : 3 - c;
+        const uint64_t h = tab[f * 5 + c], hk = tab[TPC_TAB_HK + f * 5 + c], hr = tab[f * 5 + rc], hkr = tab[TPC_TAB_HK + f * 5 + rc];
+        s_roll[i] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)hkr, (uint32_t)(hkr >> 32));
+        s_roll[5 * Q + i] = make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), (uint32_t)hr, (uint32_t)(hr >> 32));
+    }
+    for (int i = tid; i < seed_rows * 5 * Q; i += PH_THREADS) {
+        const int t = i / (5 * Q), c = (i / Q) % 5, f = i % Q, rc = c == 4 ? 4 : 3 - c;
+        const uint64_t a = p_rotl_n(tab[f * 5 + c], L, (k - 1 - t) % L), b = p_rotl_n(tab[f * 5 + rc], L, t % L);
+        s_seed[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    const int shift = L - LOG_NB;
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    // one rank: a workgroup's regions are contiguous ([w][b1]); sharded: destination-major (pt_r1_send)
+    auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
+    bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 5), (uint32_t)cap1); });  // 32 entries = one 128-byte unit
+    auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
+    LeanRot R;
+    R.set(L);
+    LeanSplit S;
+    S.set(perm, LOG_NB);
+    const int xw = (k + 1) / 32 + 2;
+    const uint32_t p0 = 32u + (uint32_t)lt * 32u;  // my first position relative to the first staged word (the one before the tile)
+    unsigned hashed = 0;
+    int since_flush = 0;
+    // the q Bloom addresses of one edge -> bins
+    auto emit_edge = [&](const uint64_t (&a)[Q]) {
+        constexpr int H = Q > 8 ? (Q + 1) / 2 : Q;  // more than 8 functions: two batches (claims in flight and live registers stay bounded)
+#pragma unroll
+        for (int h0 = 0; h0 < Q; h0 += H) {
+            uint32_t b[H], val[H];
+            bool ok[H];
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                ok[i] = h0 + i < Q;
+                if (h0 + i < Q) S.split(a[h0 + i], b[i], val[i]); else { b[i] = 0; val[i] = 0; }
+            }
+            bins.template push_batch<H>(b, val, ok, lost);
+        }
+    };
+    for (uint64_t pair = tile0 + 2 * (uint64_t)blockIdx.x; pair < tile0 + n_tiles; pair += 2 * (uint64_t)gridDim.x) {
+        __syncthreads();  // previous tiles' staging is no longer read
+        const uint64_t tile = pair + half;
+        const bool have = tile < tile0 + n_tiles;
+        const uint64_t wfirst = tile * PT_THREADS;
+        for (int i = lt; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
+            const int64_t w = (int64_t)wfirst - 1 + i;
+            uint64_t b = have && w >= 0 ? bases[w] : 0ull;
+            const uint32_t m = have && w >= 0 ? nmask[w] : 0xFFFFFFFFu;  // no tile: all N, nothing is emitted
+            if (m) b &= ~p_spread2(m);  // an N has code 0 in the staged word: code = c | isN << 2 below
+            s_b2[half * TW + i] = b;
+            s_n2[half * TW + i] = m;
+        }
+        __syncthreads();
+        // The text is padded with N to whole tiles (tpc_seq_upload): runs past its end find no vertex and need no guard.
+        const uint64_t cw = s_b[lt + 1];
+        const uint32_t nw = s_n[lt + 1];
+        const uint64_t cx = (uint64_t)lean_chars16(s_b, p0 + (uint32_t)k) | ((uint64_t)lean_chars16(s_b, p0 + (uint32_t)k + 16u) << 32);
+        const uint32_t nx = lean_nbits32(s_n, p0 + (uint32_t)k);
+        uint32_t cp = lean_char(s_b, s_n, p0 - 1u);
+        int ncnt = 0;  // N characters inside the window (k - definiteCount, VE.h:1033)
+        for (int t = 0; t < k; t += 32) {
+            uint32_t bits = lean_nbits32(s_n, p0 + (uint32_t)t);
+            if (k - t < 32) bits &= (1u << (k - t)) - 1u;
+            ncnt += __popc(bits);
+        }
+        uint64_t pos[Q], neg[Q];  // VertexRollingHash ctor (vertexrollinghash.h:79-102)
+#pragma unroll
+        for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
+        if (seed_rows) {
+            for (int t0 = 0; t0 < k; t0 += 16) {
+                uint32_t ch = lean_chars16(s_b, p0 + (uint32_t)t0), nb = lean_nbits32(s_n, p0 + (uint32_t)t0);
+                const int m = min(16, k - t0);
+                for (int j = 0; j < m; j++) {
+                    const uint32_t c = (ch & 3u) | ((nb & 1u) << 2);
+                    ch >>= 2; nb >>= 1;
+                    const uint4 *row = s_seed + ((t0 + j) * 5 + (int)c) * Q;
+#pragma unroll
+                    for (int i = 0; i < Q; i++) { const uint4 e = row[i]; pos[i] ^= p_lo(e); neg[i] ^= p_hi(e); }
+                }
+            }
+        } else {
+            for (int t = 0; t < k; t++) {
+                const uint32_t c = lean_char(s_b, s_n, p0 + (uint32_t)t), cr = lean_char(s_b, s_n, p0 + (uint32_t)(k - 1 - t));
+                const uint4 *rowp = s_roll + c * Q, *rown = s_roll + (5 + cr) * Q;
+#pragma unroll
+                for (int i = 0; i < Q; i++) { pos[i] = R.rotl1(pos[i]) ^ p_lo(rowp[i]); neg[i] = R.rotl1(neg[i]) ^ p_hi(rown[i]); }
+            }
+        }
+#pragma unroll 1
+        for (int s = 0; s < TPC_RUN; s++) {  // not unrolled: one copy of the push and flush code
+            const uint32_t cf = ((uint32_t)(cw >> (2 * s)) & 3u) | (((nw >> s) & 1u) << 2);  // first character of the window
+            const uint32_t cn = ((uint32_t)(cx >> (2 * s)) & 3u) | (((nx >> s) & 1u) << 2);  // the character after it
+            const uint4 *rowN = s_roll + cn * Q, *rowF = s_roll + (5 + cf) * Q;
+            // function 0 decides the strand and the round gate; hash_extend / hash_prepend of the outgoing edge
+            // (cyclichash.h:112-121) are the intermediates of update / reverse_update (cyclichash.h:86-102)
+            const uint4 eN0 = rowN[0], eF0 = rowF[0];
+            const uint64_t ep0 = R.rotl1(pos[0]) ^ p_lo(eN0), en0 = neg[0] ^ p_hi(eN0);
+            const uint64_t np0 = ep0 ^ p_lo(eF0), nn0 = R.rotr1(en0 ^ p_hi(eF0));
+            const bool vertex = ncnt == 0;
+            bool go = vertex;
+            if (GATED && go) {  // VE.h:1063-1073
+                const uint64_t first = tpc_min(pos[0], neg[0]), second = tpc_min(np0, nn0);
+                go = (first >= lo && first <= hi) || (second >= lo && second <= hi);
+            }
+            const bool main_edge = go && cn < 4u;
+            if (go && (cn | cp) >= 4u) {  // rare: the dummy edges beside an N (VE.h:1048-1058), from the window's hashes before they roll
+                const bool out_side = cn >= 4u, in_side = cp >= 4u;
+#pragma unroll 1
+                for (int d = 0; d < 4; d++) {
+                    const int c = (d & 1) ? 3 : 0;
+                    if (d < 2 ? !out_side : !in_side) continue;
+                    uint64_t p[Q], n[Q];
+                    if (d < 2) {  // out-edge v + c
+                        const uint4 *r = s_roll + c * Q;
+#pragma unroll
+                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = R.rotl1(pos[i]) ^ p_lo(e); n[i] = neg[i] ^ p_hi(e); }
+                    } else {      // in-edge c + v
+                        const uint4 *r = s_roll + (5 + c) * Q;
+#pragma unroll
+                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = p_lo(e) ^ pos[i]; n[i] = R.rotl1(neg[i]) ^ p_hi(e); }
+                    }
+                    const bool ngd = tpc_pick_neg<Q>(p, n);
+                    uint64_t a[Q];
+#pragma unroll
+                    for (int i = 0; i < Q; i++) a[i] = ngd ? n[i] : p[i];
+                    emit_edge(a);
+                }
+            }
+            // canonical strand of the out-edge (DetermineStrandExtend, vertexrollinghash.h:170-184)
+            bool ng = en0 < ep0;
+            if (main_edge && ep0 == en0) {
+                ng = false;
+                for (int i = 1; i < Q; i++) {
+                    const uint4 e = rowN[i];
+                    const uint64_t pp = R.rotl1(pos[i]) ^ p_lo(e), nn = neg[i] ^ p_hi(e);
+                    if (pp != nn) { ng = nn < pp; break; }
+                }
+            }
+            uint64_t a[Q];
+            a[0] = ng ? en0 : ep0;
+            pos[0] = np0;
+            neg[0] = nn0;
+#pragma unroll
+            for (int i = 1; i < Q; i++) {
+                const uint4 eN = rowN[i], eF = rowF[i];
+                const uint64_t ep = R.rotl1(pos[i]) ^ p_lo(eN), en = neg[i] ^ p_hi(eN);
+                a[i] = ng ? en : ep;
+                pos[i] = ep ^ p_lo(eF);
+                neg[i] = R.rotr1(en ^ p_hi(eF));
+            }
+            if (main_edge) emit_edge(a);
+            hashed += vertex;
+            ncnt += (int)(cn >> 2) - (int)(cf >> 2);
+            cp = cf;
+            if (++since_flush == pos_per_round) { bins.template flush<false>(lost); since_flush = 0; }
         }
     }
     bins.template flush<true>(lost);
@@ -280,6 +501,24 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
+    if (perm.F <= 24 && !getenv("TPC_NO_LEAN")) {  // the instruction-lean kernel (a 24-bit slice index)
+        const size_t fixed = Bins3<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 10 * 16 + 64 + 64;
+        const size_t seed = (size_t)a.P.k * 5 * Q * 16;  // the seed table, when it fits beside the rings (160 KB per workgroup)
+        const int seed_rows = fixed + seed <= (size_t)160 * 1024 - 256 ? a.P.k : 0;
+        const size_t lds = fixed + (seed_rows ? seed : 0);
+#define TPC_HASH2_GO(G, S)                                                                                                                  \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_part_hash2<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL((k_part_hash2<Q, G, S>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers, seed_rows);  \
+    } while (0)
+        if (pl.world > 1) { if (gated) TPC_HASH2_GO(true, true); else TPC_HASH2_GO(false, true); }
+        else { if (gated) TPC_HASH2_GO(true, false); else TPC_HASH2_GO(false, false); }
+#undef TPC_HASH2_GO
+        return 0;
+    }
+    if constexpr (Q > 8) return -1;  // 9..16 functions: instantiated for the lean kernel only (the caller falls back to the direct kernel)
+    else {
     const size_t lds = Bins3<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 5 * 16 + 64;
 #define TPC_HASH_GO(G, S)                                                                                                                   \
     do {                                                                                                                                    \
@@ -291,6 +530,7 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     else { if (gated) TPC_HASH_GO(true, false); else TPC_HASH_GO(false, false); }
 #undef TPC_HASH_GO
     return 0;
+    }
 }
 
 // entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the < 32 leftovers per bin
@@ -464,6 +704,14 @@ int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint6
     case 6: return launch_hash_q<6>(a, pl, gated, lo, hi, n_kmers);
     case 7: return launch_hash_q<7>(a, pl, gated, lo, hi, n_kmers);
     case 8: return launch_hash_q<8>(a, pl, gated, lo, hi, n_kmers);
+    case 9: return launch_hash_q<9>(a, pl, gated, lo, hi, n_kmers);
+    case 10: return launch_hash_q<10>(a, pl, gated, lo, hi, n_kmers);
+    case 11: return launch_hash_q<11>(a, pl, gated, lo, hi, n_kmers);
+    case 12: return launch_hash_q<12>(a, pl, gated, lo, hi, n_kmers);
+    case 13: return launch_hash_q<13>(a, pl, gated, lo, hi, n_kmers);
+    case 14: return launch_hash_q<14>(a, pl, gated, lo, hi, n_kmers);
+    case 15: return launch_hash_q<15>(a, pl, gated, lo, hi, n_kmers);
+    case 16: return launch_hash_q<16>(a, pl, gated, lo, hi, n_kmers);
     }
     return -1;
 }

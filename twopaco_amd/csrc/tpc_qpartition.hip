@@ -750,6 +750,65 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------------ D, table form
+// k_q_verify for k <= 31: the edge is a (k+1)-mer that fits one packed word, and its 2Q hashes are evaluated in closed form
+// from a table of pre-rotated letter hashes -- H_i(E) = XOR_t rotl(h_i[E_t], k - t), H_i(rc E) = XOR_t rotl(h_i[rc E_t], t)
+// (the fold of cyclichash.h:106-109 written out) -- one 16-byte LDS read per letter and function for both strands, no
+// rotations in the loop: ~600 instead of ~1600 vector instructions per survivor (the kernel was 74 % VALU issue,
+// profiles/r03a_sq.csv).  Same verdicts: canonical strand by the first function whose two values differ (tpc_pick_neg).
+template <int Q>
+__global__ void __launch_bounds__(256)
+k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ filter,
+            const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t gbase, uint32_t *rmask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(smem);  // [k + 1][4][Q]: {rotl(h_i[c], k - t), rotl(h_i[3 - c], t)}
+    const int k = P.k, L = P.L;
+    for (int i = threadIdx.x; i < (k + 1) * 4 * Q; i += 256) {
+        const int t = i / (4 * Q), c = (i / Q) & 3, f = i % Q;
+        const uint64_t a = q_rotl_n(tab[f * 5 + c], L, (k - t) % L), b = q_rotl_n(tab[f * 5 + 3 - c], L, t % L);
+        s_t[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    __syncthreads();
+    const int list = blockIdx.y;
+    const uint64_t n = min((uint64_t)surv_cur[list], surv_cap);
+    const uint64_t *my = surv + (uint64_t)list * surv_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t wmask = (1ull << (2 * k)) - 1ull;  // k <= 31
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const uint64_t sid = my[idx];
+        const int e = (int)(sid & 7), c = e & 3;
+        const uint64_t g = gbase + (sid >> 3);
+        const uint64_t w = tpc_text_word(bases, g) & wmask;
+        // the edge's k + 1 letters, first letter in the low bits: in-edge c + v, out-edge v + c
+        uint64_t E = e < 4 ? ((w << 2) | (uint64_t)c) : (w | ((uint64_t)c << (2 * k)));
+        uint64_t p[Q], nn[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) { p[i] = 0; nn[i] = 0; }
+        const uint4 *row = s_t;
+        for (int t = 0; t <= k; t++) {
+            const uint4 *r = row + ((uint32_t)E & 3u) * Q;
+            E >>= 2;
+            row += 4 * Q;
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                const uint4 x = r[i];
+                p[i] ^= ((uint64_t)x.y << 32) | x.x;
+                nn[i] ^= ((uint64_t)x.w << 32) | x.z;
+            }
+        }
+        const bool ng = tpc_pick_neg<Q>(p, nn);  // DetermineStrandExtend / Prepend (vertexrollinghash.h:170-200)
+        bool present = true;  // function 0 passed in k_q_lookup; the other probes are independent loads
+        uint32_t wv[Q];
+        uint64_t addr[Q];
+#pragma unroll
+        for (int i = 1; i < Q; i++) { addr[i] = ng ? nn[i] : p[i]; wv[i] = filter[addr[i] >> 5]; }
+#pragma unroll
+        for (int i = 1; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
+        if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
+    }
+}
+
 // ------------------------------------------------------------------------------------------ sharded verification
 // With the filter sharded by bit address the q-1 remaining probes of a survivor live on other ranks:
 // k_v_addrs gives, for hash functions fn .. fn+fn_count-1, the (owner rank, address inside the owner's
@@ -990,6 +1049,13 @@ void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, i
 template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
+    const size_t table = (size_t)(a.P.k + 1) * 4 * Q * 16;  // k_q_verify2's letter table
+    if (a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN")) {
+        (void)hipFuncSetAttribute((const void *)k_q_verify2<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
+        hipLaunchKernelGGL((k_q_verify2<Q>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
+                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+        return;
+    }
     hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
                        pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
 }
@@ -1114,7 +1180,7 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
 
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
 {
-    if (a.P.q < 1 || a.P.q > 8) return -1;  // k_q_verify is instantiated for 1..8 functions
+    if (a.P.q < 1 || a.P.q > TPC_TAB_MAXQ) return -1;  // k_q_verify is instantiated for 1..16 functions
     launch_qhash(a, pl, gated, lo, hi, rmask);
     return 0;
 }
@@ -1182,6 +1248,14 @@ int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rm
     case 6: launch_qverify<6>(a, pl, rmask); break;
     case 7: launch_qverify<7>(a, pl, rmask); break;
     case 8: launch_qverify<8>(a, pl, rmask); break;
+    case 9: launch_qverify<9>(a, pl, rmask); break;
+    case 10: launch_qverify<10>(a, pl, rmask); break;
+    case 11: launch_qverify<11>(a, pl, rmask); break;
+    case 12: launch_qverify<12>(a, pl, rmask); break;
+    case 13: launch_qverify<13>(a, pl, rmask); break;
+    case 14: launch_qverify<14>(a, pl, rmask); break;
+    case 15: launch_qverify<15>(a, pl, rmask); break;
+    case 16: launch_qverify<16>(a, pl, rmask); break;
     default: return -1;
     }
     return 0;
@@ -1207,6 +1281,7 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32
     case 6: launch_qverify<6>(a, pl, rmask); break;
     case 7: launch_qverify<7>(a, pl, rmask); break;
     case 8: launch_qverify<8>(a, pl, rmask); break;
+    default: return tpc_launch_query_verify(a, pl, rmask);
     }
     return 0;
 }
@@ -1224,6 +1299,8 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
     switch (a.P.q) {
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;
+    case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break;
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break;
     default: return -1;
     }
 #undef CALL

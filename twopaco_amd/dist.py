@@ -23,6 +23,7 @@ moves them to the owner of their filter slices.  See the docstring of `address_s
 import json
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -553,32 +554,40 @@ def merge_records(parts, rec_start, rec_length, k, n_junctions):
     return out
 
 
-def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload.
+def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None, cpu_baseline=None):
+    """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload, one process per GPU over RCCL.
 
-    TPC_BENCH_BACKEND=module:function (TEST ONLY, tests/test_dist_cpu.py): the rank backend comes from
-    function(args, rank, world) -> (backend, n_kmers, params, description) instead of the HIP library, so that the
-    launch / rendezvous / timing / reporting path of `bench.py --gpus N` can run under gloo on a machine without
-    GPUs.  Such a line says "backend": "injected" and is not a measurement."""
-    import importlib
-
+    The headline decomposition is the north star's at every N that is a power of two -- the Bloom filter sharded by bit
+    address, all-to-all of the level-1 regions per pass -- so the scaling curve is ONE decomposition; below 8 GPUs the
+    vertex-hash-range decomposition (no data-path exchange) is timed as well and reported under "ranges".
+    golden: the reference's counters for this workload (tests/golden/cases.json); a result that differs ends the run with a
+    non-zero exit code instead of a line.  cpu_baseline(recs, params) -> dict: timed on rank 0 after the timed region.
+    backend_factory(args, rank, world) -> (backend, n_kmers, params, description): what tests/ use to drive the launch /
+    rendezvous / timing / reporting path over gloo without a GPU (such a line says "backend": "injected")."""
     import torch
     import torch.distributed as dist
 
     from . import capi, synth
 
     backend = os.environ.get("TPC_DIST_BACKEND", "nccl")  # "gloo": several ranks on one GPU (testing only)
-    injected = os.environ.get("TPC_BENCH_BACKEND")
-    address = getattr(args, "decomposition", "ranges") == "address"
-    ctx = None
+    injected = backend_factory is not None
+    pow2 = world & (world - 1) == 0
+    decomposition = getattr(args, "decomposition", "auto")
+    if decomposition == "auto":
+        decomposition = "address" if pow2 and not injected else "ranges"
+    address = decomposition == "address"
+    also_ranges = address and world < 8 and getattr(args, "decomposition", "auto") == "auto"
+    ctx = ctx_r = None
     sharded2 = False
+    recs = None
+    pass2 = "replicated"
+    steps = {}
     if injected:
-        mod, fn = injected.split(":")
-        be, n_kmers, p, workload_desc = getattr(importlib.import_module(mod), fn)(args, rank, world)
+        be, n_kmers, p, workload_desc = backend_factory(args, rank, world)
         dist.init_process_group(backend)
         if address:
             raise RuntimeError("the injected test backend only drives the ranges decomposition")
-        step = lambda: sharded_step(be, dist, p["L"])
+        steps["ranges"] = lambda: sharded_step(be, dist, p["L"])
     else:
         ngpu = torch.cuda.device_count()
         device = local_rank % max(ngpu, 1)
@@ -607,34 +616,77 @@ def bench_main(args, rank, world, local_rank):
         ctx.seq_upload(text)
         if address:
             sh = AddressSharded(ctx, dist, torch.device("cuda", device), configure=pass2 != "records")
-            step = lambda: address_sharded_step(sh, sharded_pass2=pass2 if sharded2 else False)
-        else:
+            steps["address"] = lambda: address_sharded_step(sh, sharded_pass2=pass2 if sharded2 else False)
+        if not address:
             be = HipBackend(ctx)
-            step = lambda: sharded_step(be, dist, p["L"])
-    for _ in range(args.warmup):
-        step()
-    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit"] + (["shard_hash", "shard_apply"] if address else [])
-    kms = {n: 0.0 for n in names}
-    dist.barrier()
-    if ctx is not None:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
-        for n in names:
-            if ctx is not None:
-                kms[n] += max(ctx.kernel_ms(n), 0.0) / args.steps
-    if ctx is not None:
-        torch.cuda.synchronize()
-    dist.barrier()
+            steps["ranges"] = lambda: sharded_step(be, dist, p["L"])
+        elif also_ranges:  # its own context: a whole filter and the whole text on every rank
+            ctx_r = capi.Context(device)
+            ctx_r.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=20240229))
+            ctx_r.seq_upload(text)
+            be = HipBackend(ctx_r)
+            steps["ranges"] = lambda: sharded_step(be, dist, p["L"])
     dev = _dev(dist)
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
-    if not address or sharded2:  # (address-sharded with the replicated second pass: every rank already holds the whole result)
-        dist.all_reduce(tot)
-    dt = float(dt.item())
-    if rank == 0:
+    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "shard_hash", "shard_apply"]
+
+    def timed(which):
+        step = steps[which]
+        kctx = ctx if which == "address" or not address else ctx_r
+        for _ in range(args.warmup):
+            step()
+        kms = {n: 0.0 for n in names}
+        if which == "address":
+            sh.t.clear()
+            sh.stats["region_bytes_sent"] = 0
+            moved0 = sh.comm.bytes_moved
+        dist.barrier()
+        if ctx is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = step()
+            for n in names:
+                if kctx is not None:
+                    kms[n] += max(kctx.kernel_ms(n), 0.0) / args.steps
+        if ctx is not None:
+            torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
+        if which == "ranges" or sharded2:  # (address-sharded with the replicated second pass: every rank already holds the whole result)
+            dist.all_reduce(tot)
+        r = {"dt": float(dt.item()), "kms": kms, "result": {"candidate_marks": int(tot[1].item()), "junctions": st["junctions"], "junction_occurrences": int(tot[0].item())}}
+        if which == "address":
+            r["phase_ms"] = {k: v * 1e3 / args.steps for k, v in sh.t.items()}
+            r["exchange_bytes"] = (sh.comm.bytes_moved - moved0) // args.steps
+            a2a_s = sum(v for k, v in sh.t.items() if k.endswith("_all_to_all")) / args.steps
+            r["region_bytes_sent"] = sh.stats.get("region_bytes_sent", 0) // args.steps
+            # level-1 regions this rank SENT per second of all-to-all wall time (the exchange waits for every peer: a rate per
+            # rank, what the link model of DESIGN.md section 5.2 assumed as 50 GB/s per link and direction)
+            r["all_to_all_GBs"] = r["region_bytes_sent"] * (world - 1) / max(world, 1) / max(a2a_s, 1e-9) / 1e9
+            r["survivors"] = sh.stats.get("survivors")
+        return r
+
+    head = timed("address" if address else "ranges")
+    second = timed("ranges") if also_ranges else None
+    ok = True
+    if golden:  # the reference's own counters (VE.h:384-388, 413): every decomposition must reproduce them
+        for which, r in (("address" if address else "ranges", head), ("ranges", second)):
+            if r is None:
+                continue
+            res = r["result"]
+            want = {"junctions": golden["distinct"], "junction_occurrences": golden["true_marks"]}
+            if which == "address":  # one global filter: the candidate marks are the reference's too (every range has its own filter)
+                want["candidate_marks"] = golden["rounds"][0]["marks"]
+            bad = {k: (res[k], v) for k, v in want.items() if res[k] != v}
+            if bad:
+                ok = False
+                if rank == 0:
+                    print("bench: %s decomposition: result differs from the reference golden (got, want): %r" % (which, bad), file=sys.stderr)
+    dt = head["dt"]
+    if rank == 0 and ok:
+        kms = head["kms"]
         qms = max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9)
         # bytes rank 0's first-pass query moves by construction (bench.py: 6 uint64 entries per k-mer x 4 transfers, the
         # packed text, one pass over the filter): ranges -> whole text hashed, 1/world of the entries, whole filter;
@@ -653,15 +705,27 @@ def bench_main(args, rank, world, local_rank):
                                         "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
                                         "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
                        if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
-            "junction_occurrences_per_sec": int(tot[0].item()) * args.steps / dt,
+            "junction_occurrences_per_sec": head["result"]["junction_occurrences"] * args.steps / dt,
             "kernel_ms_rank0": kms,
             "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0", "achieved": design / (qms * 1e-3) / 1e9,
                          "peak": 8000.0, "unit": "GB/s", "frac": design / (qms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": design, "launch_ms": qms} if ctx is not None else None,
-            "exchange_bytes_rank0_per_step": (sh.comm.bytes_moved // (args.steps + args.warmup)) if address else None,
-            "phase_ms_rank0_per_step": {k: v * 1e3 / (args.steps + args.warmup) for k, v in sh.t.items()} if address else None,
-            "survivors_rank0": sh.stats.get("survivors") if address else None,
-            "result": {"candidate_marks": int(tot[1].item()), "junctions": st["junctions"], "junction_occurrences": int(tot[0].item())},
+            "exchange_bytes_rank0_per_step": head.get("exchange_bytes"),
+            "region_bytes_sent_rank0_per_step": head.get("region_bytes_sent"),
+            "all_to_all_GBs_rank0": head.get("all_to_all_GBs"),
+            "phase_ms_rank0_per_step": head.get("phase_ms"),
+            "survivors_rank0": head.get("survivors"),
+            "result": head["result"],
+            "result_equals_reference_golden": True if golden else None,
         }
+        if second is not None:
+            out["ranges"] = {"value": n_kmers * args.steps / second["dt"], "unit": "k-mers/s", "ms_per_step": second["dt"] / args.steps * 1e3,
+                             "decomposition": "%d vertex-hash ranges, one per GPU, no data-path exchange (DESIGN.md section 5.1)" % world,
+                             "kernel_ms_rank0": second["kms"], "result": second["result"]}
+        if cpu_baseline is not None and recs is not None:
+            out["cpu_baseline"] = cpu_baseline(recs, p)
         print(json.dumps(out), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
