@@ -138,9 +138,19 @@ def main():
         # threads > 1 only for the big cases: the bytes and counters of a single-round run do not depend on the thread count
         log, _ = O.run_reference(files, k, L, q=q, rounds=rounds, threads=threads, seed=SEED, out=out, tmpdir=tmp, debug=debug,
                                  abundance=abundance, timeout=6 * 3600)
-        data = open(out, "rb").read()
+        if keep_bin:
+            data = open(out, "rb").read()
+            digest, nbytes = hashlib.sha256(data).hexdigest(), len(data)
+        else:  # the big cases: gigabytes of output, hashed as a stream
+            h, nbytes = hashlib.sha256(), 0
+            with open(out, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+                    nbytes += len(blk)
+            digest, data = h.hexdigest(), None
+            os.remove(out)
         c = {"name": name, "fasta": fasta, "k": k, "L": L, "q": q, "n_rounds": rounds, "seed": SEED, "ref_debug_build": debug, "ref_threads": threads,
-             "abundance": abundance, "bin_sha256": hashlib.sha256(data).hexdigest(), "bin_bytes": len(data)}
+             "abundance": abundance, "bin_sha256": digest, "bin_bytes": nbytes}
         if synth_spec:
             c["synth"] = synth_spec
         c.update(parse_log(log))
@@ -149,7 +159,7 @@ def main():
                 f.write(data)
             c["bin"] = name + ".bin"
         cases.append(c)
-        print(name, len(data), c["distinct"], [r.get("false") for r in c["rounds"]])
+        print(name, nbytes, c["distinct"], [r.get("false") for r in c["rounds"]])
 
     case("example_k11", "example.fa", 11, 20)
     case("example_k15_r3", "example.fa", 15, 20, rounds=3)
@@ -189,7 +199,9 @@ def main():
     # m2_full = the bench workload (BASELINE configs[2]); m2_s05_f38 = the f = 38 geometry (512 bins per level) on a text the
     # reference finishes in minutes; m3_f38 = configs[3]'s shape (7 genomes, 1.12 Gbp of text, 32 GiB filter, several query batches)
     for name, wl, scale, L, thr in [("m1_small", "m1", 0.02, 26, 1), ("m1_full", "m1", 1.0, None, 1), ("m2_small", "m2", 0.004, 26, 1),
-                                    ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m3_f38", "m3", 1.0, None, 4)]:
+                                    ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m3_f38", "m3", 1.0, None, 4),
+                                    # m2_x15 = the bench workload with 15 x longer genomes: 4.65 G text positions, beyond 2^32 (hours of reference time)
+                                    ("m2_x15", "m2", 15.0, None, 6)]:
         if only is not None and name not in only:
             continue
 

@@ -511,6 +511,51 @@ def test_cli_binary_writes_reference_bytes(tmp_path):
     assert "Splitting the input kmers set..." in r.stdout and r.stdout.count("Round ") == case["n_rounds"]
 
 
+def test_cli_filter_checkpoint_roundtrip(tmp_path):
+    """--save-filter writes the Bloom filter of every round after its first-pass insert, --load-filter runs without the insert
+    (the reference's commented-out ReloadBloomFilter, vertexenumerator.h:29,113-121): the reloaded run writes the golden bytes,
+    with the hash tables taken from the checkpoint (no --seed given), and a checkpoint of other parameters is refused."""
+    import subprocess
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp_r4"][0]
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    fa = os.path.join(GOLDEN, case["fasta"])
+    ck = str(tmp_path / "bloom.ckpt")
+    base = [exe, "-k", str(case["k"]), "-f", str(case["L"]), "-q", str(case["q"]), "-r", str(case["n_rounds"]), "-t", "2", "--tmpdir", str(tmp_path)]
+    out1, out2 = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    r = subprocess.run(base + ["--seed", str(case["seed"]), "--save-filter", ck, "-o", out1, fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    golden = open(os.path.join(GOLDEN, case["bin"]), "rb").read()
+    assert open(out1, "rb").read() == golden
+    for rnd in range(case["n_rounds"]):
+        name = ck if rnd == 0 else "%s.%d" % (ck, rnd)
+        assert os.path.getsize(name) > ((1 << case["L"]) >> 3)
+    r2 = subprocess.run(base + ["--load-filter", ck, "-o", out2, fa], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert open(out2, "rb").read() == golden
+    counters = lambda text: [ln for ln in text.splitlines() if "count" in ln or ln.startswith("Round ") or "Hash table" in ln]
+    assert counters(r2.stdout) == counters(r.stdout)
+    r3 = subprocess.run([exe, "-k", str(case["k"] + 2), "-f", str(case["L"]), "-q", str(case["q"]), "-r", str(case["n_rounds"]), "--load-filter", ck,
+                         "-o", out2, "--tmpdir", str(tmp_path), fa], capture_output=True, text=True)
+    assert r3.returncode == 1 and "other parameters" in r3.stderr
+
+
+def test_cli_selftest_is_reproducible_with_seed(tmp_path):
+    """`twopaco --test --seed S`: the trials (sequences and hash tables) are a function of S, and a failing trial names the
+    seed that replays it (the reference draws from std::random_device, test.cpp:169)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    env = dict(os.environ, TWOPACO_SELFTEST_TRIALS="1")
+    fa = os.path.join(GOLDEN, "example.fa")
+    runs = []
+    for _ in range(2):
+        d = tmp_path / ("t%d" % len(runs))
+        d.mkdir()
+        r = subprocess.run([exe, "-f", "20", "--test", "--seed", "12345", "--tmpdir", str(d), fa], capture_output=True, text=True, env=dict(env, TWOPACO_SELFTEST_KEEP="1"))
+        assert r.returncode == 0 and "Test # 0 PASSED" in r.stderr, r.stderr[-500:]
+        runs.append(r.stderr)
+    assert runs[0] == runs[1]
+
+
 def test_cli_pipeline_twopaco_then_graphdump(tmp_path):
     """The two tools chained as users chain them: twopaco (unpinned seed, 62-genome-like synthetic input over
     several files) then graphdump -f gfa1; every path spells its input sequence back through the segments."""

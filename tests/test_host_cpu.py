@@ -135,6 +135,15 @@ def test_cli_flags_and_errors(built):
         r = subprocess.run([exe, "-k", "11", "-f", "20", fa], capture_output=True, text=True)
         assert r.returncode == 1 and "GPU" in r.stderr  # fails loudly, no CPU path
         assert "Vertex length = 11" in r.stdout
+    # --filtermemory GB -> filter bits = log2(GB * 8e9) truncated (reference constructor.cpp:158): the header is logged before any device work
+    for gb, bits in (("1.0", 32), ("0.5", 31), ("4", 34), ("0.002", 23), ("34.4", 38)):
+        r = subprocess.run([exe, "-k", "11", "--filtermemory", gb, fa], capture_output=True, text=True)
+        assert "Filter size = %d\n" % (1 << bits) in r.stdout, (gb, r.stdout[:300])
+    # the checkpoint flags parse (and need their value)
+    r = subprocess.run([exe, "-k", "11", "-f", "20", "--save-filter"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Missing a value" in r.stderr
+    r = subprocess.run([exe, "-k", "11", "-f", "20", "--load-filter", "/nonexistent/filter.bin", fa], capture_output=True, text=True)
+    assert r.returncode == 1 and "Can't open the Bloom filter checkpoint" in r.stderr
 
 
 def test_junction_api_header_roundtrip(built, tmp_path):
