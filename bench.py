@@ -108,26 +108,38 @@ def e2e_cli(files, p, golden, runs, tmp):
     file closed), FASTA files in the page cache, output sha256 checked against the reference golden."""
     exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
     threads = str(min(64, os.cpu_count() or 1))
-    walls, occ, sha_ok = [], None, None
+    walls, occ, sha_ok, phases = [], None, None, []
+    env = dict(os.environ, TWOPACO_TIMING="1")  # the CLI's own phase timers on stderr ([timing] lines, milliseconds)
     for rep in range(runs):
         out = os.path.join(tmp, "e2e_%d.bin" % rep)  # a fresh file each time
         cmd = [exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", str(GOLDEN_SEED), "--tmpdir", tmp, "-o", out] + files
         t0 = time.perf_counter()
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.perf_counter() - t0
         if res.returncode != 0:
             return {"error": res.stderr.decode()[-400:]}
         walls.append(wall)
+        phases.append((wall, {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[timing\]\s+(.*): ([0-9.eE+-]+) ms", res.stderr.decode())}))
         occ = int(re.search(r"True marks count: (\d+)", res.stdout.decode()).group(1))
         if rep == 0 and golden:
             sha_ok = sha256_file(out) == golden["bin_sha256"] and occ == golden["true_marks"]
             if not sha_ok:
                 return {"error": "e2e output differs from the reference golden %s" % golden["name"]}
         os.unlink(out)
-        time.sleep(1.0)  # the driver releases the previous process's device memory asynchronously
+        time.sleep(2.5)  # the driver releases the previous process's device memory asynchronously (a run right behind another one takes seconds)
     walls.sort()
     med = walls[len(walls) // 2]
-    return {"e2e_wall_s": med, "e2e_wall_s_min": walls[0], "e2e_wall_s_all": walls, "e2e_junction_occurrences_per_sec": occ / med,
+    ph = sorted(phases, key=lambda x: x[0])[len(phases) // 2][1]  # the median run's own timers
+    breakdown = {"exec_to_main_ms": ph.get("exec -> main"), "parse_pack_fasta_ms": ph.get("parse + pack FASTA"),
+                 "hip_startup_context_ms_parallel_thread": ph.get("setup thread: HIP start-up + context"),
+                 "filter_allocation_ms_parallel_thread": ph.get("setup thread: parameters + filter allocation"),
+                 "code_objects_ms_parallel_thread": ph.get("warm-up thread: code objects"),
+                 "partition_buffers_ms_parallel_thread": ph.get("setup thread: partition buffers"),
+                 "context_upload_ms": ph.get("context + upload"), "rounds_ms": ph.get("rounds (insert, query, exact filter)"),
+                 "insert_ms": ph.get("round: insert"), "query_ms": ph.get("round: query"), "exact_filter_ms": ph.get("round: exact filter"),
+                 "sort_ids_stream_ms": ph.get("sort + id lookup + junction stream"), "write_ms": ph.get("write junction stream"),
+                 "exec_to_output_complete_ms": ph.get("exec -> output complete"), "exec_to_context_destroyed_ms": ph.get("exec -> context destroyed")}
+    return {"e2e_wall_s": med, "breakdown_ms": breakdown, "e2e_wall_s_min": walls[0], "e2e_wall_s_all": walls, "e2e_junction_occurrences_per_sec": occ / med,
             "junction_occurrences": occ, "runs": runs, "host_threads": int(threads),
             "output_sha256_equals_reference": sha_ok,
             "what": "twopaco CLI child process, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (len(files), runs)}

@@ -67,6 +67,11 @@ const char *tpc_last_error(const tpc_ctx *ctx);
  * at the first real launch.  Touches no context state, so a one-shot caller can run it on a second host thread
  * while it uploads the text. */
 int tpc_warmup(tpc_ctx *ctx);
+/* Optional: allocate the partition buffers of the first pass now, for a text of at most n_text_max positions (after
+ * tpc_set_params, before tpc_seq_upload), instead of inside the first tpc_pass1_insert.  A one-shot caller (the CLI) knows
+ * an upper bound of the text length from its input files' sizes and lets this run beside parsing: device allocations of
+ * tens of GiB take tens of milliseconds (the reference allocates its filter up front too, vertexenumerator.h:258-259). */
+int tpc_reserve(tpc_ctx *ctx, uint64_t n_text_max);
 
 /* Hash parameters: vertex length k, filter bits L (filter has 2^L bits), q functions and
  * their character tables seed_table[q][5] (A,C,G,T,N) -- the only entries of

@@ -637,6 +637,51 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     return 0;
 }
 
+int tpc_reserve(tpc_ctx *c, uint64_t n_text_max)
+{
+    if (!c || !c->have_params) return fail(c, -1, "set_params first");
+    if (c->sh_world > 1 || n_text_max < 2) return 0;  // sharded contexts size their buffers in tpc_shard_plan
+    HIPCHK(c, hipSetDevice(c->device));
+    // the same planning as an ungated tpc_pass1_insert / tpc_pass1_query of a text of n_text_max positions
+    const uint64_t keep = c->n_text;
+    c->n_text = n_text_max;
+    const uint64_t tiles = text_tiles512(c);
+    size_t need[tpc_ctx::NPBUF] = {};
+    TpcPartPlan pl;
+    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && !(c->P.q > 8 && c->P.L - c->opt_slice_bits > 24);
+    if (part) {
+        const int64_t budget = part_budget(c);
+        for (uint64_t batches = 1;; batches *= 2) {
+            const uint64_t per = (tiles + batches - 1) / batches;
+            if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, 1.0, pl, c->opt_part_levels)) { part = false; break; }
+            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
+        }
+    }
+    if (part) {
+        const size_t ins[tpc_ctx::NPBUF] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                                             pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, tpc_part_buf3_bytes(pl), tpc_part_cnt3_bytes(pl), 0 };
+        for (int i = 0; i < tpc_ctx::NPBUF; i++) need[i] = ins[i];
+    }
+    TpcQPlan qpl;
+    const bool qpart = plan_query(c, 0, c->P.lmask + 1, false, qpl);
+    for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
+    c->n_text = keep;
+    for (int i = 0; i < tpc_ctx::NPBUF; i++)
+        if (need[i] && !ensure_pbuf(c, i, need[i])) return 0;  // not enough memory now: the passes decide again when they run
+    // the insert's level-2 regions kept aside while its apply is deferred into the query's lookup
+    if (part && qpart && c->opt_fuse && pl.b3 == 0 && qpl.b3 == 0) {
+        const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
+        for (int i = 0; i < 2; i++) {
+            if (want[i] <= c->ikeep_bytes[i]) continue;
+            if (c->ikeep[i]) (void)hipFree(c->ikeep[i]);
+            c->ikeep[i] = nullptr; c->ikeep_bytes[i] = 0;
+            if (hipMalloc(&c->ikeep[i], want[i]) != hipSuccess) { (void)hipGetLastError(); break; }
+            c->ikeep_bytes[i] = want[i];
+        }
+    }
+    return 0;
+}
+
 int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint32_t *bins_host)
 {
     if (!c || !c->have_params || !c->bases || !bins_host) return fail(c, -1, "bad arguments");

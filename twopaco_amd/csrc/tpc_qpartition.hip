@@ -240,7 +240,7 @@ __device__ __forceinline__ uint64_t q_spread2(uint32_t m)
     return x | (x << 1);
 }
 
-template <bool GATED, bool SHARDED>
+template <bool GATED, bool SHARDED, bool HALF>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
           const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round,
@@ -284,6 +284,7 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
 #pragma unroll
     for (int c = 0; c < 4; c++) { h0[c] = tab[c]; hk0[c] = tab[TPC_TAB_HK + c]; }
     const uint32_t ppr_mask = (uint32_t)pos_per_round - 1u;  // a power of two <= 16
+    constexpr bool half_rounds = HALF;                       // 512 bins: see the push below
     const uint32_t p0 = 32u + tid * (uint32_t)QH_RUN;        // my first position, relative to the first staged word (the one before the tile)
     for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
         __syncthreads();
@@ -339,11 +340,12 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
             if (GATED) check = check && within(tpc_min(pos, neg), lo, hi);  // VE.h:638
             const bool nadj = (cp | cn) >= 4u;
             if (check && nadj) word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
+            uint32_t eb[8];
+            uint64_t ev[8];
+            bool eok[8];
+            bool probing = false;
             if (check && !nadj) {
                 const uint32_t hi_s = sid0 + (uint32_t)(s << 2);  // (survivor id >> 1) without the edge: position << 2
-                uint32_t eb[8];
-                uint64_t ev[8];
-                bool eok[8];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     uint32_t rem;
@@ -356,7 +358,27 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
                     ev[4 + c] = ((uint64_t)(hi_s | (uint32_t)((4 + c) >> 1)) << 32) | (rem | ((uint32_t)(c & 1) << 31));
                     eok[4 + c] = (uint32_t)c != cn;
                 }
-                bins.template push_batch<8>(eb, ev, eok, lost);
+                if constexpr (!half_rounds) bins.template push_batch<8>(eb, ev, eok, lost);
+                else {  // 512 bins: a ring holds 32 entries, so the in-edges and the out-edges of a position go in two rounds
+                    uint32_t b4[4];
+                    uint64_t v4[4];
+                    bool o4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { b4[c] = eb[c]; v4[c] = ev[c]; o4[c] = eok[c]; }
+                    bins.template push_batch<4>(b4, v4, o4, lost);
+                }
+                probing = true;
+            }
+            if constexpr (half_rounds) {  // (uniform: every lane reaches both flushes of the position)
+                bins.template flush<false>(lost);
+                if (probing) {
+                    uint32_t b4[4];
+                    uint64_t v4[4];
+                    bool o4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { b4[c] = eb[4 + c]; v4[c] = ev[4 + c]; o4[c] = eok[4 + c]; }
+                    bins.template push_batch<4>(b4, v4, o4, lost);
+                }
             }
             if (s + 1 < QH_RUN) {  // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113), function 0
                 const uint4 en = reinterpret_cast<const uint4 *>(s_roll)[cn], ef = reinterpret_cast<const uint4 *>(s_roll)[5 + cf];
@@ -989,19 +1011,24 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     const bool rb = q_use_rbins(pl.b1);
-    // the instruction-lean kernel: flush-per-round bins, whole rounds, a 24-bit slice index
-    const bool lean = !rb && pl.sub_rounds == 1 && perm.F <= 24 && !getenv("TPC_NO_LEAN");
+    // the instruction-lean kernel: flush-per-round bins (two rounds per position at 512 bins), a 24-bit slice index
+    const bool lean = pl.b1 <= 9 && pl.sub_rounds <= 2 && perm.F <= 24 && !getenv("TPC_NO_LEAN") && !(rb && getenv("TPC_RB_HASH"));
     if (lean) {
         const size_t lds = Bins3<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + 160 + (size_t)QT_MAXK * 80 + 64;
-#define TPC_QHASH2_GO(G, S)                                                                                                                 \
+#define TPC_QHASH2_GO(G, S, H)                                                                                                              \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        hipLaunchKernelGGL((k_q_hash2<G, S>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text,  \
+        (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+        hipLaunchKernelGGL((k_q_hash2<G, S, H>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
                            pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
     } while (0)
-        if (pl.world > 1) { if (gated) TPC_QHASH2_GO(true, true); else TPC_QHASH2_GO(false, true); }
-        else { if (gated) TPC_QHASH2_GO(true, false); else TPC_QHASH2_GO(false, false); }
+#define TPC_QHASH2_GS(H)                                                                                                                    \
+    do {                                                                                                                                    \
+        if (pl.world > 1) { if (gated) TPC_QHASH2_GO(true, true, H); else TPC_QHASH2_GO(false, true, H); }                                  \
+        else { if (gated) TPC_QHASH2_GO(true, false, H); else TPC_QHASH2_GO(false, false, H); }                                             \
+    } while (0)
+        if (pl.b1 >= 9) TPC_QHASH2_GS(true); else TPC_QHASH2_GS(false);
+#undef TPC_QHASH2_GS
 #undef TPC_QHASH2_GO
         return;
     }

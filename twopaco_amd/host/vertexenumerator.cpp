@@ -7,6 +7,7 @@
 #include <cstring>
 #include <thread>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <iostream>
 #include <cstdlib>
@@ -227,6 +228,20 @@ namespace TwoPaCo
 
 						Check(tpc_set_params(ctx_, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 						setupTimer.Lap("  setup thread: parameters + filter allocation");
+						// the partition buffers of the first pass, sized for what the files can hold at most (a base per byte):
+						// allocated here, beside the parser, instead of inside the first round
+						if (!sharded && options.loadFilter.empty())
+						{
+							uint64_t bytes = 0;
+							for (const std::string & fn : fileName)
+							{
+								struct stat st;
+								if (::stat(fn.c_str(), &st) == 0) bytes += uint64_t(st.st_size) + 2;
+							}
+
+							if (bytes > 0) tpc_reserve(ctx_, bytes + 2);
+							setupTimer.Lap("  setup thread: partition buffers");
+						}
 					}
 					catch (std::exception & e)
 					{
@@ -525,9 +540,10 @@ namespace TwoPaCo
 						throw std::runtime_error("Can't create the output file");
 					}
 
-					const uint64_t CHUNK = uint64_t(8) << 20;
+					const uint64_t CHUNK = uint64_t(4) << 20;
 					const uint64_t chunks = (streamBytes + CHUNK - 1) / CHUNK;
-					const size_t workers = size_t(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, 8), chunks)));
+					const size_t workers = size_t(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, 16), chunks)));
+					if (streamBytes > 0) (void)::posix_fallocate(fd, 0, off_t(streamBytes));  // one extent up front instead of growing the file chunk by chunk
 					std::vector<int> failed(workers, 0);
 					std::vector<std::thread> pool;
 					for (size_t t = 0; t < workers; t++)
