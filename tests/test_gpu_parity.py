@@ -478,6 +478,31 @@ def test_config4_shape_m3_f38_bytes_equal_reference(capi, tmp_path):
     e.close()
 
 
+def test_beyond_2_32_positions_m2_x15_bytes_equal_reference(capi, tmp_path):
+    """More than 2^32 text positions against the real reference: the bench workload with 15 x longer genomes (62 x 75 Mbp =
+    4.65 G positions, k=25, f=36), through CreateEnumerator.  sha256 of the 7.9 GB de_bruijn.bin and every log counter
+    (VE.h:384-388, 413) equal what the reference binary produced (tests/golden/make_golden.py --only m2_x15, ~25 min at -t 6).
+    Sequence positions stay below 2^32 (junctionapi.h:33); text positions, mark lists, batch offsets do not."""
+    import shutil
+    import torch
+    case = [c for c in CASES if c["name"] == "m2_x15"][0]
+    free, _ = torch.cuda.mem_get_info()
+    if free < (120 << 30) or shutil.disk_usage(str(tmp_path)).free < (24 << 30):
+        pytest.skip("needs ~120 GB of free HBM and 24 GB of scratch disk")
+    out = str(tmp_path / "x15.bin")
+    files = case_files(case, tmp_path)
+    e = capi.Enumerator(files, case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out, seed=case["seed"], threads=64)
+    for f in files:
+        os.unlink(f)
+    assert os.path.getsize(out) == case["bin_bytes"]
+    log = parse_log(e.log)
+    assert log["rounds"] == case["rounds"] and log["true_marks"] == case["true_marks"]
+    assert e.vertices_count() == case["distinct"]
+    assert sha256_file(out) == case["bin_sha256"]
+    os.unlink(out)
+    e.close()
+
+
 def test_naive_positions_seed_free(capi, tmp_path):
     """Random seeds (like the reference's own --test, test.cpp:163-254): positions == naive oracle."""
     fa = os.path.join(GOLDEN, "rand6.fa")

@@ -797,11 +797,20 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
     const uint64_t *my = surv + (uint64_t)list * surv_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t wmask = (1ull << (2 * k)) - 1ull;  // k <= 31
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-        const uint64_t sid = my[idx];
+    // software pipeline: the survivor id and the text word of the NEXT survivor are loaded before this one is hashed (the
+    // kernel waits for scattered accesses, not for arithmetic: twice the loads in flight per lane)
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t sid_n = idx < n ? my[idx] : 0;
+    uint64_t w_n = idx < n ? tpc_text_word(bases, gbase + (sid_n >> 3)) : 0;
+    for (; idx < n; idx += stride) {
+        const uint64_t sid = sid_n;
+        const uint64_t w = w_n & wmask;
+        if (idx + stride < n) {
+            sid_n = my[idx + stride];
+            w_n = tpc_text_word(bases, gbase + (sid_n >> 3));
+        }
         const int e = (int)(sid & 7), c = e & 3;
         const uint64_t g = gbase + (sid >> 3);
-        const uint64_t w = tpc_text_word(bases, g) & wmask;
         // the edge's k + 1 letters, first letter in the low bits: in-edge c + v, out-edge v + c
         uint64_t E = e < 4 ? ((w << 2) | (uint64_t)c) : (w | ((uint64_t)c << (2 * k)));
         uint64_t p[Q], nn[Q];
