@@ -188,6 +188,26 @@ int tpc_emit_import(tpc_ctx *ctx, const uint64_t *g_dev, const int64_t *id_dev, 
  * threads at once (each into its own buffer; pinned buffers from tpc_host_alloc copy fastest). */
 int tpc_emit_stream(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint64_t *n_bytes, uint64_t *n_records);
 int tpc_emit_stream_fetch(tpc_ctx *ctx, uint64_t offset, uint64_t nbytes, void *dst_host);
+
+/* The junction stream cut over the ranks of a multi-GPU run (each holds the marks and ids of its own chunk of the text after
+ * tpc_emit): every rank formats and writes its own byte range of the file, nobody gathers (position, id) lists.  The
+ * reference's ordered flush (FlushEdgeResults, VE.h:837-854; JunctionPositionWriter, junctionapi.h:118-126) becomes an
+ * exclusive scan over per-sequence counts.  Every slot of the stream belongs to a text position (a record to its k-mer, a
+ * stub to the end k-mer it stands for, the separator between sequences j and j + 1 to the character in front of j + 1), so
+ * the slots of a chunk [chunk_lo, chunk_hi) are contiguous in the file.
+ *   tpc_shard_chunk          this rank's chunk of text positions (the tiles it hashes; the last rank's end is UINT64_MAX)
+ *   tpc_emit_stream_partial  per sequence: cnt_host[r] = real-id records among THIS rank's marks, flags_host[r] bit 0 / 1 =
+ *                            this rank holds the first / last k-mer of the sequence with a real id
+ *   (the host adds the ranks up: gflags = OR of the flags | 4 for sequences of >= k bases; per sequence n = sum of cnt + stubs,
+ *    e_scan / s_scan = exclusive scans of n / stubs over the sequences (n_rec + 1 entries); before[r] = cnt of the ranks before
+ *    this one; r_last = last sequence of >= k bases; slot0 = slots of the ranks before this one)
+ *   tpc_emit_stream_part     formats this rank's n_slots slots (12 bytes each) into the stream buffer; fetch with
+ *                            tpc_emit_stream_fetch (offsets relative to the rank's first byte) */
+int tpc_shard_chunk(const tpc_ctx *ctx, uint64_t *chunk_lo, uint64_t *chunk_hi);
+int tpc_emit_stream_partial(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint64_t *cnt_host, uint32_t *flags_host);
+int tpc_emit_stream_part(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, const uint32_t *gflags_host,
+                         const uint64_t *e_scan_host, const uint64_t *s_scan_host, const uint64_t *before_host, uint32_t r_last,
+                         uint64_t chunk_lo, uint64_t chunk_hi, uint64_t slot0, uint64_t n_slots, uint64_t *n_bytes);
 int tpc_host_alloc(void **ptr, uint64_t bytes);
 void tpc_host_free(void *ptr);
 

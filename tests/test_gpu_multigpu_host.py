@@ -137,6 +137,21 @@ def test_emulated_ranks_replicated_second_pass(capi, tmp_path, name, ranks, monk
     e.close()
 
 
+@pytest.mark.parametrize("name,ranks", [("edge_k5", 4), ("m2_small", 4)])
+def test_emulated_ranks_gathered_output(capi, tmp_path, name, ranks, monkeypatch):
+    """TWOPACO_GATHER_OUTPUT: the (position, id) lists gathered on rank 0, which formats the whole stream -- the form the
+    default replaced (every rank formats and writes the byte range of its own chunk of the text, multigpu.h:ShardedStream,
+    covered by every other test of this file); same bytes."""
+    monkeypatch.setenv("TWOPACO_GATHER_OUTPUT", "1")
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    e.close()
+
+
 def test_cli_gpus_flag(tmp_path):
     case = CASES["rand6_k9_fp_r4"]
     exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")

@@ -3,7 +3,7 @@
 # HBM section: separate --pmc passes), then the plain bench line of the same build.  Any failing step fails the script.
 # Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 set -euo pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out

@@ -64,6 +64,10 @@ struct tpc_ctx {
     // junction stream (bytes of the output file)
     uint32_t *stream_buf = nullptr;
     uint64_t stream_cap = 0, stream_bytes = 0;
+    // per-rank formatting (tpc_emit_stream_partial -> tpc_emit_stream_part): kept between the two calls
+    uint64_t *sp_rec = nullptr, *sp_vscan = nullptr, *sp_cnt = nullptr, *sp_lo = nullptr;
+    uint32_t *sp_flags = nullptr;
+    uint32_t sp_n_rec = 0;
     // scalars
     unsigned long long *counters = nullptr;  // device, 8 words
     unsigned long long *route_scratch = nullptr;  // device, 128 words: tpc_shard_route's per-owner counts and cursors
@@ -179,6 +183,7 @@ int read_counter(tpc_ctx *c, int i, uint64_t *out)
 
 int flush_pending_apply(tpc_ctx *c);
 bool ensure_pbuf(tpc_ctx *c, int i, size_t need);
+void stream_part_release(tpc_ctx *c);
 
 int materialize_reset(tpc_ctx *c)
 {   // a pending tpc_filter_reset becomes a real zero fill before anything reads the filter
@@ -321,6 +326,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     void *ptrs[] = { c->tab, c->bases_alloc, c->nmask_alloc, c->filter, c->rmask, c->mask, c->marks, c->block_sums, c->table,
                      c->keys, c->idtab, c->emit_id, c->stream_buf, c->counters, c->route_scratch, c->sh_off, c->scan_blocks, c->sort_scratch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    stream_part_release(c);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
     if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
@@ -1204,6 +1210,88 @@ int tpc_emit_stream(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_l
     HIPCHK(c, hipGetLastError());
     if (n_bytes) *n_bytes = c->stream_bytes;
     if (n_records) *n_records = totals[0];
+    return 0;
+}
+
+namespace {
+void stream_part_release(tpc_ctx *c)
+{
+    for (void *p : { (void *)c->sp_rec, (void *)c->sp_vscan, (void *)c->sp_cnt, (void *)c->sp_lo, (void *)c->sp_flags }) if (p) (void)hipFree(p);
+    c->sp_rec = c->sp_vscan = c->sp_cnt = c->sp_lo = nullptr;
+    c->sp_flags = nullptr;
+    c->sp_n_rec = 0;
+}
+}  // namespace
+
+int tpc_shard_chunk(const tpc_ctx *c, uint64_t *chunk_lo, uint64_t *chunk_hi)
+{
+    if (!c || !chunk_lo || !chunk_hi || !c->n_text) return -1;
+    const uint64_t W = c->sh_world, tiles = text_tiles512(c), chunk = (tiles + W - 1) / W;  // the split of tpc_shard_hash
+    const uint64_t t0 = std::min<uint64_t>(tiles, (uint64_t)c->sh_rank * chunk), t1 = std::min<uint64_t>(tiles, t0 + chunk);
+    *chunk_lo = t0 * 512 * TPC_RUN;
+    *chunk_hi = c->sh_rank + 1 == W ? ~0ull : t1 * 512 * TPC_RUN;
+    return 0;
+}
+
+int tpc_emit_stream_partial(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, uint64_t *cnt_host, uint32_t *flags_host)
+{
+    if (!c || !c->finalized || !rec_start || !rec_len || !n_rec || !cnt_host || !flags_host) return fail(c, -1, "tpc_emit first; records required");
+    if (c->n_emit != c->n_marks || (c->n_marks && !c->emit_id)) return fail(c, -1, "tpc_emit first");
+    HIPCHK(c, hipSetDevice(c->device));
+    stream_part_release(c);
+    if (hipMalloc((void **)&c->sp_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&c->sp_vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&c->sp_cnt, (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&c->sp_lo, (size_t)n_rec * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&c->sp_flags, (size_t)n_rec * sizeof(uint32_t)) != hipSuccess) { stream_part_release(c); return fail(c, -10, "out of device memory for the junction stream"); }
+    c->sp_n_rec = n_rec;
+    HIPCHK(c, hipMemcpyAsync(c->sp_rec, rec_start, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sp_rec + n_rec, rec_len, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream));
+    int rc;
+    {
+        Timed t(c, TPC_K_STREAM);
+        rc = tpc_launch_stream_partial(c->stream, c->sp_rec, c->sp_rec + n_rec, n_rec, c->P.k, c->marks, c->emit_id, c->n_marks, c->sp_vscan, c->sp_cnt, c->sp_flags, c->sp_lo);
+    }
+    if (rc) return fail(c, rc, "junction stream failed (%d)", rc);
+    HIPCHK(c, hipMemcpy(cnt_host, c->sp_cnt, (size_t)n_rec * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(flags_host, c->sp_flags, (size_t)n_rec * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int tpc_emit_stream_part(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_len, uint32_t n_rec, const uint32_t *gflags_host,
+                         const uint64_t *e_scan_host, const uint64_t *s_scan_host, const uint64_t *before_host, uint32_t r_last,
+                         uint64_t chunk_lo, uint64_t chunk_hi, uint64_t slot0, uint64_t n_slots, uint64_t *n_bytes)
+{
+    (void)rec_start; (void)rec_len;
+    if (!c || !c->sp_rec || c->sp_n_rec != n_rec || !gflags_host || !e_scan_host || !s_scan_host || !before_host) return fail(c, -1, "tpc_emit_stream_partial first");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *d_e = nullptr, *d_s = nullptr, *d_b = nullptr;
+    uint32_t *d_f = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&d_e, ((size_t)n_rec + 1) * 8) != hipSuccess || hipMalloc((void **)&d_s, ((size_t)n_rec + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&d_b, (size_t)n_rec * 8) != hipSuccess || hipMalloc((void **)&d_f, (size_t)n_rec * 4) != hipSuccess) rc = -10;
+    const uint64_t bytes = n_slots * 12;
+    if (rc == 0 && bytes > c->stream_cap) {
+        if (c->stream_buf) (void)hipFree(c->stream_buf);
+        c->stream_buf = nullptr; c->stream_cap = 0;
+        if (hipMalloc((void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
+    }
+    if (rc == 0 && (hipMemcpyAsync(d_e, e_scan_host, ((size_t)n_rec + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_s, s_scan_host, ((size_t)n_rec + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_b, before_host, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_f, gflags_host, (size_t)n_rec * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)) rc = -10;
+    if (rc == 0 && bytes) {
+        Timed t(c, TPC_K_STREAM);
+        rc = tpc_launch_stream_write_part(c->stream, c->sp_rec, c->sp_rec + n_rec, n_rec, c->P.k, c->marks, c->emit_id, c->n_marks, c->sp_vscan, c->sp_lo, d_f, d_e, d_s, d_b,
+                                          r_last, c->n_keys + 42, chunk_lo, chunk_hi, slot0, c->stream_buf);
+    }
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    for (void *p : { (void *)d_e, (void *)d_s, (void *)d_b, (void *)d_f }) if (p) (void)hipFree(p);
+    stream_part_release(c);
+    if (rc) return fail(c, rc, "junction stream failed (%d)", rc);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    c->stream_bytes = bytes;
+    if (n_bytes) *n_bytes = bytes;
     return 0;
 }
 

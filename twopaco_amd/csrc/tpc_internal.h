@@ -177,6 +177,14 @@ int tpc_launch_stream_plan(hipStream_t s, const uint64_t *d_rec_start, const uin
 int tpc_launch_stream_write(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
                             const int64_t *ids, uint64_t n_marks, const uint64_t *vscan, const void *rec, uint32_t r_last, uint64_t first_stub, uint32_t *out);
 
+// the stream cut over several ranks by text position (tpc_stream.hip)
+int tpc_launch_stream_partial(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
+                              const int64_t *ids, uint64_t n_marks, uint64_t *vscan, uint64_t *cnt, uint32_t *flags, uint64_t *mark_lo);
+int tpc_launch_stream_write_part(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, const uint64_t *marks,
+                                 const int64_t *ids, uint64_t n_marks, const uint64_t *vscan, const uint64_t *mark_lo, const uint32_t *gflags,
+                                 const uint64_t *e_scan, const uint64_t *s_scan, const uint64_t *before, uint32_t r_last, uint64_t first_stub,
+                                 uint64_t chunk_lo, uint64_t chunk_hi, uint64_t slot0, uint32_t *out);
+
 // code-object warm-up (one trivial launch per translation unit), used by tpc_warmup
 void tpc_warm_pass1(hipStream_t s);
 void tpc_warm_partition(hipStream_t s);

@@ -79,6 +79,16 @@ namespace TwoPaCo
 		}
 	}
 
+	void Transport::GatherHost(int rank, const std::vector<uint64_t> & mine, std::vector<std::vector<uint64_t> > & all)
+	{
+		barrier_.Wait();  // the previous gather has been read by everyone
+		if (rank == 0) gather_.resize(size_t(ranks_));
+		barrier_.Wait();
+		gather_[size_t(rank)] = mine;
+		barrier_.Wait();
+		all = gather_;
+	}
+
 	// ------------------------------------------------------------------------------------------ loopback transport
 	namespace
 	{
@@ -532,7 +542,7 @@ namespace TwoPaCo
 		counters[0] = truePositives; counters[1] = falsePositives; counters[2] = tableSize; counters[3] = n;
 	}
 
-	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions)
+	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions, bool gatherOnRankZero)
 	{
 		const int W = net.Ranks();
 		const size_t keyBytes = size_t(tpc_key_words(r.ctx)) * 8;
@@ -556,6 +566,7 @@ namespace TwoPaCo
 		// ---- ids of this rank's positions, then every list to rank 0 (rank order = position order)
 		uint64_t marked = 0, valid = 0;
 		LibCheck(r.ctx, tpc_emit(r.ctx, &marked, &valid), "emit");
+		if (!gatherOnRankZero) return;  // every rank formats its own part of the stream (ShardedStream)
 		uint64_t * g = static_cast<uint64_t*>(r.Ensure(REC, std::max<uint64_t>(marked, 1) * 8));
 		int64_t * id = static_cast<int64_t*>(r.Ensure(REC2, std::max<uint64_t>(marked, 1) * 8));
 		LibCheck(r.ctx, tpc_emit_export(r.ctx, g, id), "emit_export");
@@ -577,5 +588,78 @@ namespace TwoPaCo
 		net.AllToAllV(r.rank, g, sendCounts.data(), gAll, recvCounts.data(), 8);
 		net.AllToAllV(r.rank, id, sendCounts.data(), idAll, recvCounts.data(), 8);
 		if (r.rank == 0) LibCheck(r.ctx, tpc_emit_import(r.ctx, gAll, idAll, total), "emit_import");
+	}
+
+	void ShardedStream(ShardedRank & r, Transport & net, const std::vector<uint64_t> & recStart, const std::vector<uint64_t> & recLength, size_t k,
+		uint64_t * firstByte, uint64_t * nBytes, uint64_t * records)
+	{
+		const int W = net.Ranks();
+		const size_t n = recStart.size();
+		uint64_t lo = 0, hi = 0;
+		if (tpc_shard_chunk(r.ctx, &lo, &hi) != 0) throw std::runtime_error("shard_chunk failed");
+		// what this rank's marks say about every sequence
+		std::vector<uint64_t> mine(2 * n);
+		std::vector<uint32_t> flags(n);
+		LibCheck(r.ctx, tpc_emit_stream_partial(r.ctx, recStart.data(), recLength.data(), uint32_t(n), mine.data(), flags.data()), "emit_stream_partial");
+		for (size_t s = 0; s < n; s++) mine[n + s] = flags[s];
+		std::vector<std::vector<uint64_t> > all;
+		net.GatherHost(r.rank, mine, all);
+		// the whole stream's layout, the same on every rank (tpc_stream.hip: slot arithmetic)
+		std::vector<uint32_t> gflags(n, 0);
+		std::vector<uint64_t> eScan(n + 1, 0), sScan(n + 1, 0), before(n, 0);
+		uint32_t rLast = 0;
+		for (size_t s = 0; s < n; s++)
+		{
+			if (recLength[s] < k) { eScan[s + 1] = eScan[s]; sScan[s + 1] = sScan[s]; continue; }
+			rLast = uint32_t(s);
+			uint64_t total = 0;
+			uint32_t f = 4u;
+			for (int q = 0; q < W; q++)
+			{
+				if (q < r.rank) before[s] += all[size_t(q)][s];
+				total += all[size_t(q)][s];
+				f |= uint32_t(all[size_t(q)][n + s]);
+			}
+
+			const uint64_t stubs = ((f & 1u) ? 0u : 1u) + ((recLength[s] != k && !(f & 2u)) ? 1u : 0u);
+			gflags[s] = f;
+			eScan[s + 1] = eScan[s] + total + stubs;
+			sScan[s + 1] = sScan[s] + stubs;
+		}
+
+		// my slots: my real-id records, the stubs and the separators that belong to positions of my chunk
+		uint64_t slots = 0;
+		for (size_t s = 0; s < n; s++)
+		{
+			slots += all[size_t(r.rank)][s];
+			if (s < rLast)
+			{
+				const uint64_t at = recStart[s + 1] - 1;
+				if (at >= lo && at < hi) ++slots;
+			}
+
+			if (!(gflags[s] & 4u)) continue;
+			const uint64_t first = recStart[s], last = first + recLength[s] - k;
+			if (!(gflags[s] & 1u) && first >= lo && first < hi) ++slots;
+			if (recLength[s] != k && !(gflags[s] & 2u) && last >= lo && last < hi) ++slots;
+		}
+
+		std::vector<uint64_t> allSlots;
+		net.ExchangeHost(r.rank, &slots, 1, allSlots);
+		uint64_t slot0 = 0, totalSlots = 0;
+		for (int q = 0; q < W; q++)
+		{
+			if (q < r.rank) slot0 += allSlots[size_t(q)];
+			totalSlots += allSlots[size_t(q)];
+		}
+
+		const uint64_t allRecords = eScan[n];
+		if (totalSlots != allRecords + (allRecords ? rLast : 0)) throw std::runtime_error("junction stream: the ranks' slots do not add up");
+		uint64_t bytes = 0;
+		LibCheck(r.ctx, tpc_emit_stream_part(r.ctx, recStart.data(), recLength.data(), uint32_t(n), gflags.data(), eScan.data(), sScan.data(), before.data(), rLast,
+			lo, hi, slot0, allRecords ? slots : 0, &bytes), "emit_stream_part");
+		*firstByte = slot0 * 12;
+		*nBytes = bytes;
+		*records = allRecords;
 	}
 }

@@ -57,12 +57,15 @@ namespace TwoPaCo
 		virtual const char * Name() const = 0;
 		// n host values per rank -> all[r * n + i] on every rank (n <= 64)
 		void ExchangeHost(int rank, const uint64_t * mine, int n, std::vector<uint64_t> & all);
+		// any number of host values per rank (the same number on every rank) -> all[r] = rank r's values, on every rank
+		void GatherHost(int rank, const std::vector<uint64_t> & mine, std::vector<std::vector<uint64_t> > & all);
 		RankBarrier & Barrier() { return barrier_; }
 		uint64_t BytesMoved() const { return bytesMoved_; }
 	protected:
 		int ranks_;
 		RankBarrier barrier_;
 		std::vector<uint64_t> scratch_;
+		std::vector<std::vector<uint64_t> > gather_;
 		uint64_t bytesMoved_ = 0;  // by rank 0
 	};
 
@@ -103,7 +106,16 @@ namespace TwoPaCo
 	// After the last round: every rank learns all junction keys (all-gather), sorts them (tpc_junctions_finalize: the same ids
 	// everywhere), looks up the ids of its own marked positions, and the (position, id) lists are gathered on rank 0 in rank
 	// order = position order, where they replace rank 0's list (tpc_emit_import) for the output stream.
-	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions);
+	// gatherOnRankZero = false: the lists stay where they are (ShardedStream formats them rank by rank).
+	void ShardedFinish(ShardedRank & r, Transport & net, uint64_t * junctions, bool gatherOnRankZero = true);
+
+	// The junction stream formatted by every rank for its own chunk of the text (EdgeConstructionWorker's ordered flush,
+	// reference vertexenumerator.h:837-854, and JunctionPositionWriter, junctionapi.h:118-126, as an exclusive scan over
+	// per-sequence counts; include/twopaco_hip.h: tpc_emit_stream_partial / _part).  Afterwards the rank's context holds
+	// bytes [firstByte, firstByte + nBytes) of the output file (tpc_emit_stream_fetch); records = junction occurrences +
+	// stubs of the whole run (the reference's "True marks count").
+	void ShardedStream(ShardedRank & r, Transport & net, const std::vector<uint64_t> & recStart, const std::vector<uint64_t> & recLength, size_t k,
+		uint64_t * firstByte, uint64_t * nBytes, uint64_t * records);
 }
 
 #endif

@@ -488,9 +488,12 @@ namespace TwoPaCo
 				timer.Lap("rounds (insert, query, exact filter)");
 				mark = time(0);
 				uint64_t junctions = 0;
+				// several GPUs with the second pass sharded: every rank formats and writes its own byte range of the output
+				const bool perRankOutput = net && shardedPass2 && std::getenv("TWOPACO_GATHER_OUTPUT") == 0;
 				if (net && shardedPass2)
 				{
-					// key union, key sort, id lookup of every rank's own positions, (position, id) lists gathered on rank 0
+					// key union, key sort, id lookup of every rank's own positions; the (position, id) lists stay on their ranks
+					// (TWOPACO_GATHER_OUTPUT=1: gathered on rank 0, which then formats the whole stream)
 					std::vector<std::string> errors(gpus);
 					std::vector<uint64_t> perRank(gpus, 0);
 					std::vector<std::thread> pool;
@@ -500,7 +503,7 @@ namespace TwoPaCo
 						{
 							try
 							{
-								ShardedFinish(peers_[r], *net, &perRank[r]);
+								ShardedFinish(peers_[r], *net, &perRank[r], !perRankOutput);
 							}
 							catch (std::exception & e)
 							{
@@ -531,7 +534,46 @@ namespace TwoPaCo
 					throw std::runtime_error("Too many sequences");
 				}
 
-				if (!nothing) Check(tpc_emit_stream(ctx_, text.recStart.data(), text.recLength.data(), uint32_t(text.recStart.size()), &streamBytes, &occurence), "emit_stream");
+				struct Piece { tpc_ctx * ctx; uint64_t fileOffset, bytes; };
+				std::vector<Piece> pieces;
+				if (perRankOutput && !nothing)
+				{
+					// FlushEdgeResults' piece order (vertexenumerator.h:841-849) as an exclusive scan over the ranks: rank r learns
+					// the slots in front of its chunk and formats its own bytes (multigpu.h: ShardedStream)
+					std::vector<std::string> errors(gpus);
+					std::vector<uint64_t> first(gpus, 0), nb(gpus, 0), rec(gpus, 0);
+					std::vector<std::thread> pool;
+					for (int r = 0; r < gpus; r++)
+					{
+						pool.emplace_back([&, r]()
+						{
+							try
+							{
+								ShardedStream(peers_[r], *net, text.recStart, text.recLength, vertexLength, &first[r], &nb[r], &rec[r]);
+							}
+							catch (std::exception & e)
+							{
+								errors[r] = e.what();
+								net->Barrier().Fail(e.what());
+							}
+						});
+					}
+
+					for (std::thread & th : pool) th.join();
+					for (const std::string & e : errors) if (!e.empty()) throw std::runtime_error(e);
+					occurence = rec[0];
+					for (int r = 0; r < gpus; r++)
+					{
+						if (nb[r]) pieces.push_back(Piece{ peers_[r].ctx, first[r], nb[r] });
+						streamBytes += nb[r];
+					}
+				}
+				else if (!nothing)
+				{
+					Check(tpc_emit_stream(ctx_, text.recStart.data(), text.recLength.data(), uint32_t(text.recStart.size()), &streamBytes, &occurence), "emit_stream");
+					if (streamBytes) pieces.push_back(Piece{ ctx_, 0, streamBytes });
+				}
+
 				timer.Lap("sort + id lookup + junction stream");
 				{
 					const int fd = ::open(outFileName.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -541,8 +583,14 @@ namespace TwoPaCo
 					}
 
 					const uint64_t CHUNK = uint64_t(4) << 20;
-					const uint64_t chunks = (streamBytes + CHUNK - 1) / CHUNK;
-					const size_t workers = size_t(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, 16), chunks)));
+					struct Task { size_t piece; uint64_t offset, bytes; };
+					std::vector<Task> tasks;
+					for (size_t p = 0; p < pieces.size(); p++)
+					{
+						for (uint64_t off = 0; off < pieces[p].bytes; off += CHUNK) tasks.push_back(Task{ p, off, std::min(CHUNK, pieces[p].bytes - off) });
+					}
+
+					const size_t workers = size_t(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(threads, 16), tasks.size())));
 					if (streamBytes > 0) (void)::posix_fallocate(fd, 0, off_t(streamBytes));  // one extent up front instead of growing the file chunk by chunk
 					std::vector<int> failed(workers, 0);
 					std::vector<std::thread> pool;
@@ -563,16 +611,17 @@ namespace TwoPaCo
 								buf = pageable.data();
 							}
 
-							for (uint64_t c = t; c < chunks && !failed[t]; c += workers)
+							for (size_t c = t; c < tasks.size() && !failed[t]; c += workers)
 							{
-								const uint64_t off = c * CHUNK;
-								const uint64_t n = std::min(CHUNK, streamBytes - off);
-								if (tpc_emit_stream_fetch(ctx_, off, n, buf) != 0)
+								const Piece & piece = pieces[tasks[c].piece];
+								const uint64_t n = tasks[c].bytes;
+								if (tpc_emit_stream_fetch(piece.ctx, tasks[c].offset, n, buf) != 0)
 								{
 									failed[t] = 1;
 									break;
 								}
 
+								const uint64_t off = piece.fileOffset + tasks[c].offset;
 								for (uint64_t done = 0; done < n;)
 								{
 									const ssize_t w = ::pwrite(fd, buf + done, size_t(n - done), off_t(off + done));
