@@ -32,7 +32,7 @@ def _check(case, e, out):
 
 
 @pytest.mark.parametrize("name,ranks", [("rand6_k9_fp", 2), ("rand6_k9_L33", 4), ("c2_k51_r2", 2), ("edge_k5", 2), ("rand6_k25_q3", 8),
-                                        ("rand6_k9_a3", 4), ("c2_k125", 2), ("m1_small", 4), ("m2_small", 8)])
+                                        ("rand6_k9_a3", 4), ("c2_k125", 2), ("m1_small", 4), ("m2_small", 8), ("rand6_k9_q12", 2)])
 def test_emulated_ranks_write_reference_bytes(capi, tmp_path, name, ranks):
     case = CASES[name]
     out = str(tmp_path / "mg.bin")
@@ -148,6 +148,17 @@ def test_emulated_ranks_gathered_output(capi, tmp_path, name, ranks, monkeypatch
     e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
                         abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
                         seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    e.close()
+
+
+def test_saturated_filter_falls_back_to_one_gpu(capi, tmp_path):
+    """A saturated filter (every first probe survives) overflows the survivor lists of the sharded pass, which has no
+    scattered-kernel fallback: the run is repeated on one GPU and still writes the reference's bytes."""
+    case = CASES["rand6_k9_fp"]  # f = 14 on 18 kbp: the filter is full
+    out = str(tmp_path / "sat.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], tmpdir=str(tmp_path), out=out, seed=case["seed"],
+                        gpus=2, emulate_ranks=True)
     _check(case, e, out)
     e.close()
 

@@ -727,7 +727,24 @@ namespace TwoPaCo
 	{
 		(void)tmpFileName;  // candidate masks and junction keys stay in HBM: no scratch files
 		std::unique_ptr<HipVertexEnumerator> ret(new HipVertexEnumerator());
-		ret->Run(fileName, vertexLength, filterSize, hashFunctions, rounds, threads, abundance, outFileName, logStream, options);
+		try
+		{
+			ret->Run(fileName, vertexLength, filterSize, hashFunctions, rounds, threads, abundance, outFileName, logStream, options);
+		}
+		catch (std::runtime_error & e)
+		{
+			// A filter cut over several GPUs has no scattered-kernel fallback: address skew beyond its overflow lists (a saturated
+			// or tiny filter, a poly-A genome) ends the sharded pass.  The single-GPU path handles any input (its partitioned
+			// passes fall back to the direct kernels), so the run is repeated there instead of failing.
+			if ((options.gpus <= 1 && !options.forceSharded) || std::string(e.what()).find("the sharded path handles") == std::string::npos) throw;
+			logStream << "Address skew beyond what the sharded filter handles (" << e.what() << "): repeating the run on one GPU" << std::endl;
+			ret.reset(new HipVertexEnumerator());
+			EnumeratorOptions single(options);
+			single.gpus = 1;
+			single.forceSharded = false;
+			ret->Run(fileName, vertexLength, filterSize, hashFunctions, rounds, threads, abundance, outFileName, logStream, single);
+		}
+
 		return std::unique_ptr<VertexEnumerator>(ret.release());
 	}
 
