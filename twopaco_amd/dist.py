@@ -724,6 +724,11 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
                              "kernel_ms_rank0": second["kms"], "result": second["result"]}
         if cpu_baseline is not None and recs is not None:
             out["cpu_baseline"] = cpu_baseline(recs, p)
+        try:  # librccl prints a version banner through C stdio, which would otherwise land behind the JSON line when the process ends
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
