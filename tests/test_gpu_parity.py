@@ -852,6 +852,38 @@ def test_config5_shape_k51_f40_r4_vs_oracle(capi, tmp_path):
     o.close()
 
 
+def test_config5_shape_exact_k39_f40_r4_vs_oracle(capi, tmp_path):
+    """The exact twin of test_config5_shape_k51_f40_r4_vs_oracle: k + 1 = 40 <= L, so no two (k+1)-mers share all q addresses
+    structurally, the split histogram is order independent and EVERYTHING must equal the oracle's: the four round ranges
+    (VE.h:206-254), marks / true / false / table of every round (VE.h:384-388), the bytes (two-word keys, 128 GiB filter,
+    three-level partition, split pass + four rounds)."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m2", scale=0.004)
+    files = []
+    for i, r in enumerate(recs):
+        f = str(tmp_path / ("c5e_%d.fa" % i))
+        synth.write_fasta(f, [r], first_id=i)
+        files.append(f)
+    seed = 4242
+    o = O.Oracle(39, 40, 5, O.seed_table(seed, 5, 40))
+    for f in files:
+        o.add_fasta(f)
+    o.enumerate(rounds=4)
+    ref = str(tmp_path / "o.bin")
+    o.write_bin(ref)
+    out = str(tmp_path / "g.bin")
+    e = capi.Enumerator(files, 39, 40, q=5, rounds=4, tmpdir=str(tmp_path), out=out, seed=seed)
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    log = parse_log(e.log)
+    want = [o.round_stats(i) for i in range(4)]
+    for got, w in zip(log["rounds"], want):
+        assert (got["low"], got["high"]) == (w["low"], w["high"])
+        assert (got["marks"], got["true"], got["false"], got["table"]) == (w["marks"], w["true"], w["false"], w["table"])
+    assert e.vertices_count() == len(o.keys) > 0
+    e.close()
+    o.close()
+
+
 def test_text_length_multiple_of_16384(capi):
     """n_text = 16384 * m: the 512-word tiling then has one more tile than the text has words (the halo of the last real
     tile).  Partitioned insert and query == oracle."""

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end CLI timing on a synthetic workload: writes the FASTA files, runs bin/twopaco, prints
 wall time and junction occurrences per second.  python tools/e2e_cli.py [m1|m2] [threads]
-E2E_EXTRA="--gpus 2 --emulate-ranks": extra CLI flags (e.g. the multi-GPU host with its ranks emulated on one device)."""
+E2E_EXTRA="--gpus 2 --emulate-ranks": extra CLI flags (e.g. the multi-GPU host with its ranks emulated on one device).
+E2E_CONTIGS=N: every genome cut into N records of its file (contig-level assemblies: thousands of records, so the packer's
+record index and the junction stream's stub / separator path are in the timing)."""
 import os, re, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,9 +18,14 @@ if os.environ.get("E2E_SINGLE_FILE"):  # every genome a record of one big file (
     synth.write_fasta(f, recs)
     files.append(f)
 else:
+    contigs = int(os.environ.get("E2E_CONTIGS", "1"))
     for i, r in enumerate(recs):
         f = os.path.join(tmp, "g%d.fa" % i)
-        synth.write_fasta(f, [r], first_id=i)
+        if contigs > 1:
+            cut = [len(r) * j // contigs for j in range(contigs + 1)]
+            synth.write_fasta(f, [r[a:b] for a, b in zip(cut, cut[1:])], first_id=i * contigs)
+        else:
+            synth.write_fasta(f, [r], first_id=i)
         files.append(f)
 exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
 out = os.path.join(tmp, "out.bin")

@@ -367,7 +367,14 @@ namespace TwoPaCo
 		// 3. pack the pieces
 		std::vector<size_t> pieceErrorAt(piece.size(), size_t(-1));
 		std::vector<std::string> pieceError(piece.size());
-		parallel(piece.size(), [&](size_t i) { PackPiece(input[piece[i].file], piece[i], pieceErrorAt[i], pieceError[i]); });
+		// (contig-level assemblies: thousands of small pieces -- a task is a block of consecutive pieces, not one piece)
+		const size_t block = std::max<size_t>(1, piece.size() / (team * 8));
+		auto blocks = [&](const std::function<void(size_t)> & fn)
+		{
+			parallel((piece.size() + block - 1) / block, [&](size_t b) { for (size_t i = b * block; i < std::min(piece.size(), (b + 1) * block); i++) fn(i); });
+		};
+
+		blocks([&](size_t i) { PackPiece(input[piece[i].file], piece[i], pieceErrorAt[i], pieceError[i]); });
 		lap("pack");
 		for (size_t i = 0; i < piece.size(); i++)
 		{
@@ -463,7 +470,7 @@ namespace TwoPaCo
 		});
 		lap("zero");
 		setN(0);  // leading separator
-		parallel(piece.size(), place);
+		blocks(place);
 		lap("place");
 	}
 }
