@@ -344,7 +344,8 @@ namespace TwoPaCo
 				const uint64_t BIN_SIZE = std::max(uint64_t(1), realSize / BINS_COUNT);
 				std::vector<uint32_t> binCounter;
 				double roundSize = 0;
-				if (rounds > 1)
+				const bool rangesFromCheckpoint = !options.loadFilter.empty();  // a checkpoint names the range of the round it holds
+				if (rounds > 1 && !rangesFromCheckpoint)
 				{
 					logStream << "Splitting the input kmers set..." << std::endl;
 					binCounter.resize(BINS_COUNT + 1);
@@ -373,7 +374,21 @@ namespace TwoPaCo
 				for (size_t round = 0; round < rounds; round++)
 				{
 					mark = time(0);
-					if (rounds > 1)
+					if (rangesFromCheckpoint)
+					{
+						// the round's range is the one its filter was filled for (the split pass that chose it counts first-seen edges in
+						// arrival order, vertexenumerator.h:559-570: a rerun may cut a saturated filter's rounds a few bins away)
+						const std::string name = FilterFileName(options.loadFilter, round);
+						std::FILE * f = std::fopen(name.c_str(), "rb");
+						if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + name);
+						FilterFileHeader h;
+						std::vector<uint64_t> fileTable;
+						try { ReadFilterHeader(f, name, h, fileTable); } catch (...) { std::fclose(f); throw; }
+						std::fclose(f);
+						low = h.low;
+						high = h.high;
+					}
+					else if (rounds > 1)
 					{
 						// reference vertexenumerator.h:234-250
 						uint64_t accumulated = binCounter[std::min<uint64_t>(lowBoundary, BINS_COUNT)];
