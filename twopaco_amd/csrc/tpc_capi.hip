@@ -244,7 +244,8 @@ uint64_t filter_words_for(int L, uint32_t world)
 }
 
 // Buffer budget of one tile batch.  Automatic: 40 GiB (the first ~48 GiB of hipMalloc are cheap on this system), more when
-// the device has room -- fewer batches mean fewer passes over the filter (45 % of what is free plus what is already held).
+// the device has room -- fewer batches mean fewer passes over the filter (60 % of what is free plus what is already held;
+// the rest stays for the second pass's table, the stream and the overflow lists).
 int64_t part_budget(const tpc_ctx *c)
 {
     if (c->opt_part_budget > 0) return c->opt_part_budget;
@@ -252,8 +253,12 @@ int64_t part_budget(const tpc_ctx *c)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (int64_t)40 << 30; }
     size_t held = 0;
     for (size_t b : c->pbytes) held += b;
-    return std::max<int64_t>((int64_t)40 << 30, (int64_t)((double)(free_b + held) * 0.45));
+    return std::max<int64_t>((int64_t)40 << 30, (int64_t)((double)(free_b + held) * 0.60));
 }
+
+// Batch counts tried in turn: every count up to 8, then steps of ~1/8 -- each batch streams the whole filter once, so a text that
+// needs 17 batches should not be cut into 32.
+uint64_t next_batches(uint64_t b) { return b + std::max<uint64_t>(1, b / 8); }
 
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
@@ -263,7 +268,7 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
     const uint64_t tiles = text_tiles512(c);
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
     const int64_t budget = part_budget(c);
-    for (uint64_t batches = 1;; batches *= 2) {
+    for (uint64_t batches = 1;; batches = next_batches(batches)) {
         const uint64_t per = (tiles + batches - 1) / batches;
         const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl, c->opt_part_levels);
         if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) return false;  // geometry unsupported (not a size problem)
@@ -519,7 +524,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);
-        for (;; batches *= 2) {
+        for (;; batches = next_batches(batches)) {
             const uint64_t per = (tiles + batches - 1) / batches;
             if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl, c->opt_part_levels)) { part = false; break; }
             if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
@@ -657,7 +662,7 @@ int tpc_reserve(tpc_ctx *c, uint64_t n_text_max)
     bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && !(c->P.q > 8 && c->P.L - c->opt_slice_bits > 24);
     if (part) {
         const int64_t budget = part_budget(c);
-        for (uint64_t batches = 1;; batches *= 2) {
+        for (uint64_t batches = 1;; batches = next_batches(batches)) {
             const uint64_t per = (tiles + batches - 1) / batches;
             if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, 1.0, pl, c->opt_part_levels)) { part = false; break; }
             if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
@@ -1395,7 +1400,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
     if (pass == TPC_SHARD_INSERT) {
         const double frac = gated ? std::min(1.0, (1.0 - (1.0 - m) * (1.0 - m)) * 1.15) : 1.0;
         TpcPartPlan &pl = c->sh_ipl;
-        for (uint64_t batches = 1;; batches *= 2) {
+        for (uint64_t batches = 1;; batches = next_batches(batches)) {
             per = (per_total + batches - 1) / batches;
             if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->opt_part_levels))
                 return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
@@ -1411,7 +1416,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv; geom[12] = pl.b3;
     } else {
         TpcQPlan &pl = c->sh_qpl;
-        for (uint64_t batches = 1;; batches *= 2) {
+        for (uint64_t batches = 1;; batches = next_batches(batches)) {
             per = (per_total + batches - 1) / batches;
             uint32_t log_w = 0;
             while ((1u << log_w) < c->sh_world) ++log_w;
