@@ -63,9 +63,11 @@ int tpc_ctx_create(int device, tpc_ctx **out);
 void tpc_ctx_destroy(tpc_ctx *ctx);
 const char *tpc_last_error(const tpc_ctx *ctx);
 
-/* Optional: make the runtime load every kernel code object now (one trivial launch per translation unit) instead of
- * at the first real launch.  Touches no context state, so a one-shot caller can run it on a second host thread
- * while it uploads the text. */
+/* Optional: make the runtime load every kernel code object now (an attribute query of one kernel per translation unit,
+ * ~30 ms in all) instead of at the first real launch.  Neither call needs a stream or touches context state, so a one-shot
+ * caller (the CLI) runs tpc_warmup on a second host thread while it allocates the filter and uploads the text; tpc_preload
+ * is the same for a device that has no context yet. */
+int tpc_preload(int device);
 int tpc_warmup(tpc_ctx *ctx);
 /* Optional: allocate the partition buffers of the first pass now, for a text of at most n_text_max positions (after
  * tpc_set_params, before tpc_seq_upload), instead of inside the first tpc_pass1_insert.  A one-shot caller (the CLI) knows

@@ -24,7 +24,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
-               "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part"]
+               "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part"]
 
 _hip = None
 _host = None
@@ -70,6 +70,7 @@ def hip():
         L.tpc_filter_download.argtypes = [p, p]
         L.tpc_filter_upload.argtypes = [p, p]
         L.tpc_warmup.argtypes = [p]
+        L.tpc_preload.argtypes = [ctypes.c_int]
         L.tpc_reserve.argtypes = [p, u64]
         L.tpc_mask_words.restype = u64
         L.tpc_mask_words.argtypes = [p]

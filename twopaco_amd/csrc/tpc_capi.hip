@@ -360,25 +360,26 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     return fail(c, -1, "unknown option %s", name);
 }
 
+int tpc_preload(int device)
+{   // needs no context and no stream (a second queue costs ~20 ms to create): attribute queries load the code objects
+    if (hipSetDevice(device) != hipSuccess) return -10;
+    const bool timing = getenv("TWOPACO_TIMING") != nullptr;
+    int (*const warm[5])() = { tpc_warm_pass1, tpc_warm_partition, tpc_warm_qpartition, tpc_warm_pass2, tpc_warm_stream };
+    const char *const name[5] = { "pass1", "partition", "qpartition", "pass2", "stream" };
+    // one after the other: loading them from several host threads at once is no faster (the runtime serialises it) and was seen
+    // to stall device allocations made meanwhile by ~0.5 s
+    for (int i = 0; i < 5; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (warm[i]() != 0) return -10;
+        if (timing) fprintf(stderr, "[timing]     code object %s: %.1f ms\n", name[i], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return 0;
+}
+
 int tpc_warmup(tpc_ctx *c)
 {   // touches no context state: may run beside tpc_seq_upload on another host thread
     if (!c) return -1;
-    if (hipSetDevice(c->device) != hipSuccess) return -10;
-    hipStream_t s = nullptr;
-    if (hipStreamCreate(&s) != hipSuccess) return -10;
-    const bool timing = getenv("TWOPACO_TIMING") != nullptr;
-    void (*const warm[5])(hipStream_t) = { tpc_warm_pass1, tpc_warm_partition, tpc_warm_qpartition, tpc_warm_pass2, tpc_warm_stream };
-    const char *const name[5] = { "pass1", "partition", "qpartition", "pass2", "stream" };
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 5 && e == hipSuccess; i++) {
-        hipEvent_t dummy = nullptr; (void)dummy;
-        const auto t0 = std::chrono::steady_clock::now();
-        warm[i](s);
-        e = hipStreamSynchronize(s);
-        if (timing) fprintf(stderr, "[timing]     code object %s: %.1f ms\n", name[i], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-    (void)hipStreamDestroy(s);
-    return e == hipSuccess ? 0 : -10;
+    return tpc_preload(c->device);
 }
 
 int64_t tpc_get_stat(const tpc_ctx *c, const char *name)

@@ -185,9 +185,9 @@ int tpc_launch_stream_write_part(hipStream_t s, const uint64_t *d_rec_start, con
                                  const uint64_t *e_scan, const uint64_t *s_scan, const uint64_t *before, uint32_t r_last, uint64_t first_stub,
                                  uint64_t chunk_lo, uint64_t chunk_hi, uint64_t slot0, uint32_t *out);
 
-// code-object warm-up (one trivial launch per translation unit), used by tpc_warmup
-void tpc_warm_pass1(hipStream_t s);
-void tpc_warm_partition(hipStream_t s);
-void tpc_warm_qpartition(hipStream_t s);
-void tpc_warm_pass2(hipStream_t s);
-void tpc_warm_stream(hipStream_t s);
+// code-object warm-up (an attribute query of one kernel per translation unit makes the runtime load its code object), used by tpc_preload
+int tpc_warm_pass1();
+int tpc_warm_partition();
+int tpc_warm_qpartition();
+int tpc_warm_pass2();
+int tpc_warm_stream();

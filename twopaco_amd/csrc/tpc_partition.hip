@@ -752,9 +752,9 @@ int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl0, ui
     return tpc_launch_insert_part_apply(a, pl, fresh);
 }
 
-// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+// tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_partition() {}
-void tpc_warm_partition(hipStream_t s) { hipLaunchKernelGGL(k_warm_partition, dim3(1), dim3(64), 0, s); }
+int tpc_warm_partition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_partition)) == hipSuccess ? 0 : -1; }
 
 int tpc_launch_region_offsets(const TpcLaunch &a, const uint32_t *cnt, uint32_t n_regions, uint64_t *off)
 {

@@ -408,6 +408,6 @@ int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *
     return 0;
 }
 
-// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+// tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_pass1() {}
-void tpc_warm_pass1(hipStream_t s) { hipLaunchKernelGGL(k_warm_pass1, dim3(1), dim3(64), 0, s); }
+int tpc_warm_pass1() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_pass1)) == hipSuccess ? 0 : -1; }

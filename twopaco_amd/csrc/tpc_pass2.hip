@@ -846,7 +846,7 @@ int TPC_PASS2_FN(tpc_launch_emit)(const TpcLaunch &a, int C, const uint64_t *mar
 }
 
 #if TPC_PASS2_PART == 0
-// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+// tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_pass2() {}
-void tpc_warm_pass2(hipStream_t s) { hipLaunchKernelGGL(k_warm_pass2, dim3(1), dim3(64), 0, s); }
+int tpc_warm_pass2() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_pass2)) == hipSuccess ? 0 : -1; }
 #endif

@@ -1404,6 +1404,6 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
     return 0;
 }
 
-// tpc_warmup: the first launch of any kernel of this translation unit makes the runtime load its code object
+// tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_qpartition() {}
-void tpc_warm_qpartition(hipStream_t s) { hipLaunchKernelGGL(k_warm_qpartition, dim3(1), dim3(64), 0, s); }
+int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }

@@ -213,7 +213,8 @@ namespace TwoPaCo
 						}
 
 						setupTimer.Lap("  setup thread: HIP start-up + context");
-						// the kernels' code objects load on a third thread while the filter is allocated and the text goes up
+						// the kernels' code objects load on a third thread while the filter is allocated and the text goes up (started
+						// beside tpc_ctx_create instead it gains nothing: the runtime's start-up is serial, and stalls of 0.3 s were seen)
 						warm = std::thread([this]() { PhaseTimer warmTimer; tpc_warmup(ctx_); warmTimer.Lap("  warm-up thread: code objects"); });
 
 						Check(tpc_set_option(ctx_, "insert_test_first", options.insertTestFirst ? 1 : 0), "set_option");
