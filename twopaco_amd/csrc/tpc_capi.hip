@@ -43,6 +43,8 @@ struct tpc_ctx {
     uint64_t *marks = nullptr;
     uint64_t marks_cap = 0, n_marks = 0;
     bool marks_valid = false;  // marks[] is the compaction of rmask
+    bool rmask_sums_valid = false;  // block_sums / rmask_sums_n are those of the current rmask (left by the partitioned query's count)
+    uint64_t rmask_sums_n = 0;
     uint64_t *block_sums = nullptr;
     uint64_t *scan_blocks = nullptr;  // scan2 per-chunk counts / offsets
     // exact filter table
@@ -287,10 +289,15 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
 int compact_mask(tpc_ctx *c, const uint32_t *m)
 {   // ordered list of the set bits of m -> c->marks / c->n_marks
     Timed t(c, TPC_K_COMPACT);
-    tpc_launch_mask_count(c->stream, m, c->n_words, c->block_sums, c->counters + 2);
     uint64_t n = 0;
-    int rc = read_counter(c, 2, &n);
-    if (rc) return rc;
+    int rc = 0;
+    if (m == c->rmask && c->rmask_sums_valid) {
+        n = c->rmask_sums_n;  // the query has just counted this mask: its block sums are still in place
+    } else {
+        c->rmask_sums_valid = false;
+        tpc_launch_mask_count(c->stream, m, c->n_words, c->block_sums, c->counters + 2);
+        if ((rc = read_counter(c, 2, &n))) return rc;
+    }
     rc = ensure(c, c->marks, c->marks_cap, n);
     if (rc) return rc;
     if (n) tpc_launch_mask_scatter(c->stream, m, c->n_words, c->block_sums, c->marks);
@@ -427,7 +434,7 @@ int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
     }
     c->have_params = true;
     c->pending_apply = false;
-    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false; c->rmask_sums_valid = false;
     return 0;
 }
 
@@ -482,14 +489,14 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     c->text_windowed = windowed; c->text_w0 = w0; c->text_w1 = w1;
     c->pending_apply = false;
     c->n_text = n_text; c->n_words = (n_text >> 5) + 1; c->n_words_alloc = alloc; c->n_tiles = tiles;
-    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false; c->rmask_sums_valid = false;
     return 0;
 }
 
 int tpc_run_begin(tpc_ctx *c)
 {
     if (!c) return -1;
-    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false;
+    c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false; c->rmask_sums_valid = false;
     c->n_marks = 0; c->n_emit = 0; c->keys_host.clear();
     return 0;
 }
@@ -740,7 +747,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
-    c->marks_valid = false;
+    c->marks_valid = false; c->rmask_sums_valid = false;
     TpcQPlan pl;
     const uint64_t tiles = text_tiles512(c);
     bool part = plan_query(c, lo, hi, gated, pl);
@@ -819,6 +826,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     pr[0], pr[8], pr[9], pr[10], pr[12], pr[16], pr[17], pr[18], pr[20]);
         }
         if (!overflowed) {
+            c->rmask_sums_valid = true;
+            c->rmask_sums_n = n;
             if (n_marks) *n_marks = n;
             return 0;
         }
@@ -1154,7 +1163,7 @@ int tpc_emit(tpc_ctx *c, uint64_t *n_marked, uint64_t *n_valid)
     // one round: the round's list is the run-wide list; otherwise compact the merged mask
     if (c->mask_dirty || !c->marks_valid) {
         if ((rc = compact_mask(c, c->mask))) return rc;
-        c->marks_valid = false;
+        c->marks_valid = false; c->rmask_sums_valid = false;
     }
     if (c->n_marks > c->emit_cap || !c->emit_id) {
         if (c->emit_id) (void)hipFree(c->emit_id);
@@ -1362,7 +1371,7 @@ int tpc_emit_import(tpc_ctx *c, const uint64_t *g_dev, const int64_t *id_dev, ui
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_marks = n; c->n_emit = n;
-    c->marks_valid = false;  // the list no longer is this rank's round list
+    c->marks_valid = false; c->rmask_sums_valid = false;  // the list no longer is this rank's round list
     return 0;
 }
 
@@ -1492,7 +1501,7 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
         HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
         // marks of this batch's survivors land anywhere in the batch, the hash kernel only rewrites this rank's tiles
         if (batch == 0) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));
-        c->marks_valid = false;
+        c->marks_valid = false; c->rmask_sums_valid = false;
         {
             Timed t(c, TPC_K_SHARD_HASH);
             if (tpc_launch_query_part_hash(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "hash launch failed");
@@ -1679,7 +1688,7 @@ int tpc_shard_mark(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n)
     if (!c || !c->sh_have[TPC_SHARD_QUERY] || (n && !sid_dev)) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     tpc_launch_shard_mark(make_launch(c), c->sh_qpl, sid_dev, n, c->rmask);
-    c->marks_valid = false;
+    c->marks_valid = false; c->rmask_sums_valid = false;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1699,7 +1708,7 @@ int tpc_mask_merge(tpc_ctx *c, const uint32_t *src_dev, uint32_t count)
     if (!c || !c->rmask || (!src_dev && count)) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < count; i++) tpc_launch_mask_or(c->stream, c->rmask, src_dev + (uint64_t)i * c->n_words, c->n_words);
-    c->marks_valid = false;
+    c->marks_valid = false; c->rmask_sums_valid = false;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1786,7 +1795,7 @@ int tpc_mask_import(tpc_ctx *c, const uint32_t *src_dev)
     if (!c || !c->rmask || !src_dev) return fail(c, -1, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->rmask, src_dev, c->n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    c->marks_valid = false;
+    c->marks_valid = false; c->rmask_sums_valid = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -571,25 +571,31 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 }
 
 // ------------------------------------------------------------------------------------------ compacted exchange
-// off[i] = sum of cnt[0..i) (entries), off[n] = total: one workgroup, every thread sums a run of regions.
+// off[i] = sum of cnt[0..i) (entries), off[n] = total: one workgroup, every wave owns a contiguous segment (coalesced reads).
 __global__ void __launch_bounds__(1024) k_region_offsets(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off)
 {
     __shared__ unsigned long long s_w[16];
-    const uint32_t per = (n + 1023u) / 1024u, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t seg = ((n + 15u) / 16u + 63u) & ~63u;
+    const uint64_t i0 = (uint64_t)wv * seg, i1 = min((uint64_t)n, i0 + seg);
     unsigned long long sum = 0;
-    for (uint32_t i = i0; i < i1; i++) sum += cnt[i];
-    unsigned long long inc = sum;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wv] = inc;
+    for (uint64_t i = i0 + lane; i < i1; i += 64) sum += cnt[i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_w[wv] = sum;
     __syncthreads();
-    unsigned long long base = 0, tot = 0;
-    for (int i = 0; i < 16; i++) { const unsigned long long x = s_w[i]; if (i < wv) base += x; tot += x; }
-    unsigned long long run = base + inc - sum;
-    for (uint32_t i = i0; i < i1; i++) { off[i] = run; run += cnt[i]; }
+    unsigned long long run = 0, tot = 0;
+    for (uint32_t i = 0; i < 16; i++) { const unsigned long long x = s_w[i]; if (i < wv) run += x; tot += x; }
+    for (uint64_t i = i0; i < i1; i += 64) {  // uniform per wave
+        const bool in = i + lane < i1;
+        const unsigned long long v = in ? cnt[i + lane] : 0;
+        unsigned long long inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += t;
+        }
+        if (in) off[i + lane] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
     if (threadIdx.x == 0) off[n] = tot;
 }
 

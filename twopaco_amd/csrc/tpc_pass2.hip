@@ -94,18 +94,31 @@ __global__ void __launch_bounds__(256) k_mask_count(const uint32_t *__restrict__
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// single workgroup: exclusive scan of block_sums in place, total to *n_out
+// single workgroup: exclusive scan of block_sums in place, total to *n_out (16 consecutive sums per thread and iteration)
 __global__ void __launch_bounds__(256) k_scan_sums(uint64_t *block_sums, uint64_t n, unsigned long long *n_out)
 {
-    __shared__ uint32_t s_w[4];
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < n; base += 256) {
-        const uint64_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? (uint32_t)block_sums[i] : 0;  // per-block sums are <= 8192
-        uint32_t total;
-        const uint32_t ex = block_excl_scan256(v, s_w, total);
-        if (i < n) block_sums[i] = carry + ex;
-        carry += total;
+    __shared__ unsigned long long s_w[4];
+    constexpr int PER = 16;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (uint64_t base = 0; base < n; base += 256 * PER) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * PER;
+        unsigned long long v[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { v[j] = i0 + j < n ? block_sums[i0 + j] : 0; sum += v[j]; }
+        unsigned long long inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        unsigned long long run = carry + inc - sum;
+        for (int i = 0; i < wv; i++) run += s_w[i];
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; j++) { if (i0 + j < n) block_sums[i0 + j] = run; run += v[j]; }
     }
     if (threadIdx.x == 0) *n_out = carry;
 }
