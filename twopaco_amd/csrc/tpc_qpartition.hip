@@ -778,7 +778,13 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
 // (the fold of cyclichash.h:106-109 written out) -- one 16-byte LDS read per letter and function for both strands, no
 // rotations in the loop: ~600 instead of ~1600 vector instructions per survivor (the kernel was 74 % VALU issue,
 // profiles/r03a_sq.csv).  Same verdicts: canonical strand by the first function whose two values differ (tpc_pick_neg).
-template <int Q>
+// LAZY (the form in use; TPC_VERIFY_LAZY=0 selects the other one for measurements): function 0 on both strands -- it decides
+// the strand -- then function 1 of that strand and its probe ALONE, and only a survivor that passes goes on to functions
+// 2..Q-1.  On a well-filled filter most survivors are Bloom false positives of function 0 and end at that first probe: a
+// quarter of the scattered loads and under half of the instructions of the all-at-once form (full configs[3], f = 38, 0.4
+// survivors per position: query 1798 -> 1654 ms).  Where the survivors are mostly true second edges (M2: 54 of 58 M pass every
+// probe) the two forms measure the same (27.7 ms per step either way).
+template <int Q, bool LAZY>
 __global__ void __launch_bounds__(256)
 k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ filter,
             const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t gbase, uint32_t *rmask)
@@ -813,29 +819,101 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
         const uint64_t g = gbase + (sid >> 3);
         // the edge's k + 1 letters, first letter in the low bits: in-edge c + v, out-edge v + c
         uint64_t E = e < 4 ? ((w << 2) | (uint64_t)c) : (w | ((uint64_t)c << (2 * k)));
-        uint64_t p[Q], nn[Q];
+        bool present = true;  // function 0 passed in k_q_lookup
+        if constexpr (!LAZY || Q < 3) {
+            uint64_t p[Q], nn[Q];
 #pragma unroll
-        for (int i = 0; i < Q; i++) { p[i] = 0; nn[i] = 0; }
-        const uint4 *row = s_t;
-        for (int t = 0; t <= k; t++) {
-            const uint4 *r = row + ((uint32_t)E & 3u) * Q;
-            E >>= 2;
-            row += 4 * Q;
+            for (int i = 0; i < Q; i++) { p[i] = 0; nn[i] = 0; }
+            const uint4 *row = s_t;
+            for (int t = 0; t <= k; t++) {
+                const uint4 *r = row + ((uint32_t)E & 3u) * Q;
+                E >>= 2;
+                row += 4 * Q;
 #pragma unroll
-            for (int i = 0; i < Q; i++) {
-                const uint4 x = r[i];
-                p[i] ^= ((uint64_t)x.y << 32) | x.x;
-                nn[i] ^= ((uint64_t)x.w << 32) | x.z;
+                for (int i = 0; i < Q; i++) {
+                    const uint4 x = r[i];
+                    p[i] ^= ((uint64_t)x.y << 32) | x.x;
+                    nn[i] ^= ((uint64_t)x.w << 32) | x.z;
+                }
+            }
+            const bool ng = tpc_pick_neg<Q>(p, nn);  // DetermineStrandExtend / Prepend (vertexrollinghash.h:170-200)
+            uint32_t wv[Q];  // the other probes are independent loads
+            uint64_t addr[Q];
+#pragma unroll
+            for (int i = 1; i < Q; i++) { addr[i] = ng ? nn[i] : p[i]; wv[i] = filter[addr[i] >> 5]; }
+#pragma unroll
+            for (int i = 1; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
+        } else {
+            // function 0, both strands
+            uint64_t p0 = 0, n0 = 0;
+            {
+                uint64_t e2 = E;
+                const uint4 *row = s_t;
+                for (int t = 0; t <= k; t++) {
+                    const uint4 x = row[((uint32_t)e2 & 3u) * Q];
+                    e2 >>= 2;
+                    row += 4 * Q;
+                    p0 ^= ((uint64_t)x.y << 32) | x.x;
+                    n0 ^= ((uint64_t)x.w << 32) | x.z;
+                }
+            }
+            bool ng = n0 < p0;
+            if (p0 == n0) {  // a strand tie on function 0 (palindromic edge or a collision): the later functions decide
+                uint64_t p[Q], nn[Q];
+#pragma unroll
+                for (int i = 0; i < Q; i++) { p[i] = 0; nn[i] = 0; }
+                uint64_t e2 = E;
+                const uint4 *row = s_t;
+                for (int t = 0; t <= k; t++) {
+                    const uint4 *r = row + ((uint32_t)e2 & 3u) * Q;
+                    e2 >>= 2;
+                    row += 4 * Q;
+#pragma unroll
+                    for (int i = 0; i < Q; i++) {
+                        const uint4 x = r[i];
+                        p[i] ^= ((uint64_t)x.y << 32) | x.x;
+                        nn[i] ^= ((uint64_t)x.w << 32) | x.z;
+                    }
+                }
+                ng = tpc_pick_neg<Q>(p, nn);
+            }
+            // function 1 of the canonical strand alone
+            const uint2 *half = reinterpret_cast<const uint2 *>(s_t) + (ng ? 1 : 0);  // .xy = positive, .zw = negative strand
+            uint64_t a1 = 0;
+            {
+                uint64_t e2 = E;
+                const uint2 *row = half + 2;  // function 1
+                for (int t = 0; t <= k; t++) {
+                    const uint2 x = row[((uint32_t)e2 & 3u) * (2 * Q)];
+                    e2 >>= 2;
+                    row += 8 * Q;
+                    a1 ^= ((uint64_t)x.y << 32) | x.x;
+                }
+            }
+            present = (filter[a1 >> 5] >> ((uint32_t)a1 & 31u)) & 1u;
+            if (present) {
+                uint64_t a[Q];
+#pragma unroll
+                for (int i = 2; i < Q; i++) a[i] = 0;
+                uint64_t e2 = E;
+                const uint2 *row = half;
+                for (int t = 0; t <= k; t++) {
+                    const uint2 *r = row + ((uint32_t)e2 & 3u) * (2 * Q);
+                    e2 >>= 2;
+                    row += 8 * Q;
+#pragma unroll
+                    for (int i = 2; i < Q; i++) {
+                        const uint2 x = r[2 * i];
+                        a[i] ^= ((uint64_t)x.y << 32) | x.x;
+                    }
+                }
+                uint32_t wv[Q];
+#pragma unroll
+                for (int i = 2; i < Q; i++) wv[i] = filter[a[i] >> 5];
+#pragma unroll
+                for (int i = 2; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)a[i] & 31u)) & 1u);
             }
         }
-        const bool ng = tpc_pick_neg<Q>(p, nn);  // DetermineStrandExtend / Prepend (vertexrollinghash.h:170-200)
-        bool present = true;  // function 0 passed in k_q_lookup; the other probes are independent loads
-        uint32_t wv[Q];
-        uint64_t addr[Q];
-#pragma unroll
-        for (int i = 1; i < Q; i++) { addr[i] = ng ? nn[i] : p[i]; wv[i] = filter[addr[i] >> 5]; }
-#pragma unroll
-        for (int i = 1; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
@@ -1087,9 +1165,18 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
     const size_t table = (size_t)(a.P.k + 1) * 4 * Q * 16;  // k_q_verify2's letter table
     if (a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN")) {
-        (void)hipFuncSetAttribute((const void *)k_q_verify2<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
-        hipLaunchKernelGGL((k_q_verify2<Q>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
-                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+        const char *force = getenv("TPC_VERIFY_LAZY");  // measurements: 0 = all Q - 1 probes at once
+        const bool lazy = !(force && force[0] == '0');
+        const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
+        if (lazy) {
+            (void)hipFuncSetAttribute((const void *)k_q_verify2<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
+            hipLaunchKernelGGL((k_q_verify2<Q, true>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, gbase,
+                               rmask);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_q_verify2<Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
+            hipLaunchKernelGGL((k_q_verify2<Q, false>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, gbase,
+                               rmask);
+        }
         return;
     }
     hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
