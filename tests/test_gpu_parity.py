@@ -39,6 +39,17 @@ def test_library_is_the_hip_one(capi):
     ctx.close()
 
 
+def test_code_objects_preload_without_context_or_stream(capi):
+    """tpc_preload / tpc_warmup (include/twopaco_hip.h): load every translation unit's code object through attribute queries;
+    both are optional, return 0 on a GPU box and a bad device is an error, not a crash."""
+    lib = capi.hip()
+    assert lib.tpc_preload(0) == 0
+    assert lib.tpc_preload(1 << 20) != 0
+    ctx = capi.Context(0)
+    assert lib.tpc_warmup(ctx._h) == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["rand6_k9_fp", "rand6_k9_L33", "c2_k51_r2", "edge_k5"])
 def test_vertex_hashes(capi, tmp_path, name):
     case = [c for c in CASES if c["name"] == name][0]
