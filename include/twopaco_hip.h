@@ -322,13 +322,15 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *                      each filter slice itself (the filter is written once and not read back by that batch); TPC_K_INSERT then
  *                      covers hash + split only and TPC_K_FUSED the shared kernel; 0: off
  *   test_sched_cap     tests only, process-wide: rounds per segment of the split kernels' round schedule (0 = what fits in LDS)
- *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 45 % of the free device
- *                      memory when that is more); part_min_tiles  smallest batch */
+ *   test_fail_mallocs  tests only, process-wide: the next N second-pass / output allocations fail at their first attempt, as if
+ *                      the device were full (they then give the partition buffers back and try again, see "pbuf_releases")
+ *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 60 % of the free device
+ *                      memory when that is more; any number of batches, not only powers of two); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
- * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "round_marks" = candidate marks of the round the last
+ * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "pbuf_releases" = times a second-pass or output allocation did not fit beside the first pass' partition buffers, which were then freed (the next first pass allocates them again); "round_marks" = candidate marks of the round the last
  * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does).
  * -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);

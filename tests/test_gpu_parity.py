@@ -168,6 +168,44 @@ def test_all_passes_forced_partitioned(capi, tmp_path, name):
     ctx.close()
 
 
+def test_second_pass_allocations_take_back_the_partition_buffers(capi, tmp_path):
+    """The first pass' partition buffers may hold 60 % of the device (part_budget).  A second-pass / output allocation that does
+    not fit frees them and is repeated; the next round's first pass allocates them again.  Simulated with option
+    test_fail_mallocs on a four-round run: every round's counters, the keys and the records stay the oracle's."""
+    case = [c for c in CASES if c["name"] == "rand6_k9_fp_r4"][0]
+    o = _oracle_for(case, tmp_path)
+    o.enumerate(rounds=case["n_rounds"], abundance=MAXU)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", 8)):
+        ctx.set_option(opt, val)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    ctx.seq_upload(text)
+    ctx.run_begin()
+    try:
+        for r in range(case["n_rounds"]):
+            st = o.round_stats(r)
+            ctx.filter_reset()
+            ctx.pass1_insert(st["low"], st["high"])
+            assert ctx.pass1_query(st["low"], st["high"]) == st["marks"]
+            assert ctx.stat("insert_path") % 10 in (2, 3) and ctx.stat("query_path") % 10 in (2, 3)
+            ctx.set_option("test_fail_mallocs", 1)  # the mark list (round 0) or the next allocation that is made
+            assert ctx.pass2_filter(MAXU) == {"true": st["true"], "false": st["false"], "table": st["table"]}
+        # a hook still armed here (the last round's exact filter allocated nothing) fires in one of these, with buffers to give back
+        J = ctx.junctions_finalize()
+        assert (ctx.junction_keys() == o.keys).all()
+        ctx.emit()
+    finally:
+        ctx.set_option("test_fail_mallocs", 0)
+    assert ctx.stat("pbuf_releases") >= 2  # at least: round 0's mark list, and one of the later ones after the buffers came back
+    g, ids = ctx.emit_fetch()
+    seq, pos, oid = o.records
+    real = np.abs(oid) <= J
+    valid = ids != capi.INVALID_VERTEX
+    assert (g[valid] == o.rec_start[seq[real]] + pos[real].astype(np.uint64)).all() and (ids[valid] == oid[real]).all()
+    ctx.close()
+
+
 def test_test_first_variant_same_filter(capi, tmp_path):
     case = [c for c in CASES if c["name"] == "rand6_k9_fp"][0]
     text = capi.PackedText.from_fasta(case_files(case, tmp_path))

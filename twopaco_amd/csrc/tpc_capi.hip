@@ -108,6 +108,7 @@ struct tpc_ctx {
     uint64_t *iovf_off = nullptr;         // [slices + 1]
     uint32_t iovf_slices = 0;
     int64_t stat_fused = 0;
+    int64_t stat_pbuf_releases = 0;  // times the partition buffers were given back to let a second-pass allocation through
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
     TpcPartPlan sh_ipl;
@@ -161,6 +162,23 @@ uint64_t rotln_host(uint64_t x, int L, int r)
     return ((x & maskn) << r) | (x >> (L - r));
 }
 
+// Device allocations of the second pass and the output (mark list, exact-filter table, keys, ids, junction stream).  The first
+// pass' partition buffers stay allocated between rounds and may hold 60 % of the device (part_budget): when one of these
+// allocations does not fit, they are given back (the next first pass allocates them again) and the allocation is repeated.
+int tpc_test_fail_mallocs = 0;  // option "test_fail_mallocs" (tests only, process-wide): the next N first attempts fail
+bool release_partition_buffers(tpc_ctx *c);
+hipError_t dev_malloc(tpc_ctx *c, void **p, size_t bytes)
+{
+    hipError_t e = hipErrorOutOfMemory;
+    if (tpc_test_fail_mallocs > 0) { --tpc_test_fail_mallocs; *p = nullptr; } else e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    if (!release_partition_buffers(c)) return e;
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) *p = nullptr;
+    return e;
+}
+
 template <typename T>
 int ensure(tpc_ctx *c, T *&p, uint64_t &cap, uint64_t need)
 {
@@ -169,7 +187,7 @@ int ensure(tpc_ctx *c, T *&p, uint64_t &cap, uint64_t need)
     p = nullptr;
     cap = 0;
     uint64_t n = need + need / 8 + 16;
-    HIPCHK(c, hipMalloc((void **)&p, n * sizeof(T)));
+    HIPCHK(c, dev_malloc(c, (void **)&p, n * sizeof(T)));
     cap = n;
     return 0;
 }
@@ -237,6 +255,26 @@ bool ensure_pbuf(tpc_ctx *c, int i, size_t need)
     if (i == 11) c->off3_uploaded.clear();
     if (hipMalloc(&c->pbuf[i], need) != hipSuccess) { (void)hipGetLastError(); return false; }
     c->pbytes[i] = need;
+    return true;
+}
+
+bool release_partition_buffers(tpc_ctx *c)
+{   // false: nothing to give back (or a deferred insert still lives in them)
+    if (c->pending_apply) return false;
+    size_t held = 0;
+    for (size_t b : c->pbytes) held += b;
+    for (void *p : c->ikeep) if (p) held += 1;
+    if (!held) return false;
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < tpc_ctx::NPBUF; i++) {
+        if (c->pbuf[i]) (void)hipFree(c->pbuf[i]);
+        c->pbuf[i] = nullptr; c->pbytes[i] = 0;
+    }
+    for (void *&p : c->ikeep) { if (p) (void)hipFree(p); p = nullptr; }
+    for (size_t &b : c->ikeep_bytes) b = 0;
+    c->off2_uploaded.clear();
+    c->off3_uploaded.clear();
+    c->stat_pbuf_releases++;
     return true;
 }
 
@@ -364,12 +402,13 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
+    if (!strcmp(name, "test_fail_mallocs")) { tpc_test_fail_mallocs = value > 0 ? (int)value : 0; return 0; }  // process-wide, tests only
     return fail(c, -1, "unknown option %s", name);
 }
 
 int tpc_preload(int device)
 {   // needs no context and no stream (a second queue costs ~20 ms to create): attribute queries load the code objects
-    if (hipSetDevice(device) != hipSuccess) return -10;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return -10; }  // the error is this call's, not the next one's
     const bool timing = getenv("TWOPACO_TIMING") != nullptr;
     int (*const warm[5])() = { tpc_warm_pass1, tpc_warm_partition, tpc_warm_qpartition, tpc_warm_pass2, tpc_warm_stream };
     const char *const name[5] = { "pass1", "partition", "qpartition", "pass2", "stream" };
@@ -398,6 +437,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
+    if (!strcmp(name, "pbuf_releases")) return c->stat_pbuf_releases;
     if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
     if (!strcmp(name, "round_marks")) return c->marks_valid ? (int64_t)c->n_marks : -1;  // set bits of the round mask (after tpc_pass2_filter)
     return -1;
@@ -952,7 +992,7 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
             if (c->table) (void)hipFree(c->table);
             c->table = nullptr;
             c->table_alloc = 0;
-            HIPCHK(c, hipMalloc(&c->table, cap * sb));
+            HIPCHK(c, dev_malloc(c, &c->table, cap * sb));
             c->table_alloc = cap;
         }
         c->table_cap = cap;
@@ -978,7 +1018,7 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
                 if (need > c->keys_cap) {
                     uint64_t *nk = nullptr;
                     const uint64_t ncap = need + need / 4 + 1024;
-                    HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
+                    HIPCHK(c, dev_malloc(c, (void **)&nk, ncap * c->C * sizeof(uint64_t)));
                     if (c->n_keys) HIPCHK(c, hipMemcpyAsync(nk, c->keys, c->n_keys * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                     if (c->keys) (void)hipFree(c->keys);
@@ -1030,7 +1070,7 @@ int tpc_junctions_finalize(tpc_ctx *c, uint64_t *n_junctions)
             if (c->idtab) (void)hipFree(c->idtab);
             c->idtab = nullptr;
             c->idtab_bytes = 0;
-            HIPCHK(c, hipMalloc((void **)&c->idtab, cap * slot_bytes));
+            HIPCHK(c, dev_malloc(c, (void **)&c->idtab, cap * slot_bytes));
             c->idtab_bytes = cap * slot_bytes;
         }
         c->idtab_cap = cap;
@@ -1075,7 +1115,7 @@ int tpc_junction_keys_set(tpc_ctx *c, const uint64_t *keys_host, uint64_t n)
     if (n > c->keys_cap) {
         if (c->keys) (void)hipFree(c->keys);
         c->keys = nullptr; c->keys_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->keys, (n + 1024) * c->C * sizeof(uint64_t)));
+        HIPCHK(c, dev_malloc(c, (void **)&c->keys, (n + 1024) * c->C * sizeof(uint64_t)));
         c->keys_cap = n + 1024;
     }
     if (n) HIPCHK(c, hipMemcpy(c->keys, keys_host, n * c->C * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -1105,7 +1145,7 @@ int tpc_junction_keys_import(tpc_ctx *c, const uint64_t *src_dev, uint64_t n, in
     if (need > c->keys_cap) {
         uint64_t *nk = nullptr;
         const uint64_t ncap = need + need / 2 + 1024;
-        HIPCHK(c, hipMalloc((void **)&nk, ncap * c->C * sizeof(uint64_t)));
+        HIPCHK(c, dev_malloc(c, (void **)&nk, ncap * c->C * sizeof(uint64_t)));
         if (base) HIPCHK(c, hipMemcpy(nk, c->keys, base * c->C * sizeof(uint64_t), hipMemcpyDeviceToDevice));
         if (c->keys) (void)hipFree(c->keys);
         c->keys = nk;
@@ -1169,7 +1209,7 @@ int tpc_emit(tpc_ctx *c, uint64_t *n_marked, uint64_t *n_valid)
         if (c->emit_id) (void)hipFree(c->emit_id);
         c->emit_id = nullptr;
         const uint64_t cap = c->n_marks + c->n_marks / 8 + 16;
-        HIPCHK(c, hipMalloc((void **)&c->emit_id, cap * sizeof(int64_t)));
+        HIPCHK(c, dev_malloc(c, (void **)&c->emit_id, cap * sizeof(int64_t)));
         c->emit_cap = cap;
     }
     HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, sizeof(unsigned long long), c->stream));
@@ -1198,7 +1238,7 @@ int tpc_emit_stream(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_l
     void *plan = nullptr;
     int rc = 0;
     uint64_t totals[2] = {0, 0};
-    if (hipMalloc((void **)&d_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
+    if (hipMalloc((void **)&d_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || dev_malloc(c, (void **)&vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc(&plan, tpc_stream_plan_bytes(n_rec)) != hipSuccess) rc = -10;
     if (rc == 0 && (hipMemcpyAsync(d_rec, rec_start, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                     hipMemcpyAsync(d_rec + n_rec, rec_len, (size_t)n_rec * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)) rc = -10;
@@ -1210,7 +1250,7 @@ int tpc_emit_stream(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *rec_l
             if (bytes > c->stream_cap) {
                 if (c->stream_buf) (void)hipFree(c->stream_buf);
                 c->stream_buf = nullptr; c->stream_cap = 0;
-                if (hipMalloc((void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
+                if (dev_malloc(c, (void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
             }
             if (rc == 0 && bytes)
                 rc = tpc_launch_stream_write(c->stream, d_rec, d_rec + n_rec, n_rec, c->P.k, c->marks, c->emit_id, c->n_marks, vscan, plan, r_last,
@@ -1254,7 +1294,7 @@ int tpc_emit_stream_partial(tpc_ctx *c, const uint64_t *rec_start, const uint64_
     if (c->n_emit != c->n_marks || (c->n_marks && !c->emit_id)) return fail(c, -1, "tpc_emit first");
     HIPCHK(c, hipSetDevice(c->device));
     stream_part_release(c);
-    if (hipMalloc((void **)&c->sp_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&c->sp_vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
+    if (hipMalloc((void **)&c->sp_rec, 2 * (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || dev_malloc(c, (void **)&c->sp_vscan, (c->n_marks + 1) * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc((void **)&c->sp_cnt, (size_t)n_rec * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&c->sp_lo, (size_t)n_rec * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc((void **)&c->sp_flags, (size_t)n_rec * sizeof(uint32_t)) != hipSuccess) { stream_part_release(c); return fail(c, -10, "out of device memory for the junction stream"); }
     c->sp_n_rec = n_rec;
@@ -1288,7 +1328,7 @@ int tpc_emit_stream_part(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     if (rc == 0 && bytes > c->stream_cap) {
         if (c->stream_buf) (void)hipFree(c->stream_buf);
         c->stream_buf = nullptr; c->stream_cap = 0;
-        if (hipMalloc((void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
+        if (dev_malloc(c, (void **)&c->stream_buf, bytes + 64) != hipSuccess) rc = -10; else c->stream_cap = bytes;
     }
     if (rc == 0 && (hipMemcpyAsync(d_e, e_scan_host, ((size_t)n_rec + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                     hipMemcpyAsync(d_s, s_scan_host, ((size_t)n_rec + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -1362,7 +1402,7 @@ int tpc_emit_import(tpc_ctx *c, const uint64_t *g_dev, const int64_t *id_dev, ui
         if (c->emit_id) (void)hipFree(c->emit_id);
         c->emit_id = nullptr; c->emit_cap = 0;
         const uint64_t cap = n + n / 8 + 16;
-        HIPCHK(c, hipMalloc((void **)&c->emit_id, cap * sizeof(int64_t)));
+        HIPCHK(c, dev_malloc(c, (void **)&c->emit_id, cap * sizeof(int64_t)));
         c->emit_cap = cap;
     }
     if (n) {
