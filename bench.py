@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
-    ap.add_argument("--e2e-runs", type=int, default=3, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
+    ap.add_argument("--e2e-runs", type=int, default=5, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
     ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
                     help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
                          "power-of-two N), or vertex-hash ranges (the reference's rounds side by side, no data-path exchange).  auto: "
