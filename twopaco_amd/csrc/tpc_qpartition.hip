@@ -692,82 +692,78 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
         //  the survivors by position first (one radix pass) makes the text reads local but piles the mark atomics of the waves
         //  in flight onto the same words: 5.4 ms.)
         const int c = e & 3;
-        uint64_t addr[Q];  // Bloom addresses of the edge, functions 1..Q-1 (function 0 passed in k_q_lookup)
-        bool have = false;
-        if (P.k <= 32) {
-            // The strand is decided by function 0 unless its two values tie (vertexrollinghash.h:170-200): roll function 0
-            // on both strands, then functions 1..Q-1 on the chosen strand only (same instruction stream for both choices:
-            // a lane on the negative strand reads the window backwards and complemented) -- 2 + (Q-1) rolls instead of 2Q.
-            const uint64_t w = tpc_text_word(bases, g);
-            uint64_t pos0 = 0, neg0 = 0;
-            for (int t = 0; t < P.k; t++) {
-                pos0 = tpc_rotl1(pos0, P.L, P.lmask) ^ s_h[(int)((w >> (2 * t)) & 3)];
-                neg0 = tpc_rotl1(neg0, P.L, P.lmask) ^ s_h[3 - (int)((w >> (2 * (P.k - 1 - t))) & 3)];
-            }
-            const uint64_t p0 = e < 4 ? (s_hk[c] ^ pos0) : (tpc_rotl1(pos0, P.L, P.lmask) ^ s_h[c]);
-            const uint64_t n0 = e < 4 ? (tpc_rotl1(neg0, P.L, P.lmask) ^ s_h[3 - c]) : (neg0 ^ s_hk[3 - c]);
-            if (p0 != n0) {
-                const bool ng = n0 < p0;
-                uint64_t h[Q];
+        // vertex hash of the window at g for functions LO .. HI-1 on one strand (VertexRollingHash ctor, vertexrollinghash.h:79-102;
+        // the negative strand reads the window backwards and complemented)
+        auto roll = [&](auto lo_tag, auto hi_tag, bool neg_strand, uint64_t (&h)[Q]) {
+            constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
 #pragma unroll
-                for (int i = 0; i < Q; i++) h[i] = 0;
-                for (int t = 0; t < P.k; t++) {
-                    const int ch = ng ? 3 - (int)((w >> (2 * (P.k - 1 - t))) & 3) : (int)((w >> (2 * t)) & 3);
+            for (int i = LO; i < HI; i++) h[i] = 0;
+            if (!neg_strand) {
+                for (int t0 = 0; t0 < P.k; t0 += 32) {
+                    uint64_t w = tpc_text_word(bases, g + t0);
+                    const int m = min(32, P.k - t0);
+                    for (int t = 0; t < m; t++) {
+                        const int ch = (int)(w & 3);
+                        w >>= 2;
 #pragma unroll
-                    for (int i = 1; i < Q; i++) h[i] = tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                        for (int i = LO; i < HI; i++) h[i] = tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                    }
                 }
+            } else {
+                for (int t1 = P.k; t1 > 0; t1 -= 32) {  // reverse complement: last base first
+                    const int m = min(32, t1);
+                    const uint64_t w = tpc_text_word(bases, g + t1 - m);
+                    for (int t = m - 1; t >= 0; t--) {
+                        const int ch = 3 - (int)((w >> (2 * t)) & 3);
 #pragma unroll
-                for (int i = 1; i < Q; i++) {
-                    if (e < 4) addr[i] = ng ? (tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c]) : (s_hk[i * 5 + c] ^ h[i]);          // in-edge c + v
-                    else addr[i] = ng ? (h[i] ^ s_hk[i * 5 + 3 - c]) : (tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + c]);               // out-edge v + c
-                }
-                have = true;
-            }
-        }
-        if (!have) {  // long k-mers, or a function-0 tie: all 2Q vertex hashes (VertexRollingHash ctor, vertexrollinghash.h:79-102)
-            uint64_t pos[Q], neg[Q];
-#pragma unroll
-            for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
-            for (int t0 = 0; t0 < P.k; t0 += 32) {
-                uint64_t w = tpc_text_word(bases, g + t0);
-                const int m = min(32, P.k - t0);
-                for (int t = 0; t < m; t++) {
-                    const int ch = (int)(w & 3);
-                    w >>= 2;
-#pragma unroll
-                    for (int i = 0; i < Q; i++) pos[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                        for (int i = LO; i < HI; i++) h[i] = tpc_rotl1(h[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
+                    }
                 }
             }
-            for (int t1 = P.k; t1 > 0; t1 -= 32) {  // reverse complement: last base first
-                const int m = min(32, t1);
-                const uint64_t w = tpc_text_word(bases, g + t1 - m);
-                for (int t = m - 1; t >= 0; t--) {
-                    const int ch = 3 - (int)((w >> (2 * t)) & 3);
-#pragma unroll
-                    for (int i = 0; i < Q; i++) neg[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + ch];
-                }
+        };
+        // hash of the edge (in-edge c + v for e < 4, out-edge v + c otherwise) from the vertex hash of its strand
+        auto edge = [&](int i, bool neg_strand, uint64_t vh) -> uint64_t {
+            if (!neg_strand) return e < 4 ? (s_hk[i * 5 + c] ^ vh) : (tpc_rotl1(vh, P.L, P.lmask) ^ s_h[i * 5 + c]);
+            return e < 4 ? (tpc_rotl1(vh, P.L, P.lmask) ^ s_h[i * 5 + 3 - c]) : (vh ^ s_hk[i * 5 + 3 - c]);
+        };
+        auto probe = [&](uint64_t a) -> bool { return (filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u; };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, (Q > 2 ? 2 : Q)>;
+        using IQ = std::integral_constant<int, Q>;
+        // Function 0 on both strands decides the strand unless its two values tie (vertexrollinghash.h:170-200); then function 1
+        // of that strand and its probe alone -- a Bloom false positive of function 0 (most survivors of a well-filled filter)
+        // ends there -- and functions 2..Q-1 only for what passed: 3 rolls instead of 2Q for the common survivor.
+        bool present = true;  // function 0 passed in k_q_lookup
+        uint64_t hp[Q], hn[Q];
+        roll(I0(), I1(), false, hp);
+        roll(I0(), I1(), true, hn);
+        const uint64_t p0 = edge(0, false, hp[0]), n0 = edge(0, true, hn[0]);
+        if (p0 != n0) {
+            const bool ng = n0 < p0;
+            if (Q > 1) {
+                roll(I1(), I2(), ng, hp);
+                present = probe(edge(1, ng, hp[1 % Q]));
             }
+            if (present && Q > 2) {
+                roll(I2(), IQ(), ng, hp);
+                uint64_t addr[Q];
+                uint32_t wv[Q];
+#pragma unroll
+                for (int i = 2; i < Q; i++) { addr[i] = edge(i, ng, hp[i]); wv[i] = filter[addr[i] >> 5]; }  // independent loads
+#pragma unroll
+                for (int i = 2; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
+            }
+        } else {  // a function-0 tie: all 2Q hashes, the first function whose two values differ decides
+            roll(I1(), IQ(), false, hp);
+            roll(I1(), IQ(), true, hn);
             uint64_t p[Q], nn[Q];
 #pragma unroll
-            for (int i = 0; i < Q; i++) {
-                if (e < 4) {  // in-edge c + v
-                    p[i] = s_hk[i * 5 + c] ^ pos[i];
-                    nn[i] = tpc_rotl1(neg[i], P.L, P.lmask) ^ s_h[i * 5 + 3 - c];
-                } else {      // out-edge v + c
-                    p[i] = tpc_rotl1(pos[i], P.L, P.lmask) ^ s_h[i * 5 + c];
-                    nn[i] = neg[i] ^ s_hk[i * 5 + 3 - c];
-                }
-            }
+            for (int i = 0; i < Q; i++) { p[i] = edge(i, false, hp[i]); nn[i] = edge(i, true, hn[i]); }
             const bool ng = tpc_pick_neg<Q>(p, nn);
 #pragma unroll
-            for (int i = 1; i < Q; i++) addr[i] = ng ? nn[i] : p[i];
+            for (int i = 1; i < Q; i++) present = present && probe(ng ? nn[i] : p[i]);
         }
-        bool present = true;  // function 0 passed in k_q_lookup; the other probes are independent loads
-        uint32_t wv[Q];
-#pragma unroll
-        for (int i = 1; i < Q; i++) wv[i] = filter[addr[i] >> 5];
-#pragma unroll
-        for (int i = 1; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)addr[i] & 31u)) & 1u);
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
