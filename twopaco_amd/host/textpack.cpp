@@ -177,10 +177,10 @@ namespace TwoPaCo
 			size_t file, record;      // record: index over all records of all files
 			size_t begin, end;        // byte range in the file
 			std::string header;
-			std::vector<uint64_t> bases;
-			std::vector<uint32_t> nmask;
+			uint64_t * bases;         // room for (end - begin) / 32 + 2 words each in the arenas of PackFastaFiles: a piece
+			uint32_t * nmask;         // allocates nothing (contig-level inputs have 10^5 pieces)
 			uint64_t n;
-			Piece() : n(0) {}
+			Piece() : bases(0), nmask(0), n(0) {}
 		};
 
 		void PackPiece(const InputFile & in, Piece & p, size_t & errorAt, std::string & error)
@@ -189,8 +189,10 @@ namespace TwoPaCo
 			uint64_t word = 0;
 			uint32_t mask = 0;
 			unsigned fill = 0;
-			p.bases.reserve((p.end - p.begin) / 32 + 2);
-			p.nmask.reserve((p.end - p.begin) / 32 + 2);
+			uint64_t * const B = p.bases;
+			uint32_t * const M = p.nmask;
+			size_t w = 0;
+			uint64_t n = 0;
 			for (size_t i = p.begin; i < p.end; ++i)
 			{
 				const uint8_t cls = PACK.t[d[i]];
@@ -200,26 +202,30 @@ namespace TwoPaCo
 					mask |= uint32_t(cls >> 2) << fill;
 					if (++fill == 32)
 					{
-						p.bases.push_back(word);
-						p.nmask.push_back(mask);
+						B[w] = word;
+						M[w] = mask;
+						++w;
 						word = 0; mask = 0; fill = 0;
 					}
 
-					++p.n;
+					++n;
 				}
 				else if (cls == 7)
 				{
 					errorAt = i;
 					error = "Found an invalid character '" + std::string(1, char(d[i])) + "' in sequence " + p.header;
+					p.n = n;
 					return;
 				}
 			}
 
 			if (fill)
 			{
-				p.bases.push_back(word);
-				p.nmask.push_back(mask);
+				B[w] = word;
+				M[w] = mask;
 			}
+
+			p.n = n;
 		}
 	}
 
@@ -364,7 +370,18 @@ namespace TwoPaCo
 			}
 		}
 
-		// 3. pack the pieces
+		// 3. pack the pieces, each into its own span of two arenas (no allocation per piece; the pages are touched first by the
+		// packing threads)
+		std::vector<size_t> arenaAt(piece.size() + 1, 0);
+		for (size_t i = 0; i < piece.size(); i++) arenaAt[i + 1] = arenaAt[i] + (piece[i].end - piece[i].begin) / 32 + 2;
+		std::unique_ptr<uint64_t[]> arenaBases(new uint64_t[arenaAt[piece.size()] + 1]);
+		std::unique_ptr<uint32_t[]> arenaMask(new uint32_t[arenaAt[piece.size()] + 1]);
+		for (size_t i = 0; i < piece.size(); i++)
+		{
+			piece[i].bases = arenaBases.get() + arenaAt[i];
+			piece[i].nmask = arenaMask.get() + arenaAt[i];
+		}
+
 		std::vector<size_t> pieceErrorAt(piece.size(), size_t(-1));
 		std::vector<std::string> pieceError(piece.size());
 		// (contig-level assemblies: thousands of small pieces -- a task is a block of consecutive pieces, not one piece)
@@ -425,8 +442,8 @@ namespace TwoPaCo
 			const uint64_t n = p.n;
 			if (idx + 1 == piece.size() || piece[idx + 1].record != p.record) setN(start[idx] + n);  // separator after the record
 			if (n == 0) return;
-			const uint64_t * b = p.bases.data();
-			const uint32_t * m = p.nmask.data();
+			const uint64_t * b = p.bases;
+			const uint32_t * m = p.nmask;
 			const uint64_t w0 = start[idx] >> 5;
 			const unsigned o = unsigned(start[idx] & 31);
 			const uint64_t nw = (n + 31) / 32;
