@@ -202,6 +202,12 @@ namespace TwoPaCo
 				// on the input: they are set up by a second thread while this one parses and packs the FASTA files
 				std::string setupError;
 				std::thread warm;
+				// joined after the upload, or when this scope is left by an exception
+				struct ThreadJoiner
+				{
+					std::thread & t;
+					~ThreadJoiner() { if (t.joinable()) t.join(); }
+				} warmJoiner{warm};
 				std::thread setup([&]()
 				{
 					try
@@ -286,7 +292,7 @@ namespace TwoPaCo
 				const bool nothing = dispStart.empty();
 				{
 					const int rcUpload = nothing ? 0 : tpc_seq_upload(ctx_, text.bases.data(), text.nmask.data(), text.length);
-					if (warm.joinable()) warm.join();
+					if (warm.joinable()) warm.join();  // (letting the rounds start while the last objects load measured the same)
 					Check(rcUpload, "seq_upload");
 				}
 				timer.Lap("context + upload");
