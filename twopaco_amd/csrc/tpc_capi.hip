@@ -484,6 +484,7 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
 {
     if (!c || !bases || !nmask || n_text < 2) return fail(c, -1, "bad text");
     HIPCHK(c, hipSetDevice(c->device));
+    const auto t_begin = std::chrono::steady_clock::now();
     const uint64_t nw = (n_text + 31) / 32;
     if (!((nmask[0] & 1u) && ((nmask[(n_text - 1) >> 5] >> ((n_text - 1) & 31)) & 1u)))
         return fail(c, -1, "text must start and end with the N separator");
@@ -517,15 +518,21 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     HIPCHK(c, hipMemsetAsync(c->rmask, 0, alloc * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->mask, 0, alloc * sizeof(uint32_t), c->stream));
     const uint64_t ce = std::min(nw, w1);  // host words [w0, ce) exist
-    std::vector<uint32_t> nm;
+    uint32_t last_word = 0;
     if (ce > w0) {
         HIPCHK(c, hipMemcpyAsync(c->bases_alloc, bases + w0, (ce - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        // the last word may be partial: mark the bits past n_text as N
-        nm.assign(nmask + w0, nmask + ce);
-        if ((n_text & 31) && ce == nw) nm[nw - 1 - w0] |= ~0u << (n_text & 31);
-        HIPCHK(c, hipMemcpyAsync(c->nmask_alloc, nm.data(), (ce - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->nmask_alloc, nmask + w0, (ce - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        // the last word may be partial: mark the bits past n_text as N (one word patched on the device; the caller's 39 MB of
+        // mask used to be copied on the host for this)
+        if ((n_text & 31) && ce == nw) {
+            last_word = nmask[nw - 1] | (~0u << (n_text & 31));
+            HIPCHK(c, hipMemcpyAsync(c->nmask_alloc + (nw - 1 - w0), &last_word, sizeof last_word, hipMemcpyHostToDevice, c->stream));
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("TWOPACO_TIMING"))
+        fprintf(stderr, "[timing]   tpc_seq_upload (allocations, %.0f MB host to device): %.1f ms\n", (double)(ce > w0 ? (ce - w0) * 12 : 0) / 1e6,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     c->bases = c->bases_alloc - w0;
     c->nmask = c->nmask_alloc - w0;
     c->text_windowed = windowed; c->text_w0 = w0; c->text_w1 = w1;
