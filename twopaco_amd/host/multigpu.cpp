@@ -318,6 +318,33 @@ namespace TwoPaCo
 		return buf[which];
 	}
 
+	void ShardedRank::PhaseBegin()
+	{
+		phaseOn = rank == 0 && std::getenv("TWOPACO_TIMING") != 0;
+		phaseT0 = std::chrono::steady_clock::now();
+	}
+
+	void ShardedRank::Phase(const char * name)
+	{
+		if (!phaseOn) return;
+		const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+		const double ms = std::chrono::duration<double, std::milli>(now - phaseT0).count();
+		phaseT0 = now;
+		for (auto & p : phaseMs) if (p.first == name) { p.second += ms; return; }
+		phaseMs.push_back(std::make_pair(std::string(name), ms));
+	}
+
+	void ShardedRank::PhasePrint(const char * title)
+	{
+		if (!phaseOn) return;
+		std::fprintf(stderr, "[timing]     %s (rank 0, ms):", title);
+		for (auto & p : phaseMs) std::fprintf(stderr, " %s %.1f;", p.first.c_str(), p.second);
+		size_t held = 0;
+		for (int i = 0; i < 16; i++) held += cap[i];
+		std::fprintf(stderr, " exchange buffers held %.2f GB\n", double(held) / 1e9);
+		phaseMs.clear();
+	}
+
 	void ShardedRank::Release()
 	{
 		(void)hipSetDevice(device);
@@ -343,15 +370,20 @@ namespace TwoPaCo
 			void * recvR = r.Ensure(RECV_R, size_t(W) * geom[2]);
 			void * recvC = r.Ensure(RECV_C, size_t(W) * geom[3]);
 			uint64_t overflow = 0;
+			r.Phase("buffers");
 			LibCheck(r.ctx, tpc_shard_hash(r.ctx, pass, batch, lo, hi, sendR, sendC, &overflow), "shard_hash");
+			r.Phase(pass == TPC_SHARD_INSERT ? "insert hash" : "query hash");
 			net.AllToAll(r.rank, sendC, recvC, geom[3]);
+			r.Phase("exchange counts");
 			if (r.compactExchange)
 			{
 				// the fixed-capacity regions are about 3/4 full: pack their used prefixes and move exactly those
 				// (every destination's share is a whole number of 128-byte lines)
 				void * packed = r.Ensure(PACKED, size_t(W) * geom[2]);
 				std::vector<uint64_t> bytes(W), all;
+				r.Phase("buffers");
 				LibCheck(r.ctx, tpc_shard_pack(r.ctx, pass, sendR, sendC, packed, bytes.data()), "shard_pack");
+				r.Phase("pack");
 				net.ExchangeHost(r.rank, bytes.data(), W, all);
 				std::vector<uint64_t> sendUnits(W), recvUnits(W);
 				for (int s = 0; s < W; s++)
@@ -362,6 +394,7 @@ namespace TwoPaCo
 				}
 
 				net.AllToAllV(r.rank, packed, sendUnits.data(), recvR, recvUnits.data(), 16);
+				r.Phase(pass == TPC_SHARD_INSERT ? "insert all-to-all" : "query all-to-all");
 			}
 			else
 			{
@@ -395,6 +428,8 @@ namespace TwoPaCo
 
 				LibCheck(r.ctx, tpc_shard_overflow_set(r.ctx, pass, gathered, total), "shard_overflow_set");
 			}
+
+			r.Phase("overflow lists");
 		}
 
 		// The survivors of the first probe (ids in r.buf[SID]) go back to the rank that hashed their position -- it rides in the id --
@@ -471,32 +506,41 @@ namespace TwoPaCo
 	{
 		const int W = net.Ranks();
 		uint64_t geom[16];
+		r.PhaseBegin();
 		// ---- insert (FilterFillerWorker)
 		LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_INSERT, lo, hi, geom), "shard_plan(insert)");
 		LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
+		r.Phase("plan");
 		for (uint64_t b = 0; b < geom[0]; b++)
 		{
 			HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
 			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+			r.Phase("insert apply");
 		}
 
 		net.Barrier().Wait();  // every shard is complete before anyone probes it
+		r.Phase("barrier");
 		// ---- query (CandidateCheckingWorker)
 		LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_QUERY, lo, hi, geom), "shard_plan(query)");
+		r.Phase("plan");
 		for (uint64_t b = 0; b < geom[0]; b++)
 		{
 			HashAndExchange(r, net, TPC_SHARD_QUERY, geom, b, lo, hi);
 			uint64_t n = 0;
 			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+			r.Phase("query apply");
 			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
 			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
 			n = ReturnSurvivors(r, net, n);
+			r.Phase("survivors home");
 			// function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together
 			if (hashFunctions > 1) n = VerifyStep(r, net, n, 1, 1);
 			if (hashFunctions > 2) n = VerifyStep(r, net, n, 2, hashFunctions - 2);
 			LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");
+			r.Phase("verify + mark");
 		}
 
+		r.PhasePrint("sharded first pass");
 		if (r.shardedSecondPass) return;  // the marks stay on the rank that found them (ShardedSecondPass)
 		// ---- union of the candidate masks: OR all-reduce by word ranges
 		const uint64_t words = tpc_mask_words(r.ctx);

@@ -19,6 +19,9 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <string>
+#include <utility>
 
 struct tpc_ctx;
 
@@ -89,7 +92,14 @@ namespace TwoPaCo
 		// rank); false: union of the candidate masks, the single-GPU second pass on rank 0, which keeps the whole text
 		bool shardedSecondPass;
 		uint64_t regionBytesSent;
-		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
+		// TWOPACO_TIMING=1: host-clock milliseconds per phase of the first pass (every phase ends synchronised), printed by rank 0
+		std::vector<std::pair<std::string, double> > phaseMs;
+		std::chrono::steady_clock::time_point phaseT0;
+		bool phaseOn;
+		void PhaseBegin();
+		void Phase(const char * name);  // time since the previous Phase / PhaseBegin goes to `name`
+		void PhasePrint(const char * title);
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), phaseOn(false) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};
