@@ -302,6 +302,15 @@ uint64_t next_batches(uint64_t b) { return b + std::max<uint64_t>(1, b / 8); }
 
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
+// Bytes of the single-GPU query's buffer i: with three levels the level-3 regions take the place of the level-1 buffer (dead once
+// level 2 has split it), as in the insert -- a batch holds two of the three large buffers, not three.
+size_t qpart_need(const TpcQPlan &pl, int i)
+{
+    if (i == 0) return std::max(tpc_qpart_bytes(pl, 0), tpc_qpart_bytes(pl, 9));
+    if (i == 9) return 0;
+    return tpc_qpart_bytes(pl, i);
+}
+
 // Tile batching of the partitioned query under the buffer budget; false: use the direct kernel.
 bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan &pl)
 {
@@ -312,7 +321,7 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
         const uint64_t per = (tiles + batches - 1) / batches;
         const bool ok = tpc_qpart_plan(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, range_mass(c, lo, hi) * 1.15) : 1.0, pl, c->opt_part_levels);
         if (!ok && per * 512 * TPC_RUN <= (1ull << 30)) return false;  // geometry unsupported (not a size problem)
-        if (ok && ((int64_t)(tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= budget || (int64_t)per <= c->opt_part_min_tiles)) {
+        if (ok && ((int64_t)(qpart_need(pl, 0) + tpc_qpart_bytes(pl, 2)) <= budget || (int64_t)per <= c->opt_part_min_tiles)) {
             // Every batch streams the whole filter through LDS once.  That pays while a slice sees a few thousand probes per
             // batch; below that (sparse huge filters: f >= 39 on the 62-genome input) the direct loads are cheaper.
             // tools/large_filter_bench.py: f=38 3.5 k probes per slice and batch 52 vs 61 ms, f=39 1.8 k 64 vs 61, f=40 0.9 k 99 vs 63.
@@ -584,7 +593,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         for (;; batches = next_batches(batches)) {
             const uint64_t per = (tiles + batches - 1) / batches;
             if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, ins_frac, pl, c->opt_part_levels)) { part = false; break; }
-            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
+            if ((int64_t)(std::max(tpc_part_buf1_bytes(pl), tpc_part_buf3_bytes(pl)) + tpc_part_buf2_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
         }
         // A batch after the first loads and stores every filter slice (2 x 2^L/8 bytes at ~5 TB/s) to save ~40 ps per address
         // against the direct atomics: worth it only above ~2^slice_bits/800 addresses per slice and batch.
@@ -594,12 +603,14 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         }
     }
     if (part) {
-        size_t need[tpc_ctx::NPBUF] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
-                                        pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, tpc_part_buf3_bytes(pl), tpc_part_cnt3_bytes(pl), 0 };
+        // three levels: the level-3 regions take the level-1 buffer's place (its entries are dead once level 2 has split them),
+        // so a batch holds two of the three buffers at a time -- fewer batches, each of which streams the whole filter
+        size_t need[tpc_ctx::NPBUF] = { std::max(tpc_part_buf1_bytes(pl), tpc_part_buf3_bytes(pl)), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                                        pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, 0, tpc_part_cnt3_bytes(pl), 0 };
         // the query of the same round shares these buffers: size them for both now (one allocation, not free + grow)
         TpcQPlan qpl;
         const bool qpart = plan_query(c, lo, hi, gated, qpl);
-        for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
+        for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], qpart_need(qpl, i));
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (need[i]) part = ensure_pbuf(c, i, need[i]);  // not enough HBM: direct path
         // deferred apply: the insert in one batch, the query partitioned with the same slice geometry (its FIRST batch then
         // builds the slices), and room for the insert's level-2 regions beside the query's buffers
@@ -619,7 +630,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     if (part) {
         pl.buf1 = (uint32_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
-        pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
+        pl.buf3 = (uint32_t *)c->pbuf[0]; pl.cnt3 = (uint32_t *)c->pbuf[10];  // level 3 writes where level 1 was (see need[] above)
         if (defer) { pl.buf2 = (uint32_t *)c->ikeep[0]; pl.cnt2 = (uint32_t *)c->ikeep[1]; }
         bool fresh = c->filter_zero_pending;
         unsigned long long ov[2] = {0, 0};
@@ -722,17 +733,17 @@ int tpc_reserve(tpc_ctx *c, uint64_t n_text_max)
         for (uint64_t batches = 1;; batches = next_batches(batches)) {
             const uint64_t per = (tiles + batches - 1) / batches;
             if (!tpc_part_plan(c->P.L, c->P.q, c->opt_slice_bits, per, 1.0, pl, c->opt_part_levels)) { part = false; break; }
-            if ((int64_t)(tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
+            if ((int64_t)(std::max(tpc_part_buf1_bytes(pl), tpc_part_buf3_bytes(pl)) + tpc_part_buf2_bytes(pl)) <= budget || (int64_t)per <= c->opt_part_min_tiles) break;
         }
     }
     if (part) {
-        const size_t ins[tpc_ctx::NPBUF] = { tpc_part_buf1_bytes(pl), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
-                                             pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, tpc_part_buf3_bytes(pl), tpc_part_cnt3_bytes(pl), 0 };
+        const size_t ins[tpc_ctx::NPBUF] = { std::max(tpc_part_buf1_bytes(pl), tpc_part_buf3_bytes(pl)), tpc_part_cnt1_bytes(pl), tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl),
+                                             pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long), 0, 0, 0, 0, tpc_part_cnt3_bytes(pl), 0 };
         for (int i = 0; i < tpc_ctx::NPBUF; i++) need[i] = ins[i];
     }
     TpcQPlan qpl;
     const bool qpart = plan_query(c, 0, c->P.lmask + 1, false, qpl);
-    for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], tpc_qpart_bytes(qpl, i));
+    for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], qpart_need(qpl, i));
     c->n_text = keep;
     for (int i = 0; i < tpc_ctx::NPBUF; i++)
         if (need[i] && !ensure_pbuf(c, i, need[i])) return 0;  // not enough memory now: the passes decide again when they run
@@ -801,7 +812,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     const uint64_t tiles = text_tiles512(c);
     bool part = plan_query(c, lo, hi, gated, pl);
     if (part)
-        for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (tpc_qpart_bytes(pl, i)) part = ensure_pbuf(c, i, tpc_qpart_bytes(pl, i));  // not enough HBM: direct path
+        for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (qpart_need(pl, i)) part = ensure_pbuf(c, i, qpart_need(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
     const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
                        pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2;
@@ -815,7 +826,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             HIPCHK(c, hipMemcpy(c->pbuf[8], pl.off2_host.data(), pl.off2_host.size() * 8, hipMemcpyHostToDevice));
             c->off2_uploaded = pl.off2_host;
         }
-        pl.buf3 = (uint64_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];
+        pl.buf3 = (uint64_t *)c->pbuf[0]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];  // qpart_need
         if (pl.b3 && c->off3_uploaded != pl.off3_host) {
             HIPCHK(c, hipMemcpy(c->pbuf[11], pl.off3_host.data(), pl.off3_host.size() * 8, hipMemcpyHostToDevice));
             c->off3_uploaded = pl.off3_host;
