@@ -55,7 +55,7 @@ def run(text, args, mode, tab, ranges, fetch):
     t0 = time.time()
     ctx.seq_upload(text)
     up = time.time() - t0
-    for rep in range(max(1, args.repeat if mode == 0 else 1)):  # --repeat 2: the second pass runs with every buffer allocated ("warm")
+    for rep in range(max(1, args.repeat if mode != 1 else 1)):  # --repeat 2: the second pass runs with every buffer allocated ("warm")
         ctx.run_begin()
         rounds = []
         t_all = time.time()
@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--sample", type=int, default=20000)
     ap.add_argument("--repeat", type=int, default=1, help="passes of the partitioned run on the same context; the last one is reported")
     ap.add_argument("--json", default="")
+    ap.add_argument("--force-mode", type=int, default=0, help="insert_mode / query_mode of the first run: 0 automatic, 2 the partitioned passes whatever the plan's own estimate says")
     args = ap.parse_args()
     n = int(args.len)
     t0 = time.time()
@@ -188,7 +189,7 @@ def main():
         args.genomes, n, text.length / 1e9, np.log2(text.length), kmers / 1e9, gen_s), flush=True)
     tab = capi.seed_table(args.q, args.L, seed=20240229)
     ranges = [(0, 1 << args.L)] if args.rounds == 1 else vertex_ranges(args.L, args.rounds)
-    a = run(text, args, 0, tab, ranges, fetch=True)
+    a = run(text, args, args.force_mode, tab, ranges, fetch=True)
     summary = {"genomes": args.genomes, "len": n, "positions": int(text.length), "k": args.k, "L": args.L, "q": args.q, "rounds": args.rounds,
                "kmers_estimate": kmers, "generate_pack_s": gen_s}
     for r in a["rounds"]:
