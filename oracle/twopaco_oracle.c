@@ -30,12 +30,13 @@
 #include <sys/mman.h>
 
 #define ORC_N 4
+#define ORC_MAXQ 64 /* the reference takes any -q (constructor.cpp:83-90); 64 is what the product accepts */
 #define ORC_INVALID_VERTEX INT64_MAX /* graphconstructor/common.cpp:5 */
 
 typedef struct {
     int k, L, q;
-    uint64_t h[16][5];  /* h[i][c]: character table of hash fn i, c in A,C,G,T,N */
-    uint64_t hk[16][5]; /* rotl_L(h[i][c], k mod L) */
+    uint64_t h[ORC_MAXQ][5];  /* h[i][c]: character table of hash fn i, c in A,C,G,T,N */
+    uint64_t hk[ORC_MAXQ][5]; /* rotl_L(h[i][c], k mod L) */
     /* text */
     uint8_t *txt;
     uint64_t ntxt, captxt;
@@ -177,7 +178,7 @@ static inline uint64_t rotln(uint64_t x, int L, int r)
 }
 static inline int rc(int c) { return c == ORC_N ? ORC_N : 3 - c; } /* dnachar.cpp:52-58 */
 
-typedef struct { uint64_t pos[16], neg[16]; } orc_vhash;
+typedef struct { uint64_t pos[ORC_MAXQ], neg[ORC_MAXQ]; } orc_vhash;
 
 /* VertexRollingHash ctor, vertexrollinghash.h:79-102: pos = eat left to right,
  * neg = eat reverse complement (right to left). eat: cyclichash.h:106-109 */
@@ -212,7 +213,7 @@ static inline uint64_t vh_vertex(const orc_vhash *v)
  * GetOutgoingEdgeHash (:157-168); hash_extend cyclichash.h:112-114, hash_prepend :117-121 */
 static void edge_out(const orc_run *R, const orc_vhash *v, int c, uint64_t *addr)
 {
-    uint64_t p[16], n[16];
+    uint64_t p[ORC_MAXQ], n[ORC_MAXQ];
     int neg = 0;
     for (int i = 0; i < R->q; i++) {
         p[i] = rotl1(v->pos[i], R->L) ^ R->h[i][c];
@@ -226,7 +227,7 @@ static void edge_out(const orc_run *R, const orc_vhash *v, int c, uint64_t *addr
 /* Ingoing edge c+v: DetermineStrandPrepend (:186-200), GetIngoingEdgeHash (:144-155) */
 static void edge_in(const orc_run *R, const orc_vhash *v, int c, uint64_t *addr)
 {
-    uint64_t p[16], n[16];
+    uint64_t p[ORC_MAXQ], n[ORC_MAXQ];
     int neg = 0;
     for (int i = 0; i < R->q; i++) {
         p[i] = R->hk[i][c] ^ v->pos[i];
@@ -261,7 +262,7 @@ static int filter_zero(orc_run *R)
 
 orc_run *orc_create(int k, int L, int q, const uint64_t *table)
 {
-    if (q < 1 || q > 16 || L < 2 || L > 62 || k < 1) return NULL;
+    if (q < 1 || q > ORC_MAXQ || L < 2 || L > 62 || k < 1) return NULL;
     orc_run *R = (orc_run *)calloc(1, sizeof(orc_run));
     R->k = k; R->L = L; R->q = q;
     for (int i = 0; i < q; i++)
@@ -513,7 +514,7 @@ static void split_pass(orc_run *R, uint32_t *bins, uint64_t bin_size)
     uint64_t nw = filter_words(R);
     uint32_t *f = (uint32_t *)mmap(NULL, nw * sizeof(uint32_t), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (f == MAP_FAILED) abort();
-    uint64_t addr[16];
+    uint64_t addr[ORC_MAXQ];
     orc_vhash v;
     for (uint32_t r = 0; r < R->nrec; r++) {
         uint64_t len = R->rec_len[r];
@@ -546,7 +547,7 @@ static void split_pass(orc_run *R, uint32_t *bins, uint64_t bin_size)
 /* FilterFillerWorker VE.h:995-1105 over the global text. */
 static void fill_pass(orc_run *R, const uint32_t *run, uint64_t low, uint64_t high)
 {
-    uint64_t addr[16];
+    uint64_t addr[ORC_MAXQ];
     orc_vhash v;
     int have = 0;
     for (uint64_t g = 1; g + R->k < R->ntxt; g++) {
@@ -584,7 +585,7 @@ static int in_bloom(const orc_run *R, const uint64_t *addr)
 /* CandidateCheckingWorker VE.h:586-704 */
 static uint64_t check_pass(orc_run *R, const uint32_t *run, uint64_t low, uint64_t high)
 {
-    uint64_t addr[16], marks = 0;
+    uint64_t addr[ORC_MAXQ], marks = 0;
     orc_vhash v;
     int have = 0;
     for (uint64_t g = 1; g + R->k < R->ntxt; g++) {

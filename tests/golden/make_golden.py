@@ -190,6 +190,10 @@ def main():
     case("lk_k603_r2", "lk.fa", 603, 24, rounds=2)
     case("lk_k159", "lk.fa", 159, 20)
     case("rand6_k9_q12", "rand6.fa", 9, 20, q=12)
+    # more than 16 hash functions (the reference takes any -q, constructor.cpp:83-90): the closed-form kernels of tpc_pass1_anyq.hip;
+    # _fp: a filter small enough for Bloom false positives, two rounds (the split pass with 20 functions)
+    case("rand6_k9_q20", "rand6.fa", 9, 22, q=20)
+    case("rand6_k9_q20_fp_r2", "rand6.fa", 9, 18, q=20, rounds=2)
     # collision-free multi-round runs: "first seen" in the split pass (VE.h:559-570) is then order independent,
     # so the round ranges (VE.h:206-254) below are what ANY correct implementation must print
     case("rand6_k9_L24_r4", "rand6.fa", 9, 24, rounds=4)

@@ -454,6 +454,63 @@ def test_split_histogram_structural_collisions_k_ge_L(capi, tmp_path):
             assert int(np.abs(d).max()) <= 2 and int((d != 0).sum()) <= 0.01 * int((bins > 0).sum())
 
 
+@pytest.mark.parametrize("name", ["rand6_k9_fp_r4", "edge_k5", "rand6_k9_q12", "c2_k51_r2", "rand6_k9_L33"])
+def test_closed_form_kernels_of_q_beyond_16_on_small_q(capi, tmp_path, name):
+    """The closed-form first-pass kernels that serve -q 17..64 (csrc/tpc_pass1_anyq.hip; the reference takes any -q,
+    constructor.cpp:83-90), forced onto goldens with q <= 16: filter bitmap, marks and candidate mask of every round
+    (gated ranges, N-adjacent dummy edges, strand ties) == the oracle's; their own goldens (rand6_k9_q20*) run in the sweeps above."""
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    o.enumerate(rounds=case["n_rounds"])
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    ctx.set_option("test_force_anyq", 1)  # process-wide: always reset below
+    try:
+        ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+        ctx.seq_upload(text)
+        for r in range(case["n_rounds"]):
+            st = o.round_stats(r)
+            ctx.filter_reset()
+            assert ctx.pass1_insert(st["low"], st["high"]) > 0
+            assert ctx.stat("insert_path") == 1
+            if r == case["n_rounds"] - 1:
+                assert (ctx.filter_download() == o.filter).all(), "Bloom filter bitmap differs"
+            assert ctx.pass1_query(st["low"], st["high"]) == st["marks"] and ctx.stat("query_path") == 1
+            if r == case["n_rounds"] - 1:
+                assert (ctx.mask_download(False) == o.round_mask).all(), "candidate mask differs"
+            assert ctx.pass2_filter() == {"true": st["true"], "false": st["false"], "table": st["table"]}
+    finally:
+        ctx.set_option("test_force_anyq", 0)
+        ctx.close()
+
+
+def test_closed_form_split_histogram(capi, tmp_path):
+    """k_split_anyq == the oracle's histogram bin for bin on a collision-free scratch filter (as k_split, above)."""
+    case = [c for c in CASES if c["name"] == "rand6_k9_L24_r4"][0]
+    probe = capi.Context(0)
+    probe.set_option("test_force_anyq", 1)
+    try:
+        got, bins = _split_hist(capi, case, tmp_path)
+    finally:
+        probe.set_option("test_force_anyq", 0)
+        probe.close()
+    assert int(bins.sum()) > 0 and (got == bins).all()
+
+
+def test_q_beyond_16_runs_on_one_gpu_and_is_refused_by_a_sharded_filter(capi, tmp_path):
+    """-q 20 through the CLI-level factory writes the reference's bytes; a sharded context refuses its plan with a message (the
+    multi-GPU host then repeats the run on one GPU)."""
+    case = [c for c in CASES if c["name"] == "rand6_k9_q20_fp_r2"][0]
+    out = str(tmp_path / "q20.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=20, rounds=2, tmpdir=str(tmp_path), out=out, seed=case["seed"])
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read() and e.vertices_count() == case["distinct"]
+    e.close()
+    out2 = str(tmp_path / "q20s.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=20, rounds=1, tmpdir=str(tmp_path), out=out2, seed=case["seed"], gpus=2, emulate_ranks=True)
+    assert open(out2, "rb").read() == open(os.path.join(GOLDEN, case["bin"]), "rb").read()  # one-GPU fallback
+    e.close()
+
+
 def test_m1_full_size_bytes_equal_reference(capi, tmp_path):
     """BASELINE.json configs[1] at full size (8 x 5 Mbp, k=25, f=32): the sha256 of the GPU path's
     de_bruijn.bin equals the one the real reference produced (tests/golden/make_golden.py)."""

@@ -88,8 +88,8 @@ def run(text, args, mode, tab, ranges, fetch):
         out["ids_sha"] = sha(g) + sha(ids)
         out["_keys"], out["_g"], out["_ids"] = keys, g, ids
         rs, rl = text.rec_start, text.rec_length
-        nb, nr = ctypes_stream(ctx, rs, rl)
-        out["stream_bytes"], out["stream_records"] = nb, nr
+        nb, nr, ssha = ctypes_stream(ctx, rs, rl)
+        out["stream_bytes"], out["stream_records"], out["stream_sha"] = nb, nr, ssha
     ctx.close()
     return out
 
@@ -100,7 +100,14 @@ def ctypes_stream(ctx, rs, rl):
     rl = np.ascontiguousarray(rl, dtype=np.uint64)
     nb, nr = ctypes.c_uint64(0), ctypes.c_uint64(0)
     ctx._ck(capi.hip().tpc_emit_stream(ctx._h, rs.ctypes.data, rl.ctypes.data, rs.size, ctypes.byref(nb), ctypes.byref(nr)))
-    return nb.value, nr.value
+    h = hashlib.sha256()  # the bytes of de_bruijn.bin as the device formatted them, fetched in 256 MiB pieces
+    buf = np.zeros(min(nb.value, 1 << 28), dtype=np.uint8)
+    for off in range(0, nb.value, 1 << 28):
+        m = min(1 << 28, nb.value - off)
+        if capi.hip().tpc_emit_stream_fetch(ctx._h, off, m, buf.ctypes.data) != 0:
+            raise RuntimeError("tpc_emit_stream_fetch failed")
+        h.update(memoryview(buf)[:m])
+    return nb.value, nr.value, h.hexdigest()[:16]
 
 
 def host_ids(text, args, tab, keys, g, ids, sample, seed=1):
@@ -153,30 +160,56 @@ def host_ids(text, args, tab, keys, g, ids, sample, seed=1):
     return pick.size, bad
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--genomes", type=int, default=7)
-    ap.add_argument("--len", type=float, default=3.1e9)
-    ap.add_argument("--k", type=int, default=25)
-    ap.add_argument("--L", type=int, default=38)
-    ap.add_argument("--q", type=int, default=5)
-    ap.add_argument("--rounds", type=int, default=1)
-    ap.add_argument("--div", type=float, default=0.001, help="substitution rate of every genome against the common root")
-    ap.add_argument("--budget-gb", type=float, default=0)
-    ap.add_argument("--no-direct", action="store_true", help="skip the comparison run on the direct kernels")
-    ap.add_argument("--sample", type=int, default=20000)
-    ap.add_argument("--repeat", type=int, default=1, help="passes of the partitioned run on the same context; the last one is reported")
-    ap.add_argument("--json", default="")
-    ap.add_argument("--force-mode", type=int, default=0, help="insert_mode / query_mode of the first run: 0 automatic, 2 the partitioned passes whatever the plan's own estimate says")
-    args = ap.parse_args()
+def enumerator_leg(recs_files, args, stream_sha, stream_bytes, n_rec, tmpdir):
+    """The same input through CreateEnumerator (host/vertexenumerator.cpp: FASTA parse, device split pass when rounds > 1,
+    junction stream written to a file; reference VE.h:122-466).  The file's bytes do not depend on where the round boundaries
+    fall -- a Bloom false positive never gets an id -- so its sha256 must equal the C-ABI run's stream, whose rounds were cut
+    at the analytic quantiles; its size is 12 x (records + separators) (junctionapi.h:118-126)."""
+    import re
+    out = os.path.join(tmpdir, "big.bin")
+    t0 = time.time()
+    e = capi.Enumerator(recs_files, args.k, args.L, q=args.q, rounds=args.rounds, tmpdir=tmpdir, out=out, seed=20240229, threads=min(64, os.cpu_count() or 1))
+    wall = time.time() - t0
+    log = e.log
+    e.close()
+    rounds = [(int(a), int(b)) for a, b in re.findall(r"Round \d+, (\d+):(\d+)", log)]
+    tj = [int(x) for x in re.findall(r"True junctions count = (\d+)", log)]
+    fj = [int(x) for x in re.findall(r"False junctions count = (\d+)", log)]
+    ht = [int(x) for x in re.findall(r"Hash table size = (\d+)", log)]
+    records = int(re.search(r"True marks count: (\d+)", log).group(1))
+    size = os.path.getsize(out)
+    assert len(rounds) == args.rounds and len(tj) == args.rounds, log
+    assert rounds[0][0] == 0 and all(rounds[i + 1][0] == rounds[i][1] + 1 for i in range(args.rounds - 1)), rounds  # VE.h:234-254
+    assert all(t + f == h for t, f, h in zip(tj, fj, ht)), (tj, fj, ht)   # VE.h:384-388
+    assert size == 12 * (records + (n_rec - 1)), (size, records, n_rec)    # every sequence of these inputs is long enough to emit
+    h = hashlib.sha256()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    os.unlink(out)
+    assert size == stream_bytes and h.hexdigest()[:16] == stream_sha, "CreateEnumerator's file differs from the C-ABI run's junction stream"
+    if args.rounds > 1:
+        assert "Splitting the input kmers set..." in log
+    print("CreateEnumerator: %.1f s wall, %d rounds %s, junctions %d, records %d, file %d bytes == 12 x (records + separators), sha256 == C-ABI stream" % (
+        wall, args.rounds, rounds, sum(tj), records, size), flush=True)
+    return {"wall_s": wall, "rounds": rounds, "true": tj, "false": fj, "table": ht, "records": records, "file_bytes": size}
+
+
+def check(args):
+    """Runs the configuration and every check; returns the summary (raises AssertionError on any difference)."""
     n = int(args.len)
     t0 = time.time()
     root = synth.random_genome(n, 12345)
     text = capi.PackedText()
     kmers = 0
+    files = []
+    fasta_dir = getattr(args, "fasta_dir", "") or ""
     for gidx in range(args.genomes):
         rec = synth.add_n_runs(synth.substitute(root, args.div, 4000 + gidx), 2e-6, 5000 + gidx)
         capi.host().tpch_text_add_codes(text._h, rec.ctypes.data, rec.size)
+        if fasta_dir:
+            files.append(os.path.join(fasta_dir, "big_%d.fa" % gidx))
+            synth.write_fasta(files[-1], [rec], first_id=gidx)
         bad = np.flatnonzero(rec == 4)
         kmers += rec.size - args.k + 1
         if bad.size:  # windows that hold an N: the N characters plus k - 1 positions before every run (runs are far apart)
@@ -213,6 +246,7 @@ def main():
     summary["partitioned"] = a
     summary["host_id_sample"] = checked
     ins = sum(r["insert_kernel_ms"] for r in a["rounds"]); qry = sum(r["query_kernel_ms"] for r in a["rounds"])
+    summary["kmers_per_s"] = kmers * 1.0 / a["whole_s"]
     print("partitioned: insert %.1f ms, query %.1f ms, whole path %.3f s = %.2f G k-mers/s (x %d rounds of hashing); marks %d junctions %d occurrences %d; stream %d bytes" % (
         ins, qry, a["whole_s"], kmers * 1.0 / a["whole_s"] / 1e9, args.rounds, sum(r["marks"] for r in a["rounds"]), a["junctions"], a["occurrences"], a["stream_bytes"]), flush=True)
     if not args.no_direct:
@@ -220,13 +254,43 @@ def main():
         b = run(text, args, 1, tab, ranges, fetch=True)
         for kname in ("_keys", "_g", "_ids"):
             b.pop(kname)
-        same = all(b[x] == a[x] for x in ("junctions", "marked", "occurrences", "mask_sha", "keys_sha", "ids_sha", "stream_bytes", "stream_records"))
+        same = all(b[x] == a[x] for x in ("junctions", "marked", "occurrences", "mask_sha", "keys_sha", "ids_sha", "stream_bytes", "stream_records", "stream_sha"))
         same = same and all(all(ra[x] == rb[x] for x in ("marks", "true", "false", "table")) for ra, rb in zip(a["rounds"], b["rounds"]))
-        print("direct kernels: insert %.1f ms, query %.1f ms, whole path %.3f s; partitioned == direct (mask sha, counters, keys sha, ids sha): %s" % (
+        print("direct kernels: insert %.1f ms, query %.1f ms, whole path %.3f s; partitioned == direct (mask sha, counters, keys sha, ids sha, stream sha): %s" % (
             sum(r["insert_kernel_ms"] for r in b["rounds"]), sum(r["query_kernel_ms"] for r in b["rounds"]), b["whole_s"], same), flush=True)
         summary["direct"] = b
         summary["partitioned_equals_direct"] = same
         assert same
+    if fasta_dir:
+        del text
+        summary["enumerator"] = enumerator_leg(files, args, a["stream_sha"], a["stream_bytes"], n_rec, fasta_dir)
+        for f in files:
+            os.unlink(f)
+    return summary
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genomes", type=int, default=7)
+    ap.add_argument("--len", type=float, default=3.1e9)
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--L", type=int, default=38)
+    ap.add_argument("--q", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=1)
+    ap.add_argument("--div", type=float, default=0.001, help="substitution rate of every genome against the common root")
+    ap.add_argument("--budget-gb", type=float, default=0)
+    ap.add_argument("--no-direct", action="store_true", help="skip the comparison run on the direct kernels")
+    ap.add_argument("--sample", type=int, default=20000)
+    ap.add_argument("--repeat", type=int, default=1, help="passes of the partitioned run on the same context; the last one is reported")
+    ap.add_argument("--json", default="")
+    ap.add_argument("--force-mode", type=int, default=0, help="insert_mode / query_mode of the first run: 0 automatic, 2 the partitioned passes whatever the plan's own estimate says")
+    ap.add_argument("--fasta-dir", default="", help="also write the genomes as FASTA files there and run them through CreateEnumerator (file size, counters, sha256 == the C-ABI stream)")
+    return ap
+
+
+def main():
+    args = parser().parse_args()
+    summary = check(args)
     if args.json:
         with open(args.json, "a") as f:
             f.write(json.dumps(summary) + "\n")

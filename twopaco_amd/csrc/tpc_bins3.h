@@ -33,10 +33,14 @@ struct Bins3 {
     static constexpr int NB_MAX = 512;
     static constexpr int WAVES = THREADS / 64;
     static constexpr T SENT = (T)~(T)0;
-    static constexpr uint32_t OFF_TAIL = PT_BIN_BYTES, OFF_LIMIT = OFF_TAIL + NB_MAX * 4, OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_CNTDOWN = OFF_DONE + 64, OFF_END = OFF_CNTDOWN + 64;
-    static_assert(PT_BIN_BYTES == 131072 && PT_LINE == 128, "layout constants");
+    // The control words sit BELOW the rings: with the workgroup's dynamic LDS starting at address 0 their offsets (and the rings'
+    // base, 4224) fit the 16-bit immediate of the DS instructions, so a push forms no address beyond `bin << 2` (round 3 had
+    // the rings first: every tail / limit access paid a v_add of a 131072+ base that no immediate can hold).
+    static constexpr uint32_t OFF_TAIL = 0, OFF_LIMIT = OFF_TAIL + NB_MAX * 4, OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_CNTDOWN = OFF_DONE + 64, OFF_RINGS = OFF_CNTDOWN + 64,
+                              OFF_END = OFF_RINGS + PT_BIN_BYTES;
+    static_assert(PT_BIN_BYTES == 131072 && PT_LINE == 128 && OFF_RINGS % PT_LINE == 0, "layout constants");
 
-    unsigned char *base;   // LDS: rings at 0, then tail, limit, done, cntdown
+    unsigned char *base;   // LDS: tail, limit, done, cntdown, then the rings
     unsigned char *gbase;  // the global buffer all regions live in + this lane's 16-byte column of a line
     uint32_t LOG_NB, LOG_CAP, CAP, LOG_GPB;  // GPB = ring groups per bin
     uint32_t my_bin, my_slot;     // the bin and the ring-group slot inside it that this lane owns
@@ -97,7 +101,7 @@ struct Bins3 {
 #pragma unroll
         for (int i = 0; i < N; i++) {
             if (ok[i]) {
-                if (slot[i] < lim[i]) *reinterpret_cast<T *>(base + (((b[i] << LOG_CAP) | (slot[i] & (CAP - 1u))) << LOG_T)) = val[i];
+                if (slot[i] < lim[i]) *reinterpret_cast<T *>(base + OFF_RINGS + (((b[i] << LOG_CAP) | (slot[i] & (CAP - 1u))) << LOG_T)) = val[i];
                 else pend |= 1u << i;
             }
         }
@@ -119,7 +123,7 @@ struct Bins3 {
                     for (uint32_t w = w0; w < w0 + nw; w++) owners_done = owners_done && __hip_atomic_load(&done()[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == flushes;
                     const uint32_t l2 = __hip_atomic_load(&limit()[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (si < l2) {
-                        *reinterpret_cast<T *>(base + (((bi << LOG_CAP) | (si & (CAP - 1u))) << LOG_T)) = vi;
+                        *reinterpret_cast<T *>(base + OFF_RINGS + (((bi << LOG_CAP) | (si & (CAP - 1u))) << LOG_T)) = vi;
                         pend &= ~(1u << i);
 #ifdef TPC_BINS3_DEBUG
                         if (dbg) atomicAdd(dbg + 3, 1ull);
@@ -176,7 +180,7 @@ struct Bins3 {
         }
         // copy-out: 8 lanes per 128-byte group, 16 bytes per lane
         constexpr int EPL = 16 / (int)sizeof(T);
-        const unsigned char *ring = base + (wave << 13) + l * 16u;  // this wave's 64 ring groups
+        const unsigned char *ring = base + OFF_RINGS + (wave << 13) + l * 16u;  // this wave's 64 ring groups
         for (uint32_t i0 = 0; i0 < cnt; i0 += 8u) {  // uniform trip count: the crossbar reads need every SOURCE lane active
             const uint32_t i = i0 + (lane >> 3);
             uint2 it;

@@ -4,6 +4,7 @@
 #include "tpc_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -119,6 +120,9 @@ struct tpc_ctx {
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
+    // debug switches, read from the environment once per context (not on every pass)
+    bool dbg_ovf = false, dbg_phases = false, dbg_timing = false, no_lean = false;
+    uint64_t reserve_text_bytes = 0;  // tpc_reserve ran before the upload: bytes the text will need, kept out of the buffer budget
 };
 
 namespace {
@@ -165,12 +169,12 @@ uint64_t rotln_host(uint64_t x, int L, int r)
 // Device allocations of the second pass and the output (mark list, exact-filter table, keys, ids, junction stream).  The first
 // pass' partition buffers stay allocated between rounds and may hold 60 % of the device (part_budget): when one of these
 // allocations does not fit, they are given back (the next first pass allocates them again) and the allocation is repeated.
-int tpc_test_fail_mallocs = 0;  // option "test_fail_mallocs" (tests only, process-wide): the next N first attempts fail
+std::atomic<int> tpc_test_fail_mallocs{0};  // option "test_fail_mallocs" (tests only, process-wide; contexts of a multi-GPU host allocate from several threads): the next N first attempts fail
 bool release_partition_buffers(tpc_ctx *c);
 hipError_t dev_malloc(tpc_ctx *c, void **p, size_t bytes)
 {
     hipError_t e = hipErrorOutOfMemory;
-    if (tpc_test_fail_mallocs > 0) { --tpc_test_fail_mallocs; *p = nullptr; } else e = hipMalloc(p, bytes);
+    if (tpc_test_fail_mallocs.load(std::memory_order_relaxed) > 0 && tpc_test_fail_mallocs.fetch_sub(1) > 0) *p = nullptr; else e = hipMalloc(p, bytes);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
     if (!release_partition_buffers(c)) return e;
@@ -274,6 +278,7 @@ bool release_partition_buffers(tpc_ctx *c)
     for (size_t &b : c->ikeep_bytes) b = 0;
     c->off2_uploaded.clear();
     c->off3_uploaded.clear();
+    c->sh_have[0] = c->sh_have[1] = false;  // the sharded plans hold pointers into the buffers just freed: tpc_shard_plan again before any tpc_shard_* call
     c->stat_pbuf_releases++;
     return true;
 }
@@ -293,7 +298,10 @@ int64_t part_budget(const tpc_ctx *c)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (int64_t)40 << 30; }
     size_t held = 0;
     for (size_t b : c->pbytes) held += b;
-    return std::max<int64_t>((int64_t)40 << 30, (int64_t)((double)(free_b + held) * 0.60));
+    // tpc_reserve before tpc_seq_upload: the text (bases, N mask, two candidate masks: 20 bytes per 32 positions) is not resident
+    // yet and must not be counted as free.  The 40 GiB floor only holds while that much is really there.
+    const double avail = std::max(0.0, (double)(free_b + held) - (double)(c->bases ? 0 : c->reserve_text_bytes));
+    return std::max<int64_t>(std::min<int64_t>((int64_t)40 << 30, (int64_t)(avail * 0.90)), (int64_t)(avail * 0.60));
 }
 
 // Batch counts tried in turn: every count up to 8, then steps of ~1/8 -- each batch streams the whole filter once, so a text that
@@ -311,10 +319,22 @@ size_t qpart_need(const TpcQPlan &pl, int i)
     return tpc_qpart_bytes(pl, i);
 }
 
+// Can the partitioned (LDS write-combining) passes hash with this context's parameters?  One gate for tpc_pass1_insert,
+// tpc_pass1_query, tpc_reserve and tpc_shard_plan: the rolling kernels exist for 1..16 functions; 9..16 run on the
+// instruction-lean hash kernel only (tpc_partition.hip:launch_hash_q), which takes a slice index of at most 24 bits and can be
+// switched off (TPC_NO_LEAN, measurements); the test hook that forces the closed-form kernels means the direct path too.
+bool part_hash_supported(const tpc_ctx *c)
+{
+    if (c->P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return false;
+    if (c->P.q > 8 && (c->P.L - c->opt_slice_bits > 24 || c->no_lean)) return false;
+    return true;
+}
+
 // Tile batching of the partitioned query under the buffer budget; false: use the direct kernel.
 bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan &pl)
 {
     const uint64_t tiles = text_tiles512(c);
+    if (c->P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return false;  // the verification kernels are the rolling ones
     if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
     const int64_t budget = part_budget(c);
     for (uint64_t batches = 1;; batches = next_batches(batches)) {
@@ -366,6 +386,7 @@ int tpc_ctx_create(int device, tpc_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return -4;
     tpc_ctx *c = new tpc_ctx();
     c->device = device;
+    c->dbg_ovf = getenv("TPC_DEBUG_OVF") != nullptr; c->dbg_phases = getenv("TPC_PROFILE_PHASES") != nullptr; c->dbg_timing = getenv("TWOPACO_TIMING") != nullptr; c->no_lean = getenv("TPC_NO_LEAN") != nullptr;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
     for (int i = 0; i < TPC_K_COUNT; i++) {
         if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { delete c; return -5; }
@@ -411,7 +432,8 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
-    if (!strcmp(name, "test_fail_mallocs")) { tpc_test_fail_mallocs = value > 0 ? (int)value : 0; return 0; }  // process-wide, tests only
+    if (!strcmp(name, "test_force_anyq")) { tpc_test_force_anyq = value != 0; return 0; }  // process-wide, tests only
+    if (!strcmp(name, "test_fail_mallocs")) { tpc_test_fail_mallocs.store(value > 0 ? (int)value : 0); return 0; }  // process-wide, tests only
     return fail(c, -1, "unknown option %s", name);
 }
 
@@ -517,11 +539,12 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
         if (p) (void)hipFree(p);
     c->bases = nullptr; c->nmask = nullptr; c->bases_alloc = nullptr; c->nmask_alloc = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
     const uint64_t wn = w1 - w0;
-    HIPCHK(c, hipMalloc((void **)&c->bases_alloc, wn * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void **)&c->nmask_alloc, wn * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->rmask, alloc * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->mask, alloc * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->block_sums, (alloc / 256 + 2) * sizeof(uint64_t)));
+    // through dev_malloc: a reservation made before the upload (tpc_reserve) is given back when the text does not fit beside it
+    HIPCHK(c, dev_malloc(c, (void **)&c->bases_alloc, wn * sizeof(uint64_t)));
+    HIPCHK(c, dev_malloc(c, (void **)&c->nmask_alloc, wn * sizeof(uint32_t)));
+    HIPCHK(c, dev_malloc(c, (void **)&c->rmask, alloc * sizeof(uint32_t)));
+    HIPCHK(c, dev_malloc(c, (void **)&c->mask, alloc * sizeof(uint32_t)));
+    HIPCHK(c, dev_malloc(c, (void **)&c->block_sums, (alloc / 256 + 2) * sizeof(uint64_t)));
     HIPCHK(c, hipMemsetAsync(c->bases_alloc, 0, wn * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->nmask_alloc, 0xFF, wn * sizeof(uint32_t), c->stream));  // padding = N
     HIPCHK(c, hipMemsetAsync(c->rmask, 0, alloc * sizeof(uint32_t), c->stream));
@@ -539,7 +562,7 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("TWOPACO_TIMING"))
+    if (c->dbg_timing)
         fprintf(stderr, "[timing]   tpc_seq_upload (allocations, %.0f MB host to device): %.1f ms\n", (double)(ce > w0 ? (ce - w0) * 12 : 0) / 1e6,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     c->bases = c->bases_alloc - w0;
@@ -584,9 +607,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     const uint64_t tiles = text_tiles512(c);
     uint64_t batches = 1;
     bool defer = false;
-    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28);  // small filters: the direct kernel is as fast
-    // 9..16 hash functions run on the instruction-lean hash kernel only (tpc_partition.hip), which takes a 24-bit slice index
-    if (c->P.q > 8 && c->P.L - c->opt_slice_bits > 24) part = false;
+    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && part_hash_supported(c);  // small filters: the direct kernel is as fast
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);
@@ -689,7 +710,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         c->filter_zero_pending = false;
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (getenv("TPC_DEBUG_OVF"))
+        if (c->dbg_ovf)
             fprintf(stderr, "[ovf] insert: %llu overflow entries (cap %llu, flag %llu) b1=%d b2=%d ppr=%d cap1=%llu cap2=%llu nwg1=%u\n", ov[0], (unsigned long long)pl.ovf_cap, ov[1], pl.b1,
                     pl.b2, pl.pos_per_round, (unsigned long long)pl.cap1, (unsigned long long)pl.cap2, pl.nwg1);
         overflowed = overflowed || ov[1] != 0;
@@ -724,10 +745,11 @@ int tpc_reserve(tpc_ctx *c, uint64_t n_text_max)
     // the same planning as an ungated tpc_pass1_insert / tpc_pass1_query of a text of n_text_max positions
     const uint64_t keep = c->n_text;
     c->n_text = n_text_max;
+    c->reserve_text_bytes = c->bases ? 0 : (n_text_max / 32 + 1024) * 20;
     const uint64_t tiles = text_tiles512(c);
     size_t need[tpc_ctx::NPBUF] = {};
     TpcPartPlan pl;
-    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && !(c->P.q > 8 && c->P.L - c->opt_slice_bits > 24);
+    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && part_hash_supported(c);
     if (part) {
         const int64_t budget = part_budget(c);
         for (uint64_t batches = 1;; batches = next_batches(batches)) {
@@ -746,7 +768,10 @@ int tpc_reserve(tpc_ctx *c, uint64_t n_text_max)
     for (int i = 0; i < tpc_ctx::NPBUF && qpart; i++) need[i] = std::max(need[i], qpart_need(qpl, i));
     c->n_text = keep;
     for (int i = 0; i < tpc_ctx::NPBUF; i++)
-        if (need[i] && !ensure_pbuf(c, i, need[i])) return 0;  // not enough memory now: the passes decide again when they run
+        if (need[i] && !ensure_pbuf(c, i, need[i])) {  // not enough memory now: nothing half-reserved stays behind, the passes decide again when they run
+            release_partition_buffers(c);
+            return 0;
+        }
     // the insert's level-2 regions kept aside while its apply is deferred into the query's lookup
     if (part && qpart && c->opt_fuse && pl.b3 == 0 && qpl.b3 == 0) {
         const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
@@ -871,7 +896,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         overflowed = overflowed || f1[1] != 0 || f2 != 0;
         c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
-        if (getenv("TPC_DEBUG_OVF")) {
+        if (c->dbg_ovf) {
             unsigned long long sc[65];
             (void)hipMemcpy(sc, pl.surv_cur, sizeof sc, hipMemcpyDeviceToHost);
             unsigned long long tot = 0, most = 0;
@@ -879,7 +904,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             fprintf(stderr, "[ovf] query: %llu overflow entries (cap %llu, flag %llu), survivors %llu (fullest list %llu of %llu, flag %llu) b1=%d b2=%d ppr=%d loads=%d\n", f1[0],
                     (unsigned long long)pl.ovf_cap, f1[1], tot, most, (unsigned long long)pl.surv_cap, f2, pl.b1, pl.b2, pl.pos_per_round, pl.loads);
         }
-        if (getenv("TPC_PROFILE_PHASES")) {
+        if (c->dbg_phases) {
             unsigned long long pr[32];
             (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
             fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu rounds %llu | hash: push %llu book %llu copy %llu rounds %llu (10 ns ticks summed over WGs)\n",
@@ -1462,6 +1487,9 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
     if (!c || !c->have_params || !c->bases || !geom) return fail(c, -1, "set_params and seq_upload first");
     if (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) return fail(c, -1, "bad pass");
     HIPCHK(c, hipSetDevice(c->device));
+    if (!part_hash_supported(c))
+        return fail(c, -1, "a sharded filter needs the partitioned hash kernels: q=%d, L=%d, slice_bits=%d are outside what they cover (1..8 functions, or 9..16 with L - slice_bits <= 24)",
+                    c->P.q, c->P.L, c->opt_slice_bits);
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     const uint64_t W = c->sh_world, tiles = text_tiles512(c);
     const uint64_t per_total = (tiles + W - 1) / W;

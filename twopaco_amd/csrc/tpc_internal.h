@@ -3,8 +3,9 @@
 #include "tpc_device.h"
 #include <vector>
 
-#define TPC_TAB_MAXQ 16
-#define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[16][5] then hk[16][5]
+#define TPC_TAB_MAXQ 64                // = TPC_MAX_Q (include/twopaco_hip.h)
+#define TPC_KERNEL_MAXQ 16             // the rolling kernels are instantiated for 1..16 functions; beyond that tpc_pass1_anyq.hip
+#define TPC_TAB_HK (TPC_TAB_MAXQ * 5)  // device table layout: h[64][5] then hk[64][5]
 #define TPC_TAB_WORDS (2 * TPC_TAB_MAXQ * 5)
 
 struct TpcLaunch {
@@ -23,6 +24,11 @@ int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, 
 int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks);
 int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size);  // emask is consumed (occurrences still to be counted)
 int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *out);
+// more than TPC_KERNEL_MAXQ hash functions (tpc_pass1_anyq.hip): the same three passes with every hash in closed form
+int tpc_launch_insert_anyq(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);
+int tpc_launch_query_anyq(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks);
+int tpc_launch_split_anyq(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size);
+extern int tpc_test_force_anyq;  // tpc_pass1.hip: option "test_force_anyq"
 
 // partitioned insert (tpc_partition.hip)
 struct TpcPartPlan {

@@ -167,12 +167,14 @@ __device__ __forceinline__ uint64_t p_spread2(uint32_t m)
 __device__ __forceinline__ uint64_t p_lo(const uint4 &e) { return ((uint64_t)e.y << 32) | e.x; }
 __device__ __forceinline__ uint64_t p_hi(const uint4 &e) { return ((uint64_t)e.w << 32) | e.z; }
 
-template <int Q, bool GATED, bool SHARDED>
+template <int Q, bool GATED, bool SHARDED, bool LHI>
 __global__ void __launch_bounds__(PH_THREADS)
 k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
              const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
              uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows)
-{
+{   // LHI: L > 32.  Every L-bit value lives in two separate 32-bit registers (LeanV, tpc_lean.h: round 4); for L <= 32 the high
+    // halves do not exist.
+    using V = LeanV<LHI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;
@@ -203,7 +205,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
     auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
     bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 5), (uint32_t)cap1); });  // 32 entries = one 128-byte unit
     auto lost = [shift, ovf](uint32_t b, uint32_t val) { ovf.push(((uint64_t)b << shift) | val); };
-    LeanRot R;
+    LeanRotH<LHI> R;
     R.set(L);
     LeanSplit S;
     S.set(perm, LOG_NB);
@@ -212,7 +214,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
     unsigned hashed = 0;
     int since_flush = 0;
     // the q Bloom addresses of one edge -> bins
-    auto emit_edge = [&](const uint64_t (&a)[Q]) {
+    auto emit_edge = [&](const V (&a)[Q]) {
         constexpr int H = Q > 8 ? (Q + 1) / 2 : Q;  // more than 8 functions: two batches (claims in flight and live registers stay bounded)
 #pragma unroll
         for (int h0 = 0; h0 < Q; h0 += H) {
@@ -221,7 +223,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
 #pragma unroll
             for (int i = 0; i < H; i++) {
                 ok[i] = h0 + i < Q;
-                if (h0 + i < Q) S.split(a[h0 + i], b[i], val[i]); else { b[i] = 0; val[i] = 0; }
+                if (h0 + i < Q) lean_split_h<LHI>(S, a[h0 + i], b[i], val[i]); else { b[i] = 0; val[i] = 0; }
             }
             bins.template push_batch<H>(b, val, ok, lost);
         }
@@ -241,9 +243,10 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
         }
         __syncthreads();
         // The text is padded with N to whole tiles (tpc_seq_upload): runs past its end find no vertex and need no guard.
-        const uint64_t cw = s_b[lt + 1];
+        const uint64_t cw64 = s_b[lt + 1];
+        const uint32_t cw_lo = (uint32_t)cw64, cw_hi = (uint32_t)(cw64 >> 32);
         const uint32_t nw = s_n[lt + 1];
-        const uint64_t cx = (uint64_t)lean_chars16(s_b, p0 + (uint32_t)k) | ((uint64_t)lean_chars16(s_b, p0 + (uint32_t)k + 16u) << 32);
+        const uint32_t cx_lo = lean_chars16(s_b, p0 + (uint32_t)k), cx_hi = lean_chars16(s_b, p0 + (uint32_t)k + 16u);
         const uint32_t nx = lean_nbits32(s_n, p0 + (uint32_t)k);
         uint32_t cp = lean_char(s_b, s_n, p0 - 1u);
         int ncnt = 0;  // N characters inside the window (k - definiteCount, VE.h:1033)
@@ -252,9 +255,9 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
             if (k - t < 32) bits &= (1u << (k - t)) - 1u;
             ncnt += __popc(bits);
         }
-        uint64_t pos[Q], neg[Q];  // VertexRollingHash ctor (vertexrollinghash.h:79-102)
+        V pos[Q], neg[Q];  // VertexRollingHash ctor (vertexrollinghash.h:79-102)
 #pragma unroll
-        for (int i = 0; i < Q; i++) { pos[i] = 0; neg[i] = 0; }
+        for (int i = 0; i < Q; i++) { pos[i] = lv_make<LHI>(0u, 0u); neg[i] = lv_make<LHI>(0u, 0u); }
         if (seed_rows) {
             for (int t0 = 0; t0 < k; t0 += 16) {
                 uint32_t ch = lean_chars16(s_b, p0 + (uint32_t)t0), nb = lean_nbits32(s_n, p0 + (uint32_t)t0);
@@ -264,7 +267,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                     ch >>= 2; nb >>= 1;
                     const uint4 *row = s_seed + ((t0 + j) * 5 + (int)c) * Q;
 #pragma unroll
-                    for (int i = 0; i < Q; i++) { const uint4 e = row[i]; pos[i] ^= p_lo(e); neg[i] ^= p_hi(e); }
+                    for (int i = 0; i < Q; i++) { const uint4 e = row[i]; pos[i] = lv_xor<LHI>(pos[i], e.x, e.y); neg[i] = lv_xor<LHI>(neg[i], e.z, e.w); }
                 }
             }
         } else {
@@ -272,23 +275,30 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                 const uint32_t c = lean_char(s_b, s_n, p0 + (uint32_t)t), cr = lean_char(s_b, s_n, p0 + (uint32_t)(k - 1 - t));
                 const uint4 *rowp = s_roll + c * Q, *rown = s_roll + (5 + cr) * Q;
 #pragma unroll
-                for (int i = 0; i < Q; i++) { pos[i] = R.rotl1(pos[i]) ^ p_lo(rowp[i]); neg[i] = R.rotl1(neg[i]) ^ p_hi(rown[i]); }
+                for (int i = 0; i < Q; i++) {
+                    const uint4 ep = rowp[i], en = rown[i];
+                    pos[i] = lv_xor<LHI>(R.rotl1(pos[i]), ep.x, ep.y);
+                    neg[i] = lv_xor<LHI>(R.rotl1(neg[i]), en.z, en.w);
+                }
             }
         }
 #pragma unroll 1
         for (int s = 0; s < TPC_RUN; s++) {  // not unrolled: one copy of the push and flush code
-            const uint32_t cf = ((uint32_t)(cw >> (2 * s)) & 3u) | (((nw >> s) & 1u) << 2);  // first character of the window
-            const uint32_t cn = ((uint32_t)(cx >> (2 * s)) & 3u) | (((nx >> s) & 1u) << 2);  // the character after it
+            // first character of the window and the character after it, as code | isN << 2 (two bit-field extracts and a v_lshl_or each)
+            uint32_t cwh = cw_lo, cxh = cx_lo;
+            if (s >= 16) { cwh = cw_hi; cxh = cx_hi; }  // (uniform)
+            const uint32_t cf = __builtin_amdgcn_ubfe(cwh, 2u * ((uint32_t)s & 15u), 2u) | (__builtin_amdgcn_ubfe(nw, (uint32_t)s, 1u) << 2);
+            const uint32_t cn = __builtin_amdgcn_ubfe(cxh, 2u * ((uint32_t)s & 15u), 2u) | (__builtin_amdgcn_ubfe(nx, (uint32_t)s, 1u) << 2);
             const uint4 *rowN = s_roll + cn * Q, *rowF = s_roll + (5 + cf) * Q;
             // function 0 decides the strand and the round gate; hash_extend / hash_prepend of the outgoing edge
             // (cyclichash.h:112-121) are the intermediates of update / reverse_update (cyclichash.h:86-102)
             const uint4 eN0 = rowN[0], eF0 = rowF[0];
-            const uint64_t ep0 = R.rotl1(pos[0]) ^ p_lo(eN0), en0 = neg[0] ^ p_hi(eN0);
-            const uint64_t np0 = ep0 ^ p_lo(eF0), nn0 = R.rotr1(en0 ^ p_hi(eF0));
+            const V ep0 = lv_xor<LHI>(R.rotl1(pos[0]), eN0.x, eN0.y), en0 = lv_xor<LHI>(neg[0], eN0.z, eN0.w);
+            const V np0 = lv_xor<LHI>(ep0, eF0.x, eF0.y), nn0 = R.rotr1(lv_xor<LHI>(en0, eF0.z, eF0.w));
             const bool vertex = ncnt == 0;
             bool go = vertex;
             if (GATED && go) {  // VE.h:1063-1073
-                const uint64_t first = tpc_min(pos[0], neg[0]), second = tpc_min(np0, nn0);
+                const uint64_t first = lv_u64<LHI>(lv_min<LHI>(pos[0], neg[0])), second = lv_u64<LHI>(lv_min<LHI>(np0, nn0));
                 go = (first >= lo && first <= hi) || (second >= lo && second <= hi);
             }
             const bool main_edge = go && cn < 4u;
@@ -302,40 +312,42 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                     if (d < 2) {  // out-edge v + c
                         const uint4 *r = s_roll + c * Q;
 #pragma unroll
-                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = R.rotl1(pos[i]) ^ p_lo(e); n[i] = neg[i] ^ p_hi(e); }
+                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = lv_u64<LHI>(lv_xor<LHI>(R.rotl1(pos[i]), e.x, e.y)); n[i] = lv_u64<LHI>(lv_xor<LHI>(neg[i], e.z, e.w)); }
                     } else {      // in-edge c + v
                         const uint4 *r = s_roll + (5 + c) * Q;
 #pragma unroll
-                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = p_lo(e) ^ pos[i]; n[i] = R.rotl1(neg[i]) ^ p_hi(e); }
+                        for (int i = 0; i < Q; i++) { const uint4 e = r[i]; p[i] = lv_u64<LHI>(lv_xor<LHI>(pos[i], e.x, e.y)); n[i] = lv_u64<LHI>(lv_xor<LHI>(R.rotl1(neg[i]), e.z, e.w)); }
                     }
                     const bool ngd = tpc_pick_neg<Q>(p, n);
-                    uint64_t a[Q];
+                    V a[Q];
 #pragma unroll
-                    for (int i = 0; i < Q; i++) a[i] = ngd ? n[i] : p[i];
+                    for (int i = 0; i < Q; i++) a[i] = lv_from64<LHI>(ngd ? n[i] : p[i]);
                     emit_edge(a);
                 }
             }
             // canonical strand of the out-edge (DetermineStrandExtend, vertexrollinghash.h:170-184)
-            bool ng = en0 < ep0;
-            if (main_edge && ep0 == en0) {
+            bool ng = lv_lt<LHI>(en0, ep0);
+            if (main_edge && lv_eq<LHI>(ep0, en0)) {
                 ng = false;
-                for (int i = 1; i < Q; i++) {
+                bool decided = false;
+#pragma unroll
+                for (int i = 1; i < Q; i++) {  // (fully unrolled: a dynamic index would put pos[] / neg[] into scratch memory)
                     const uint4 e = rowN[i];
-                    const uint64_t pp = R.rotl1(pos[i]) ^ p_lo(e), nn = neg[i] ^ p_hi(e);
-                    if (pp != nn) { ng = nn < pp; break; }
+                    const V pp = lv_xor<LHI>(R.rotl1(pos[i]), e.x, e.y), nn = lv_xor<LHI>(neg[i], e.z, e.w);
+                    if (!decided && !lv_eq<LHI>(pp, nn)) { ng = lv_lt<LHI>(nn, pp); decided = true; }
                 }
             }
-            uint64_t a[Q];
-            a[0] = ng ? en0 : ep0;
+            V a[Q];
+            a[0] = lv_sel<LHI>(ng, en0, ep0);
             pos[0] = np0;
             neg[0] = nn0;
 #pragma unroll
             for (int i = 1; i < Q; i++) {
                 const uint4 eN = rowN[i], eF = rowF[i];
-                const uint64_t ep = R.rotl1(pos[i]) ^ p_lo(eN), en = neg[i] ^ p_hi(eN);
-                a[i] = ng ? en : ep;
-                pos[i] = ep ^ p_lo(eF);
-                neg[i] = R.rotr1(en ^ p_hi(eF));
+                const V ep = lv_xor<LHI>(R.rotl1(pos[i]), eN.x, eN.y), en = lv_xor<LHI>(neg[i], eN.z, eN.w);
+                a[i] = lv_sel<LHI>(ng, en, ep);
+                pos[i] = lv_xor<LHI>(ep, eF.x, eF.y);
+                neg[i] = R.rotr1(lv_xor<LHI>(en, eF.z, eF.w));
             }
             if (main_edge) emit_edge(a);
             hashed += vertex;
@@ -506,14 +518,19 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
         const size_t seed = (size_t)a.P.k * 5 * Q * 16;  // the seed table, when it fits beside the rings (160 KB per workgroup)
         const int seed_rows = fixed + seed <= (size_t)160 * 1024 - 256 ? a.P.k : 0;
         const size_t lds = fixed + (seed_rows ? seed : 0);
-#define TPC_HASH2_GO(G, S)                                                                                                                  \
+#define TPC_HASH2_GO(G, S, H)                                                                                                               \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_part_hash2<Q, G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-        hipLaunchKernelGGL((k_part_hash2<Q, G, S>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
+        (void)hipFuncSetAttribute((const void *)k_part_hash2<Q, G, S, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        hipLaunchKernelGGL((k_part_hash2<Q, G, S, H>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers, seed_rows);  \
     } while (0)
-        if (pl.world > 1) { if (gated) TPC_HASH2_GO(true, true); else TPC_HASH2_GO(false, true); }
-        else { if (gated) TPC_HASH2_GO(true, false); else TPC_HASH2_GO(false, false); }
+#define TPC_HASH2_GS(H)                                                                                                                     \
+    do {                                                                                                                                    \
+        if (pl.world > 1) { if (gated) TPC_HASH2_GO(true, true, H); else TPC_HASH2_GO(false, true, H); }                                    \
+        else { if (gated) TPC_HASH2_GO(true, false, H); else TPC_HASH2_GO(false, false, H); }                                               \
+    } while (0)
+        if (a.P.L > 32) TPC_HASH2_GS(true); else TPC_HASH2_GS(false);  // L-bit values on 32-bit halves: no high halves at all for L <= 32
+#undef TPC_HASH2_GS
 #undef TPC_HASH2_GO
         return 0;
     }
@@ -702,6 +719,11 @@ size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.
 int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
 {
     switch (a.P.q) {
+#ifdef TPC_DEV_Q5  // development builds: one instantiation
+    case 5: return launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers);
+    default: return -1;
+    }
+#else
     case 1: return launch_hash_q<1>(a, pl, gated, lo, hi, n_kmers);
     case 2: return launch_hash_q<2>(a, pl, gated, lo, hi, n_kmers);
     case 3: return launch_hash_q<3>(a, pl, gated, lo, hi, n_kmers);
@@ -720,6 +742,7 @@ int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint6
     case 16: return launch_hash_q<16>(a, pl, gated, lo, hi, n_kmers);
     }
     return -1;
+#endif
 }
 
 int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl) { return launch_split(a, pl); }

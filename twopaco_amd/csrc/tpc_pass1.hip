@@ -377,8 +377,11 @@ void launch_split_q(const TpcLaunch &a, uint32_t *todo, uint32_t *bins, uint64_t
     default: return -1;                        \
     }
 
+int tpc_test_force_anyq = 0;  // option "test_force_anyq" (tests only, process-wide): the closed-form kernels of tpc_pass1_anyq.hip for every q
+
 int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers)
 {
+    if (a.P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return tpc_launch_insert_anyq(a, lo, hi, gated, test, n_kmers);
 #define CALL(Q) launch_insert_q<Q>(a, lo, hi, gated, test, n_kmers)
     TPC_DISPATCH_Q(a.P.q, CALL)
 #undef CALL
@@ -387,6 +390,7 @@ int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, 
 
 int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks)
 {
+    if (a.P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return tpc_launch_query_anyq(a, rmask, lo, hi, gated, n_marks);
 #define CALL(Q) launch_query_q<Q>(a, rmask, lo, hi, gated, n_marks)
     TPC_DISPATCH_Q(a.P.q, CALL)
 #undef CALL
@@ -395,6 +399,7 @@ int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t 
 
 int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size)
 {
+    if (a.P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return tpc_launch_split_anyq(a, emask, bins, bin_size);
 #define CALL(Q) launch_split_q<Q>(a, emask, bins, bin_size)
     TPC_DISPATCH_Q(a.P.q, CALL)
 #undef CALL

@@ -240,13 +240,14 @@ __device__ __forceinline__ uint64_t q_spread2(uint32_t m)
     return x | (x << 1);
 }
 
-template <bool GATED, bool SHARDED, bool HALF>
+template <bool GATED, bool SHARDED, bool HALF, bool LHI>
 __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
           const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round,
           uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
           uint64_t gbase, uint32_t *__restrict__ rmask)
-{
+{   // LHI: L > 32; L-bit values on two separate 32-bit registers (LeanV, tpc_lean.h: round 4)
+    using V = LeanV<LHI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
     constexpr int TW = PT_THREADS + 1 + TPC_XW_MAX;  // a tile is 512 packed words
@@ -273,16 +274,19 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
     auto ridx = [sh, NB, wg, nwg](uint32_t b) { return SHARDED ? pt_r1_send(sh, (uint32_t)NB, nwg, wg, b) : (uint64_t)wg * NB + b; };
     auto lost = [shift, ovf](uint32_t b, uint64_t val) { ovf.push(((uint64_t)b << shift) | (val & QE_REM_MASK), val >> QE_E_SHIFT, 1); };
     bins.init(buf1, [cap1, ridx](uint32_t b) { return make_uint2((uint32_t)((ridx(b) * cap1) >> 4), (uint32_t)cap1); });  // 16 entries = one 128-byte unit
-    LeanRot R;
+    LeanRotH<LHI> R;
     R.set(L);
     LeanSplit S;
     S.set(perm, LOG_NB);
     const int xw = (k + 1) / 32 + 2;
     uint16_t *rmask16 = reinterpret_cast<uint16_t *>(rmask);
     // function 0's table entries of the four letters as scalars: the eight candidate edges use them with constant letters
-    uint64_t h0[4], hk0[4];
+    uint32_t h0l[4], h0h[4], hk0l[4], hk0h[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) { h0[c] = tab[c]; hk0[c] = tab[TPC_TAB_HK + c]; }
+    for (int c = 0; c < 4; c++) {
+        const uint64_t h = tab[c], hk = tab[TPC_TAB_HK + c];
+        h0l[c] = (uint32_t)h; h0h[c] = (uint32_t)(h >> 32); hk0l[c] = (uint32_t)hk; hk0h[c] = (uint32_t)(hk >> 32);
+    }
     const uint32_t ppr_mask = (uint32_t)pos_per_round - 1u;  // a power of two <= 16
     constexpr bool half_rounds = HALF;                       // 512 bins: see the push below
     const uint32_t p0 = 32u + tid * (uint32_t)QH_RUN;        // my first position, relative to the first staged word (the one before the tile)
@@ -308,7 +312,7 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
             if (k - t < 32) bits &= (1u << (k - t)) - 1u;
             ncnt += __popc(bits);
         }
-        uint64_t pos = 0, neg = 0;  // VertexRollingHash ctor (vertexrollinghash.h:79-102), function 0
+        V pos = lv_make<LHI>(0u, 0u), neg = lv_make<LHI>(0u, 0u);  // VertexRollingHash ctor (vertexrollinghash.h:79-102), function 0
         if (k <= QT_MAXK) {
             for (int t0 = 0; t0 < k; t0 += 16) {
                 uint32_t ch = lean_chars16(s_b, p0 + (uint32_t)t0), nb = lean_nbits32(s_n, p0 + (uint32_t)t0);
@@ -318,26 +322,26 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
                     const uint32_t c = (ch & 3u) | ((nb & 1u) << 2);
                     ch >>= 2; nb >>= 1;
                     const uint4 e = row[j * 5 + c];
-                    pos ^= ((uint64_t)e.y << 32) | e.x;
-                    neg ^= ((uint64_t)e.w << 32) | e.z;
+                    pos = lv_xor<LHI>(pos, e.x, e.y);
+                    neg = lv_xor<LHI>(neg, e.z, e.w);
                 }
             }
         } else {
             for (int t = 0; t < k; t++) {
                 const uint32_t c = lean_char(s_b, s_n, p0 + (uint32_t)t), cr = lean_char(s_b, s_n, p0 + (uint32_t)(k - 1 - t));
-                pos = R.rotl1(pos) ^ s_roll[c * 2];
-                neg = R.rotl1(neg) ^ s_roll[10 + cr * 2 + 1];
+                pos = lv_xor<LHI>(R.rotl1(pos), lv_from64<LHI>(s_roll[c * 2]));
+                neg = lv_xor<LHI>(R.rotl1(neg), lv_from64<LHI>(s_roll[10 + cr * 2 + 1]));
             }
         }
         const uint32_t sid0 = ((uint32_t)(wfirst * TPC_RUN + (uint64_t)tid * QH_RUN - gbase) | (SHARDED ? sh.rank << (30u - sh.log_world()) : 0u)) << 2;
         uint32_t word = 0;
 #pragma unroll 1
         for (int s = 0; s < QH_RUN; s++) {  // not unrolled: one copy of the push and flush code (the loop body is ~600 instructions)
-            const uint32_t cf = ((cw >> (2 * s)) & 3u) | (((nw >> s) & 1u) << 2);  // first character of the window
-            const uint32_t cn = ((cx >> (2 * s)) & 3u) | (((nx >> s) & 1u) << 2);  // the character after it
-            const uint64_t r1p = R.rotl1(pos), r1n = R.rotl1(neg);
+            const uint32_t cf = __builtin_amdgcn_ubfe(cw, 2u * (uint32_t)s, 2u) | (__builtin_amdgcn_ubfe(nw, (uint32_t)s, 1u) << 2);  // first character of the window
+            const uint32_t cn = __builtin_amdgcn_ubfe(cx, 2u * (uint32_t)s, 2u) | (__builtin_amdgcn_ubfe(nx, (uint32_t)s, 1u) << 2);  // the character after it
+            const V r1p = R.rotl1(pos), r1n = R.rotl1(neg);
             bool check = ncnt == 0;
-            if (GATED) check = check && within(tpc_min(pos, neg), lo, hi);  // VE.h:638
+            if (GATED) check = check && within(lv_u64<LHI>(lv_min<LHI>(pos, neg)), lo, hi);  // VE.h:638
             const bool nadj = (cp | cn) >= 4u;
             if (check && nadj) word |= 1u << s;  // VE.h:640-641: an N neighbour counts 2
             uint32_t eb[8];
@@ -350,11 +354,11 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
                 for (int c = 0; c < 4; c++) {
                     uint32_t rem;
                     // in-edge c + v (DetermineStrandPrepend, vertexrollinghash.h:186-200): survivor id edge = c
-                    S.split(tpc_min(hk0[c] ^ pos, r1n ^ h0[3 - c]), eb[c], rem);
+                    lean_split_h<LHI>(S, lv_min<LHI>(lv_xor<LHI>(pos, hk0l[c], hk0h[c]), lv_xor<LHI>(r1n, h0l[3 - c], h0h[3 - c])), eb[c], rem);
                     ev[c] = ((uint64_t)(hi_s | (uint32_t)(c >> 1)) << 32) | (rem | ((uint32_t)(c & 1) << 31));
                     eok[c] = (uint32_t)c != cp;
                     // out-edge v + c (DetermineStrandExtend, vertexrollinghash.h:170-184): edge = 4 + c
-                    S.split(tpc_min(r1p ^ h0[c], neg ^ hk0[3 - c]), eb[4 + c], rem);
+                    lean_split_h<LHI>(S, lv_min<LHI>(lv_xor<LHI>(r1p, h0l[c], h0h[c]), lv_xor<LHI>(neg, hk0l[3 - c], hk0h[3 - c])), eb[4 + c], rem);
                     ev[4 + c] = ((uint64_t)(hi_s | (uint32_t)((4 + c) >> 1)) << 32) | (rem | ((uint32_t)(c & 1) << 31));
                     eok[4 + c] = (uint32_t)c != cn;
                 }
@@ -382,8 +386,8 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
             }
             if (s + 1 < QH_RUN) {  // roll: VertexRollingHash::Update (vertexrollinghash.h:104-113), function 0
                 const uint4 en = reinterpret_cast<const uint4 *>(s_roll)[cn], ef = reinterpret_cast<const uint4 *>(s_roll)[5 + cf];
-                pos = r1p ^ (((uint64_t)en.y << 32) | en.x) ^ (((uint64_t)ef.y << 32) | ef.x);
-                neg = R.rotr1(neg ^ (((uint64_t)en.w << 32) | en.z) ^ (((uint64_t)ef.w << 32) | ef.z));
+                pos = lv_xor<LHI>(lv_xor<LHI>(r1p, en.x, en.y), ef.x, ef.y);
+                neg = R.rotr1(lv_xor<LHI>(lv_xor<LHI>(neg, en.z, en.w), ef.z, ef.w));
                 ncnt += (int)(cn >> 2) - (int)(cf >> 2);
                 cp = cf;
             }
@@ -764,6 +768,9 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
 #pragma unroll
             for (int i = 1; i < Q; i++) present = present && probe(ng ? nn[i] : p[i]);
         }
+        // (Round 4 tried marking with plain byte stores -- one byte per position of the batch, folded into the mask by a small kernel
+        //  afterwards -- instead of these 54 M device-scope atomics: 3.14 -> 3.27 ms + 0.06 for the fold, profiles/r04a_*.  A scattered
+        //  partial-line store costs the memory system what the atomic does.)
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
@@ -910,6 +917,9 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
                 for (int i = 2; i < Q; i++) present = present && ((wv[i] >> ((uint32_t)a[i] & 31u)) & 1u);
             }
         }
+        // (Round 4 tried marking with plain byte stores -- one byte per position of the batch, folded into the mask by a small kernel
+        //  afterwards -- instead of these 54 M device-scope atomics: 3.14 -> 3.27 ms + 0.06 for the fold, profiles/r04a_*.  A scattered
+        //  partial-line store costs the memory system what the atomic does.)
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
@@ -1098,19 +1108,20 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     const bool lean = pl.b1 <= 9 && pl.sub_rounds <= 2 && perm.F <= 24 && !getenv("TPC_NO_LEAN") && !(rb && getenv("TPC_RB_HASH"));
     if (lean) {
         const size_t lds = Bins3<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + 160 + (size_t)QT_MAXK * 80 + 64;
-#define TPC_QHASH2_GO(G, S, H)                                                                                                              \
+#define TPC_QHASH2_GO(G, S, H, X)                                                                                                           \
     do {                                                                                                                                    \
-        (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-        hipLaunchKernelGGL((k_q_hash2<G, S, H>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
+        (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S, H, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL((k_q_hash2<G, S, H, X>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
                            pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
     } while (0)
-#define TPC_QHASH2_GS(H)                                                                                                                    \
+#define TPC_QHASH2_GS(H, X)                                                                                                                 \
     do {                                                                                                                                    \
-        if (pl.world > 1) { if (gated) TPC_QHASH2_GO(true, true, H); else TPC_QHASH2_GO(false, true, H); }                                  \
-        else { if (gated) TPC_QHASH2_GO(true, false, H); else TPC_QHASH2_GO(false, false, H); }                                             \
+        if (pl.world > 1) { if (gated) TPC_QHASH2_GO(true, true, H, X); else TPC_QHASH2_GO(false, true, H, X); }                            \
+        else { if (gated) TPC_QHASH2_GO(true, false, H, X); else TPC_QHASH2_GO(false, false, H, X); }                                       \
     } while (0)
-        if (pl.b1 >= 9) TPC_QHASH2_GS(true); else TPC_QHASH2_GS(false);
+        if (a.P.L > 32) { if (pl.b1 >= 9) TPC_QHASH2_GS(true, true); else TPC_QHASH2_GS(false, true); }
+        else { if (pl.b1 >= 9) TPC_QHASH2_GS(true, false); else TPC_QHASH2_GS(false, false); }
 #undef TPC_QHASH2_GS
 #undef TPC_QHASH2_GO
         return;
@@ -1159,11 +1170,11 @@ void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, i
 template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
+    const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const size_t table = (size_t)(a.P.k + 1) * 4 * Q * 16;  // k_q_verify2's letter table
     if (a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN")) {
         const char *force = getenv("TPC_VERIFY_LAZY");  // measurements: 0 = all Q - 1 probes at once
         const bool lazy = !(force && force[0] == '0');
-        const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
         if (lazy) {
             (void)hipFuncSetAttribute((const void *)k_q_verify2<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
             hipLaunchKernelGGL((k_q_verify2<Q, true>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, gbase,
@@ -1175,8 +1186,7 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
         }
         return;
     }
-    hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap,
-                       pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);
+    hipLaunchKernelGGL((k_q_verify<Q>), dim3(256, QS_LISTS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, gbase, rmask);
 }
 
 }  // namespace
@@ -1299,7 +1309,7 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
 
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
 {
-    if (a.P.q < 1 || a.P.q > TPC_TAB_MAXQ) return -1;  // k_q_verify is instantiated for 1..16 functions
+    if (a.P.q < 1 || a.P.q > TPC_KERNEL_MAXQ) return -1;  // k_q_verify is instantiated for 1..16 functions
     launch_qhash(a, pl, gated, lo, hi, rmask);
     return 0;
 }

@@ -45,12 +45,68 @@ namespace TwoPaCo
 		// ---- Bloom filter checkpoint (EnumeratorOptions::saveFilter / loadFilter; the reference's commented-out
 		// ReloadBloomFilter, reference vertexenumerator.h:29,113-121 -- there the dump was ConcurrentBitVector::WriteToFile of
 		// the whole vector, concurrentbitvector.cpp:59-67).  One file per round: header, q x 5 hash table, filter words.
+		// Bloom filter checkpoint (--save-filter / --load-filter; the reference's commented-out ReloadBloomFilter, vertexenumerator.h:29,113-121).
+		// The header is written field by field, little-endian (no raw struct: the format does not depend on the host ABI), and ties
+		// the filter to the INPUT as well as to the parameters: a filter saved from other FASTA files would load cleanly and silently
+		// drop junctions (Bloom false negatives), so the text's length, record count and a checksum of the packed text travel with it.
 		struct FilterFileHeader
 		{
-			char magic[8];       // "TPCBLOOM"
 			uint32_t version, k, bits, q, round, rounds;
 			uint64_t low, high, words;
+			uint64_t textLength, textRecords, textChecksum;  // version 2
+			uint32_t shard, shards;                          // version 2: shard `shard` of `shards` (address-sharded filter: one file per rank)
 		};
+
+		const uint32_t FILTER_FILE_VERSION = 2;
+
+		void PutLe(std::vector<unsigned char> & out, uint64_t v, int bytes)
+		{
+			for (int i = 0; i < bytes; i++) out.push_back((unsigned char)(v >> (8 * i)));
+		}
+
+		uint64_t GetLe(const unsigned char * p, int bytes)
+		{
+			uint64_t v = 0;
+			for (int i = 0; i < bytes; i++) v |= uint64_t(p[i]) << (8 * i);
+			return v;
+		}
+
+		const size_t FILTER_HEADER_BYTES = 8 + 6 * 4 + 6 * 8 + 2 * 4;
+
+		std::vector<unsigned char> EncodeFilterHeader(const FilterFileHeader & h)
+		{
+			std::vector<unsigned char> out;
+			out.insert(out.end(), "TPCBLOOM", "TPCBLOOM" + 8);
+			PutLe(out, h.version, 4); PutLe(out, h.k, 4); PutLe(out, h.bits, 4); PutLe(out, h.q, 4); PutLe(out, h.round, 4); PutLe(out, h.rounds, 4);
+			PutLe(out, h.low, 8); PutLe(out, h.high, 8); PutLe(out, h.words, 8);
+			PutLe(out, h.textLength, 8); PutLe(out, h.textRecords, 8); PutLe(out, h.textChecksum, 8);
+			PutLe(out, h.shard, 4); PutLe(out, h.shards, 4);
+			return out;
+		}
+
+		// Cheap fingerprint of the packed text: its length, every record's length, and up to 2^20 evenly spaced words of the bases and
+		// of the N mask (reading all of a human-scale text would cost more than the filter upload it guards).
+		uint64_t TextChecksum(const PackedText & text)
+		{
+			auto mix = [](uint64_t h, uint64_t v)
+			{
+				h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+				h *= 0xBF58476D1CE4E5B9ull;
+				return h ^ (h >> 31);
+			};
+
+			uint64_t h = mix(0x5450434B50540001ull, text.length);
+			for (uint64_t len : text.recLength) h = mix(h, len);
+			const uint64_t words = (text.length + 31) / 32;
+			const uint64_t stride = std::max<uint64_t>(1, words >> 20);
+			for (uint64_t w = 0; w < words; w += stride)
+			{
+				h = mix(h, text.bases[w]);
+				h = mix(h, text.nmask[w]);
+			}
+
+			return h;
+		}
 
 		std::string FilterFileName(const std::string & base, size_t round)
 		{
@@ -59,15 +115,29 @@ namespace TwoPaCo
 
 		void ReadFilterHeader(std::FILE * f, const std::string & name, FilterFileHeader & h, std::vector<uint64_t> & table)
 		{
-			if (std::fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, "TPCBLOOM", 8) != 0 || h.version != 1 || h.q == 0 || h.q > 64)
+			unsigned char raw[FILTER_HEADER_BYTES];
+			if (std::fread(raw, 1, sizeof(raw), f) != sizeof(raw) || std::memcmp(raw, "TPCBLOOM", 8) != 0)
 			{
 				throw std::runtime_error("Not a Bloom filter checkpoint: " + name);
 			}
 
-			table.resize(size_t(h.q) * 5);
-			if (std::fread(table.data(), sizeof(uint64_t), table.size(), f) != table.size())
+			const unsigned char * p = raw + 8;
+			h.version = uint32_t(GetLe(p, 4)); h.k = uint32_t(GetLe(p + 4, 4)); h.bits = uint32_t(GetLe(p + 8, 4)); h.q = uint32_t(GetLe(p + 12, 4));
+			h.round = uint32_t(GetLe(p + 16, 4)); h.rounds = uint32_t(GetLe(p + 20, 4));
+			h.low = GetLe(p + 24, 8); h.high = GetLe(p + 32, 8); h.words = GetLe(p + 40, 8);
+			h.textLength = GetLe(p + 48, 8); h.textRecords = GetLe(p + 56, 8); h.textChecksum = GetLe(p + 64, 8);
+			h.shard = uint32_t(GetLe(p + 72, 4)); h.shards = uint32_t(GetLe(p + 76, 4));
+			if (h.version != FILTER_FILE_VERSION || h.q == 0 || h.q > 64 || h.shards == 0 || h.shard >= h.shards)
 			{
-				throw std::runtime_error("Truncated Bloom filter checkpoint: " + name);
+				throw std::runtime_error("Not a Bloom filter checkpoint of this version: " + name);
+			}
+
+			table.resize(size_t(h.q) * 5);
+			unsigned char cell[8];
+			for (uint64_t & t : table)
+			{
+				if (std::fread(cell, 1, 8, f) != 8) throw std::runtime_error("Truncated Bloom filter checkpoint: " + name);
+				t = GetLe(cell, 8);
 			}
 		}
 
@@ -136,8 +206,12 @@ namespace TwoPaCo
 				const double filterGb = std::ldexp(1.0, int(filterSize) - 33);
 				const double autoGb = std::max(20.0, std::min(40.0, 48.0 - filterGb));
 				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : autoGb) * double(1ull << 30));
-				const int gpus = std::max(1, options.gpus);
-				const bool sharded = gpus > 1 || options.forceSharded;
+				// More than 16 hash functions run on the closed-form first-pass kernels (csrc/tpc_pass1_anyq.hip), which exist for the
+				// whole filter only: such a run takes one GPU whatever --gpus says (and says so).
+				const bool tooManyFunctionsToShard = hashFunctions > 16 && (options.gpus > 1 || options.forceSharded);
+				if (tooManyFunctionsToShard) logStream << "Hash functions = " << hashFunctions << " > 16: the Bloom filter is not sharded, running on one GPU" << std::endl;
+				const int gpus = tooManyFunctionsToShard ? 1 : std::max(1, options.gpus);
+				const bool sharded = !tooManyFunctionsToShard && (gpus > 1 || options.forceSharded);
 				// several GPUs: the second pass's exact-filter table is sharded by key hash and the text stays sharded (multigpu.h:
 				// ShardedSecondPass / ShardedFinish); TWOPACO_REPLICATED_PASS2=1: union of the candidate masks, then the single-GPU
 				// second pass on rank 0, which then keeps the whole text
@@ -269,6 +343,8 @@ namespace TwoPaCo
 				}
 
 				timer.Lap("parse + pack FASTA");
+				const uint64_t textChecksum = (options.loadFilter.empty() && options.saveFilter.empty()) ? 0 : TextChecksum(text);
+				textFingerprint_[0] = text.length; textFingerprint_[1] = text.recLength.size(); textFingerprint_[2] = textChecksum;
 				setup.join();
 				if (!setupError.empty())
 				{
@@ -392,6 +468,20 @@ namespace TwoPaCo
 						std::vector<uint64_t> fileTable;
 						try { ReadFilterHeader(f, name, h, fileTable); } catch (...) { std::fclose(f); throw; }
 						std::fclose(f);
+						// the ranges come from the checkpoint, so what can be checked is that they chain (VE.h:234-254: round 0 starts at 0, every
+						// round starts right after the one before, the last one reaches the end of the hash range) ...
+						if (h.round != round || h.low != low || h.high < h.low || (round + 1 == rounds && h.high < realSize))
+						{
+							throw std::runtime_error("The Bloom filter checkpoint " + name + " does not continue the rounds before it (round " + std::to_string(h.round) +
+								", range " + std::to_string(h.low) + ":" + std::to_string(h.high) + ")");
+						}
+
+						// ... and that the filter was filled from THIS input
+						if (h.textLength != text.length || h.textRecords != text.recLength.size() || h.textChecksum != textChecksum)
+						{
+							throw std::runtime_error("The Bloom filter checkpoint " + name + " was made from other input files (text length, record count or checksum differ)");
+						}
+
 						low = h.low;
 						high = h.high;
 					}
@@ -684,24 +774,32 @@ namespace TwoPaCo
 			}
 
 		private:
-			void SaveFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table)
+			void SaveFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table,
+				tpc_ctx * ctx = 0, uint32_t shard = 0, uint32_t shards = 1)
 			{
+				if (!ctx) ctx = ctx_;
 				FilterFileHeader h;
 				std::memset(&h, 0, sizeof(h));
-				std::memcpy(h.magic, "TPCBLOOM", 8);
-				h.version = 1; h.k = uint32_t(k); h.bits = uint32_t(bits); h.q = uint32_t(q); h.round = uint32_t(round); h.rounds = uint32_t(rounds);
-				h.low = low; h.high = high; h.words = tpc_filter_words(ctx_);
+				h.version = FILTER_FILE_VERSION; h.k = uint32_t(k); h.bits = uint32_t(bits); h.q = uint32_t(q); h.round = uint32_t(round); h.rounds = uint32_t(rounds);
+				h.low = low; h.high = high; h.words = tpc_filter_words(ctx);
+				h.textLength = textFingerprint_[0]; h.textRecords = textFingerprint_[1]; h.textChecksum = textFingerprint_[2];
+				h.shard = shard; h.shards = shards;
 				std::vector<uint32_t> words(h.words);
-				Check(tpc_filter_download(ctx_, words.data()), "filter_download");
+				if (tpc_filter_download(ctx, words.data()) != 0) throw std::runtime_error(std::string("filter_download: ") + tpc_last_error(ctx));
 				std::FILE * f = std::fopen(name.c_str(), "wb");
 				if (!f) throw std::runtime_error("Can't create the Bloom filter checkpoint " + name);
-				const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(table.data(), sizeof(uint64_t), table.size(), f) == table.size() &&
-					std::fwrite(words.data(), sizeof(uint32_t), words.size(), f) == words.size();
+				const std::vector<unsigned char> head = EncodeFilterHeader(h);
+				std::vector<unsigned char> tab;
+				for (uint64_t t : table) PutLe(tab, t, 8);
+				const bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size() && std::fwrite(tab.data(), 1, tab.size(), f) == tab.size() &&
+					std::fwrite(words.data(), sizeof(uint32_t), words.size(), f) == words.size();  // (filter words: little-endian uint32, as every supported host stores them)
 				if (std::fclose(f) != 0 || !ok) throw std::runtime_error("Can't write the Bloom filter checkpoint " + name);
 			}
 
-			void LoadFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table)
+			void LoadFilter(const std::string & name, size_t k, size_t bits, size_t q, size_t round, size_t rounds, uint64_t low, uint64_t high, const std::vector<uint64_t> & table,
+				tpc_ctx * ctx = 0, uint32_t shard = 0, uint32_t shards = 1)
 			{
+				if (!ctx) ctx = ctx_;
 				std::FILE * f = std::fopen(name.c_str(), "rb");
 				if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + name);
 				try
@@ -710,14 +808,19 @@ namespace TwoPaCo
 					std::vector<uint64_t> fileTable;
 					ReadFilterHeader(f, name, h, fileTable);
 					if (h.k != k || h.bits != bits || h.q != q || h.round != round || h.rounds != rounds || h.low != low || h.high != high || fileTable != table ||
-						h.words != tpc_filter_words(ctx_))
+						h.words != tpc_filter_words(ctx) || h.shard != shard || h.shards != shards)
 					{
-						throw std::runtime_error("The Bloom filter checkpoint " + name + " does not belong to this round (parameters, hash tables or the round's range differ)");
+						throw std::runtime_error("The Bloom filter checkpoint " + name + " does not belong to this round (parameters, hash tables, the round's range or the shard layout differ)");
+					}
+
+					if (h.textLength != textFingerprint_[0] || h.textRecords != textFingerprint_[1] || h.textChecksum != textFingerprint_[2])
+					{
+						throw std::runtime_error("The Bloom filter checkpoint " + name + " was made from other input files (text length, record count or checksum differ)");
 					}
 
 					std::vector<uint32_t> words(h.words);
 					if (std::fread(words.data(), sizeof(uint32_t), words.size(), f) != words.size()) throw std::runtime_error("Truncated Bloom filter checkpoint: " + name);
-					Check(tpc_filter_upload(ctx_, words.data()), "filter_upload");
+					if (tpc_filter_upload(ctx, words.data()) != 0) throw std::runtime_error(std::string("filter_upload: ") + tpc_last_error(ctx));
 				}
 				catch (...)
 				{
@@ -728,6 +831,7 @@ namespace TwoPaCo
 				std::fclose(f);
 			}
 
+			uint64_t textFingerprint_[3] = {0, 0, 0};  // length, records, checksum of the packed text (Bloom filter checkpoints)
 			tpc_ctx * ctx_;
 			size_t vertices_;
 			VertexRollingHashSeed seed_;
