@@ -102,17 +102,35 @@ def sha256_file(path):
     return h.hexdigest()
 
 
-def e2e_cli(files, p, golden, runs, tmp):
+BREAKDOWN_KEYS = [("exec_to_main_ms", "exec -> main"), ("parse_pack_fasta_ms", "parse + pack FASTA"),
+                  ("hip_startup_context_ms_parallel_thread", "setup thread: HIP start-up + context"),
+                  ("filter_allocation_ms_parallel_thread", "setup thread: parameters + filter allocation"),
+                  ("code_objects_ms_parallel_thread", "warm-up thread: code objects"),
+                  ("partition_buffers_ms_parallel_thread", "setup thread: partition buffers"),
+                  ("context_upload_ms", "context + upload"), ("rounds_ms", "rounds (insert, query, exact filter)"),
+                  ("insert_ms", "round: insert"), ("query_ms", "round: query"), ("exact_filter_ms", "round: exact filter"),
+                  ("sharded_insert_query_ms", "round: sharded insert + query"),
+                  ("sort_ids_stream_ms", "sort + id lookup + junction stream"), ("write_ms", "write junction stream"),
+                  ("exec_to_output_complete_ms", "exec -> output complete"), ("exec_to_context_destroyed_ms", "exec -> context destroyed")]
+
+
+def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
     """End-to-end junction occurrences per second (SURVEY 8d metric 2; reference path constructor.cpp:161-176 -> VE ctor ->
     junctionapi.h:118-132): the `twopaco` CLI as a fresh child process, wall clock from process start to exit (output
-    file closed), FASTA files in the page cache, output sha256 checked against the reference golden."""
+    file closed), FASTA files in the page cache, output sha256 checked against the reference golden.  gpus > 1: the C++
+    multi-GPU host (`twopaco --gpus N`: one rank thread per device, the Bloom filter sharded by bit address, RCCL between them,
+    host/multigpu.cpp).  Reports the median run with its own phase timers, p50 / max, and the SLOWEST run's timers beside them
+    (a tail run must show which phase ate it)."""
     exe = os.path.join(ROOT, "twopaco_amd", "bin", "twopaco")
     threads = str(min(64, os.cpu_count() or 1))
     walls, occ, sha_ok, phases = [], None, None, []
     env = dict(os.environ, TWOPACO_TIMING="1")  # the CLI's own phase timers on stderr ([timing] lines, milliseconds)
     for rep in range(runs):
         out = os.path.join(tmp, "e2e_%d.bin" % rep)  # a fresh file each time
-        cmd = [exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", str(GOLDEN_SEED), "--tmpdir", tmp, "-o", out] + files
+        cmd = [exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", str(GOLDEN_SEED), "--tmpdir", tmp, "-o", out]
+        if gpus > 1:
+            cmd += ["--gpus", str(gpus)]
+        cmd += files
         t0 = time.perf_counter()
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.perf_counter() - t0
@@ -126,23 +144,22 @@ def e2e_cli(files, p, golden, runs, tmp):
             if not sha_ok:
                 return {"error": "e2e output differs from the reference golden %s" % golden["name"]}
         os.unlink(out)
-        time.sleep(2.5)  # the driver releases the previous process's device memory asynchronously (a run right behind another one takes seconds)
+        if settle_s > 0:
+            time.sleep(settle_s)
+    order = sorted(phases, key=lambda x: x[0])
     walls.sort()
     med = walls[len(walls) // 2]
-    ph = sorted(phases, key=lambda x: x[0])[len(phases) // 2][1]  # the median run's own timers
-    breakdown = {"exec_to_main_ms": ph.get("exec -> main"), "parse_pack_fasta_ms": ph.get("parse + pack FASTA"),
-                 "hip_startup_context_ms_parallel_thread": ph.get("setup thread: HIP start-up + context"),
-                 "filter_allocation_ms_parallel_thread": ph.get("setup thread: parameters + filter allocation"),
-                 "code_objects_ms_parallel_thread": ph.get("warm-up thread: code objects"),
-                 "partition_buffers_ms_parallel_thread": ph.get("setup thread: partition buffers"),
-                 "context_upload_ms": ph.get("context + upload"), "rounds_ms": ph.get("rounds (insert, query, exact filter)"),
-                 "insert_ms": ph.get("round: insert"), "query_ms": ph.get("round: query"), "exact_filter_ms": ph.get("round: exact filter"),
-                 "sort_ids_stream_ms": ph.get("sort + id lookup + junction stream"), "write_ms": ph.get("write junction stream"),
-                 "exec_to_output_complete_ms": ph.get("exec -> output complete"), "exec_to_context_destroyed_ms": ph.get("exec -> context destroyed")}
-    return {"e2e_wall_s": med, "breakdown_ms": breakdown, "e2e_wall_s_min": walls[0], "e2e_wall_s_all": walls, "e2e_junction_occurrences_per_sec": occ / med,
-            "junction_occurrences": occ, "runs": runs, "host_threads": int(threads),
+
+    def breakdown(ph):
+        return {k: ph.get(v) for k, v in BREAKDOWN_KEYS if ph.get(v) is not None or k in ("exec_to_main_ms", "rounds_ms", "write_ms")}
+
+    return {"e2e_wall_s": med, "breakdown_ms": breakdown(order[len(order) // 2][1]), "e2e_wall_s_min": walls[0], "e2e_wall_s_p50": med, "e2e_wall_s_max": walls[-1],
+            "e2e_wall_s_all": walls, "slowest_run_breakdown_ms": breakdown(order[-1][1]), "settle_s_between_runs": settle_s,
+            "e2e_junction_occurrences_per_sec": occ / med,
+            "junction_occurrences": occ, "runs": runs, "host_threads": int(threads), "gpus": gpus,
             "output_sha256_equals_reference": sha_ok,
-            "what": "twopaco CLI child process, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (len(files), runs)}
+            "what": "twopaco CLI child process%s, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (
+                " --gpus %d (C++ host, RCCL transport)" % gpus if gpus > 1 else "", len(files), runs)}
 
 
 def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
@@ -217,7 +234,8 @@ def main():
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
-    ap.add_argument("--e2e-runs", type=int, default=5, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
+    ap.add_argument("--e2e-runs", type=int, default=10, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
+    ap.add_argument("--e2e-settle", type=float, default=0.0, help="seconds of sleep between two CLI runs (0: back to back)")
     ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
                     help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
                          "power-of-two N), or vertex-hash ranges (the reference's rounds side by side, no data-path exchange).  auto: "
@@ -241,7 +259,16 @@ def main():
                     return cpu_baseline(recs, p, tmp, args.cpu_baseline)
                 finally:
                     shutil.rmtree(tmp, ignore_errors=True)
-        return tdist.bench_main(args, rank, world, local_rank, golden=golden_case(args.workload, args.scale), cpu_baseline=base)
+        e2e = None
+        if args.e2e_runs > 0:
+            def e2e(recs, p, gpus):
+                tmp = tempfile.mkdtemp(prefix="tpc_bench_")
+                try:
+                    return e2e_cli(write_fasta_files(recs, tmp), p, golden_case(args.workload, args.scale), min(args.e2e_runs, 3), tmp, gpus=gpus,
+                                   settle_s=args.e2e_settle)
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
+        return tdist.bench_main(args, rank, world, local_rank, golden=golden_case(args.workload, args.scale), cpu_baseline=base, e2e=e2e)
 
     import torch
     from twopaco_amd import capi, synth
@@ -348,7 +375,7 @@ def main():
     try:
         if args.e2e_runs > 0:
             files = write_fasta_files(recs, tmp)
-            out["e2e"] = e2e_cli(files, p, golden, args.e2e_runs, tmp)
+            out["e2e"] = e2e_cli(files, p, golden, args.e2e_runs, tmp, settle_s=args.e2e_settle)
             if "error" in out["e2e"]:
                 print("bench: " + out["e2e"]["error"], file=sys.stderr)
                 sys.exit(4)

@@ -136,12 +136,55 @@ def test_bench_gpus_flag_launches_ranks(tmp_path):
     assert out["result"]["junctions"] == case["distinct"] and out["result"]["junction_occurrences"] == case["true_marks"]
     assert out["result_equals_reference_golden"] is True
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "kernel_ms_rank0", "phase_ms_rank0_per_step", "all_to_all_GBs_rank0",
-                "exchange_bytes_rank0_per_step", "roofline", "result"):
+                "exchange_bytes_rank0_per_step", "roofline", "result", "rccl_version", "collective_timeout_s"):
         assert key in out, key
+    assert out["collective_timeout_s"] > 0  # every collective phase runs under the wall-clock watchdog (TPC_DIST_TIMEOUT_S)
+    # the launcher's world must be the --gpus the line claims: a mismatch is an error on every rank, not a mislabelled line
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    r = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "was launched with WORLD_SIZE = 1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     # a result that differs from the reference's counters: no line, non-zero exit
     r = subprocess.run(cmd + ["--golden-junctions", str(case["distinct"] + 1)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "differs from the reference golden" in r.stderr
+
+
+def test_watchdog_ends_a_rank_stuck_in_a_collective(tmp_path):
+    """A peer that never arrives: the waiting rank's PhaseWatchdog writes the phase's name and ends the process with exit code 17
+    within TPC_DIST_TIMEOUT_S -- the first multi-GPU run cannot hang (and torch.distributed.run then stops the other ranks)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = free_port()
+    env = dict(os.environ, TPC_DIST_TIMEOUT_S="3")
+    script = os.path.join(root, "tests", "dist_failfast.py")
+    late = subprocess.Popen([sys.executable, script, "hang", "1", "2", str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, script, "hang", "0", "2", str(port)], env=env, capture_output=True, text=True, timeout=120)
+    finally:
+        late.kill()
+        late.wait()
+    assert r.returncode == 17, (r.returncode, r.stderr[-1500:])
+    assert "collective phase 'query batch 0:all_to_all(variable)' exceeded TPC_DIST_TIMEOUT_S = 3 s" in r.stderr
+    assert time.time() - t0 < 60
+
+
+def test_local_failure_is_agreed_before_the_collective(tmp_path):
+    """One rank's local work fails between two collectives: its failure flag rides in the count exchange of the next variable
+    all_to_all (and in every max all-reduce), so BOTH ranks raise DistAbort naming the phase and the failed rank, no payload moves
+    and nobody waits (host/multigpu.cpp does the same behind its rank barrier)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = free_port()
+    env = dict(os.environ, TPC_DIST_TIMEOUT_S="30")
+    script = os.path.join(root, "tests", "dist_failfast.py")
+    procs = [subprocess.Popen([sys.executable, script, "agree", str(r), "2", str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert "tpc_shard_apply: out of device memory" in outs[1][0] and "rank(s) [1] failed" in outs[0][0]
 
 
 def test_product_has_no_injected_backend_seam():

@@ -75,10 +75,16 @@ class HipBackend:
             buf = getattr(self, "_keybuf", None)
             if buf is None or buf.numel() != 1 + cap * C:
                 buf = self._keybuf = torch.empty(1 + cap * C, dtype=torch.int64, device=dev)
-            n = ctx.junction_keys_export(buf.data_ptr() + 8, cap)
+            self._comm.phase = "junction key union"
+            try:
+                n = ctx.junction_keys_export(buf.data_ptr() + 8, cap)
+            except Exception as e:  # noqa: BLE001 -- the count slot carries the failure to every rank (agreement without an extra collective)
+                self._comm.fail(e)
+                n = -1
             buf[0] = n
             allb = self._comm.all_gather(buf)
             counts = [int(x) for x in allb[:, 0].cpu().tolist()]
+            self._comm._agreed([1 if c < 0 else 0 for c in counts], "all_gather")
             if max(counts) <= cap:
                 break
             self._cap = int(max(counts) * 1.5) + 1024
@@ -139,6 +145,53 @@ def sharded_step(backend, dist, L, abundance=(1 << 64) - 1, fetch=False):
     return st
 
 
+class DistAbort(RuntimeError):
+    """Every rank raises this together: some rank's local work failed before the collective named in the message."""
+
+
+class PhaseWatchdog:
+    """Wall-clock limit per collective phase (TPC_DIST_TIMEOUT_S, default 120 s; 0 = off).  A collective whose peers never
+    arrive blocks inside the communication library, where no Python exception can reach it; one monitor thread per process
+    watches the deadline of the phase its rank is in and, when it passes, writes the phase's name to stderr and ends the
+    process with exit code 17 (os._exit: no re-exec, no attempt to unwind through the hung call).  Under torch.distributed.run
+    the agent then stops the other ranks, so the launch as a whole exits non-zero instead of hanging; without a launcher
+    every rank's own watchdog does the same within the limit.  What the reference has in this place is a shared fetch_or
+    (concurrentbitvector.cpp:31-45) that cannot wait for anybody."""
+
+    EXIT_CODE = 17
+
+    def __init__(self, rank, timeout_s=None):
+        import threading
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("TPC_DIST_TIMEOUT_S", "120"))
+        self.rank, self.timeout = rank, timeout_s
+        self._phase, self._deadline = None, None
+        self._lock = threading.Lock()
+        if self.timeout > 0:
+            t = threading.Thread(target=self._run, name="tpc-dist-watchdog", daemon=True)
+            t.start()
+
+    def enter(self, phase):
+        with self._lock:
+            self._phase, self._deadline = phase, time.monotonic() + self.timeout
+
+    def leave(self):
+        with self._lock:
+            self._phase, self._deadline = None, None
+
+    def _run(self):
+        period = max(0.05, min(0.5, self.timeout / 4))
+        while True:
+            time.sleep(period)
+            with self._lock:
+                phase, deadline = self._phase, self._deadline
+            if deadline is not None and time.monotonic() > deadline:
+                sys.stderr.write("twopaco_amd.dist: rank %d: collective phase '%s' exceeded TPC_DIST_TIMEOUT_S = %g s "
+                                 "(a peer never arrived): exiting with code %d\n" % (self.rank, phase, self.timeout, self.EXIT_CODE))
+                sys.stderr.flush()
+                os._exit(self.EXIT_CODE)
+
+
 class _Comm:
     """The collectives of the address-sharded path over torch.distributed.  backend "nccl" (RCCL) moves
     device tensors directly; with "gloo" (tests: several ranks on one GPU) they are staged through
@@ -155,6 +208,27 @@ class _Comm:
         if chunk:
             self.CHUNK = int(chunk)
         self.bytes_moved = 0
+        self.phase = "setup"     # set by the driver: names the pass a collective belongs to (watchdog / abort messages)
+        self.rc, self.err = 0, ""  # this rank's local failure since the last agreement (AddressSharded._try)
+        self.watchdog = PhaseWatchdog(self.rank)
+
+    def _enter(self, op):
+        self.watchdog.enter("%s:%s" % (self.phase, op))
+
+    def _leave(self):
+        self.watchdog.leave()
+
+    def fail(self, exc):
+        """A local failure of this rank: remembered, and agreed upon by every rank at the next collective."""
+        if not self.rc:
+            self.rc, self.err = 1, "%s: %s" % (type(exc).__name__, exc)
+
+    def _agreed(self, flags, op):
+        """flags[r] != 0: rank r failed before this collective.  Every rank sees the same flags and raises the same DistAbort."""
+        bad = [r for r, f in enumerate(flags) if f]
+        if bad:
+            mine = " (this rank: %s)" % self.err if self.rc else ""
+            raise DistAbort("phase '%s:%s': rank(s) %s failed before the collective%s" % (self.phase, op, bad, mine))
 
     def sync(self):
         if self.torch.device(self.device).type == "cuda":
@@ -174,11 +248,21 @@ class _Comm:
         torch = self.torch
         self.sync()
         self.bytes_moved += send.numel() * send.element_size()
+        self._enter("all_to_all(equal)")
+        try:
+            return self._a2a_equal(send)
+        finally:
+            self._leave()
+
+    def _a2a_equal(self, send):
+        torch = self.torch
         if not self.p2p:
             s = self._in(send)
             r = torch.empty_like(s)
             self.dist.all_to_all_single(r, s)
-            return self._out(r)
+            out = self._out(r)
+            self.sync()
+            return out
         shape, dtype = send.shape, send.dtype
         send = self._in(send)
         sb = send.contiguous().view(torch.uint8)
@@ -198,28 +282,48 @@ class _Comm:
             if ops:
                 for w in self.dist.batch_isend_irecv(ops):
                     w.wait()
-        return self._out(recv.view(-1).view(torch.uint8).view(dtype).view(shape))
+        out = self._out(recv.view(-1).view(torch.uint8).view(dtype).view(shape))
+        self.sync()  # inside the watchdog's phase: over RCCL the waits above only order the stream
+        return out
 
     def a2a_var(self, send, counts):
         """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source)."""
         torch = self.torch
         self.sync()
-        sc = torch.as_tensor(counts, dtype=torch.int64)
+        self._enter("all_to_all(variable)")
+        try:
+            return self._a2a_var(send, counts)
+        finally:
+            self._leave()
+
+    def _a2a_var(self, send, counts):
+        torch = self.torch
+        # the count exchange carries every rank's failure flag: {count, rc} per peer, so all ranks agree before any payload moves
+        # (a rank whose local work failed sends zero counts and rc = 1; nobody is left waiting for its data)
+        if self.rc:
+            counts = [0] * self.world
+            send = send[:0]
+        sc2 = torch.empty((self.world, 2), dtype=torch.int64)
+        sc2[:, 0] = torch.as_tensor(counts, dtype=torch.int64)
+        sc2[:, 1] = self.rc
         if self.direct:
-            scd = sc.to(self.device)
+            scd = sc2.to(self.device)
             rcd = torch.empty_like(scd)
             self.dist.all_to_all_single(rcd, scd)
-            rc = rcd.cpu()
+            rc2 = rcd.cpu()
         else:
-            rc = torch.empty(self.world, dtype=torch.int64)
-            self.dist.all_to_all_single(rc, sc)
-        rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in sc.tolist()]
+            rc2 = torch.empty_like(sc2)
+            self.dist.all_to_all_single(rc2, sc2)
+        self._agreed([int(x) for x in rc2[:, 1].tolist()], "all_to_all(variable)")
+        rcl, scl = [int(x) for x in rc2[:, 0].tolist()], [int(x) for x in counts]
         self.bytes_moved += send.numel() * send.element_size()
         if not self.p2p:
             s = self._in(send)
             r = torch.empty(sum(rcl), dtype=send.dtype, device=s.device)
             self.dist.all_to_all_single(r, s, output_split_sizes=rcl, input_split_sizes=scl)
-            return self._out(r), rcl
+            out = self._out(r)
+            self.sync()
+            return out, rcl
         # RCCL: grouped send/recv, at most CHUNK bytes per peer and message
         send = self._in(send)
         r = torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
@@ -245,24 +349,52 @@ class _Comm:
             if ops:
                 for w in self.dist.batch_isend_irecv(ops):
                     w.wait()
-        return self._out(r), rcl
+        out = self._out(r)
+        self.sync()
+        return out, rcl
 
     def all_gather(self, t):
         """[world, *t.shape]"""
         torch = self.torch
         self.sync()
-        s = self._in(t.contiguous())
-        out = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-        self.dist.all_gather_into_tensor(out, s) if self.direct else self.dist.all_gather(list(out.unbind(0)), s)
-        self.bytes_moved += t.numel() * t.element_size() * self.world
-        return self._out(out)
+        self._enter("all_gather")
+        try:
+            s = self._in(t.contiguous())
+            out = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+            self.dist.all_gather_into_tensor(out, s) if self.direct else self.dist.all_gather(list(out.unbind(0)), s)
+            self.bytes_moved += t.numel() * t.element_size() * self.world
+            out = self._out(out)
+            self.sync()
+            return out
+        finally:
+            self._leave()
 
     def max_ints(self, values):
+        """Element-wise maximum over the ranks; this rank's failure flag rides along as one more element (agreement)."""
         torch = self.torch
-        v = torch.as_tensor(values, dtype=torch.int64)
-        v = v.to(self.device) if self.direct else v
-        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
-        return [int(x) for x in v.cpu().tolist()]
+        self._enter("all_reduce(max)")
+        try:
+            v = torch.as_tensor(list(values) + [self.rc], dtype=torch.int64)
+            v = v.to(self.device) if self.direct else v
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+            out = [int(x) for x in v.cpu().tolist()]
+        finally:
+            self._leave()
+        if out[-1]:
+            mine = " (this rank: %s)" % self.err if self.rc else ""
+            raise DistAbort("phase '%s:all_reduce(max)': a rank failed before the collective%s" % (self.phase, mine))
+        return out[:-1]
+
+    def agree(self):
+        """Agreement on its own (one tiny all-reduce), before collectives that carry no counts: equal-block exchanges, all_gathers."""
+        self.max_ints([])
+
+    def barrier(self, what="barrier"):
+        self._enter(what)
+        try:
+            self.dist.barrier()
+        finally:
+            self._leave()
 
 
 INSERT, QUERY = 0, 1
@@ -303,6 +435,19 @@ class AddressSharded:
         self.t[name] = self.t.get(name, 0.0) + (time.perf_counter() - t0)
         return time.perf_counter()
 
+    def _try(self, fn, *args, default=0):
+        """This rank's local work between two collectives.  A failure (a library call's error code, an out-of-memory) must not
+        leave the peers waiting in the next collective for data that will never come: it is remembered (comm.fail) and `default`
+        returned, later local work is skipped, and the next collective's count exchange / all-reduce carries the flag, so that
+        EVERY rank raises DistAbort there with the phase's name (multigpu.cpp does the same behind its rank barrier)."""
+        if self.comm.rc:
+            return default
+        try:
+            return fn(*args)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the peers must hear of it
+            self.comm.fail(e)
+            return default
+
     def _buf(self, name, nbytes):
         b = self._bufs.get(name)
         if b is None or b.numel() < nbytes:
@@ -315,14 +460,19 @@ class AddressSharded:
         send_r = self._buf("send_r", W * geom["region_block_bytes"])
         send_c = self._buf("send_c", W * geom["count_block_bytes"])
         tag = "insert" if which == INSERT else "query"
+        self.comm.phase = "%s batch %d" % (tag, batch)
         t0 = time.perf_counter()
-        n_ovf = self.ctx.shard_hash(which, batch, send_r.data_ptr(), send_c.data_ptr(), lo, hi)
+        n_ovf = self._try(self.ctx.shard_hash, which, batch, send_r.data_ptr(), send_c.data_ptr(), lo, hi)
         t0 = self._tick(tag + "_hash", t0)
+        # one tiny all-reduce BEFORE anything moves: the largest overflow list of the batch and every rank's failure flag
+        m = self.comm.max_ints([n_ovf])[0]
+        if m >= (1 << 62):
+            raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
         recv_c = self.comm.a2a_equal(send_c)
         if self.compact:
             # the regions are ~3/4 full: pack their used prefixes, move exactly those (block sizes are multiples of 128 bytes)
             packed = self._buf("packed", W * geom["region_block_bytes"])
-            nbytes = self.ctx.shard_pack(which, send_r.data_ptr(), send_c.data_ptr(), packed.data_ptr(), W)
+            nbytes = self._try(self.ctx.shard_pack, which, send_r.data_ptr(), send_c.data_ptr(), packed.data_ptr(), W, default=[0] * W)
             t0 = self._tick(tag + "_pack", t0)
             recv_r, _ = self.comm.a2a_var(packed[:sum(nbytes)].view(self.torch.int64), [b // 8 for b in nbytes])
             recv_r = recv_r.view(self.torch.uint8)
@@ -335,14 +485,12 @@ class AddressSharded:
         self.comm.sync()
         t0 = self._tick(tag + "_all_to_all", t0)
         # skew path: entries that did not fit their level-1 region, for any owner
-        m = self.comm.max_ints([n_ovf])[0]
-        if m >= (1 << 62):
-            raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
         if m > 0:
             eb = geom["overflow_entry_bytes"]
             mine = self.torch.zeros(m * eb + 8, dtype=self.torch.uint8, device=self.device)
-            self.ctx.shard_overflow_get(which, mine.data_ptr() + 8, n_ovf)
+            self._try(self.ctx.shard_overflow_get, which, mine.data_ptr() + 8, n_ovf)
             mine[:8] = self.torch.tensor([n_ovf], dtype=self.torch.int64).view(self.torch.uint8).to(self.device)
+            self.comm.agree()
             allv = self.comm.all_gather(mine)
             parts = []
             for r in range(W):
@@ -350,70 +498,95 @@ class AddressSharded:
                 parts.append(allv[r, 8:8 + n * eb])
             cat = self.torch.cat(parts).contiguous()
             self.comm.sync()
-            self.ctx.shard_overflow_set(which, cat.data_ptr(), cat.numel() // eb)
+            self._try(self.ctx.shard_overflow_set, which, cat.data_ptr(), cat.numel() // eb)
         self.comm.sync()
         return recv_r, recv_c
 
     def insert(self, lo=0, hi=None):
-        geom = self.ctx.shard_plan(INSERT, lo, hi)
-        self.ctx.filter_reset()
+        self.comm.phase = "insert plan"
+        geom = self._try(self.ctx.shard_plan, INSERT, lo, hi, default=None)
+        self.comm.agree()  # every rank has a plan (the batch geometry must agree) before the first exchange
+        self._try(self.ctx.filter_reset)
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(INSERT, geom, b, lo, hi)
             t0 = time.perf_counter()
-            (self.ctx.shard_apply_packed if self.compact else self.ctx.shard_apply)(INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
+            self._try(self.ctx.shard_apply_packed if self.compact else self.ctx.shard_apply, INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
             self._tick("insert_apply", t0)
         return geom
+
+    def _verify_rounds(self, n_first):
+        """(first function, count) of the verification's round trips.  Lazy -- function 1 alone, then 2..q-1 of what is left -- pays
+        when most first-probe survivors are Bloom false positives of function 0 (a well-filled filter: the second probe rejects
+        them); when most are true second edges (the 62-genome workload: 54 of 58 M pass every probe) every survivor makes both
+        trips and one trip with all q - 1 addresses is cheaper.  The pass rate of function 1 on THIS rank's first batch decides
+        for the batches after it; the ranks agree through an all-reduce (they must issue the same collectives)."""
+        q = self.ctx.q
+        if q < 2:
+            return []
+        mode = os.environ.get("TPC_VERIFY_ROUNDS", "auto")  # "lazy", "eager", "auto"
+        eager = mode == "eager" or (mode == "auto" and getattr(self, "_fn1_pass_rate", 0.0) > 0.5)
+        if eager or q == 2:
+            return [(1, q - 1)]
+        return [(1, 1), (2, q - 2)]
 
     def query(self, lo=0, hi=None, union=True):
         """union = False: every rank keeps only the marks of the positions it hashed (for the key-sharded second pass)."""
         torch, ctx, W = self.torch, self.ctx, self.world
-        geom = ctx.shard_plan(QUERY, lo, hi)
+        self.comm.phase = "query plan"
+        geom = self._try(ctx.shard_plan, QUERY, lo, hi, default=None)
+        self.comm.agree()
         survivors = []
+        zeros = [0] * W
         for b in range(geom["batches"]):
             recv_r, recv_c = self._exchange(QUERY, geom, b, lo, hi)
             t0 = time.perf_counter()
-            n = (ctx.shard_apply_packed if self.compact else ctx.shard_apply)(QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
+            n = self._try(ctx.shard_apply_packed if self.compact else ctx.shard_apply, QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
             t0 = self._tick("query_apply", t0)
+            self.comm.phase = "query batch %d: survivors home" % b
             sid = torch.empty(n, dtype=torch.int64, device=self.device)
-            ctx.shard_survivors(sid.data_ptr())
+            self._try(ctx.shard_survivors, sid.data_ptr())
             # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
             # their text is: a rank then needs only its own chunk of the packed text
             src = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            ctx.shard_survivor_sources(sid.data_ptr(), n, src.data_ptr())
+            self._try(ctx.shard_survivor_sources, sid.data_ptr(), n, src.data_ptr())
             perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            counts = ctx.shard_route(src.data_ptr(), n, perm.data_ptr(), W)
+            counts = self._try(ctx.shard_route, src.data_ptr(), n, perm.data_ptr(), W, default=zeros)
             send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
-            ctx.shard_permute64(sid.data_ptr(), perm.data_ptr(), n, send.data_ptr())
+            self._try(ctx.shard_permute64, sid.data_ptr(), perm.data_ptr(), n, send.data_ptr())
             sid, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
             sid = sid.contiguous()
             self.comm.sync()
             trace = [n]
             # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange
-            for fn, cnt in ([(1, 1)] if ctx.q > 1 else []) + ([(2, ctx.q - 2)] if ctx.q > 2 else []):
+            for fn, cnt in self._verify_rounds(n):
+                self.comm.phase = "query batch %d: probes of functions %d..%d" % (b, fn, fn + cnt - 1)
                 n = sid.numel()
                 addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
                 owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
-                ctx.shard_verify_addrs(fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
+                self._try(ctx.shard_verify_addrs, fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
                 # owner-major send order from the library (tpc_shard_route), answers come back in that order
                 perm = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
-                counts = ctx.shard_route(owner.data_ptr(), n * cnt, perm.data_ptr(), W)
+                counts = self._try(ctx.shard_route, owner.data_ptr(), n * cnt, perm.data_ptr(), W, default=zeros)
                 send = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
-                ctx.shard_permute64(addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
+                self._try(ctx.shard_permute64, addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
                 req, rcounts = self.comm.a2a_var(send, counts)
                 hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
                 self.comm.sync()
-                ctx.shard_probe(req.data_ptr(), req.numel(), hit.data_ptr())
+                self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
                 back, _ = self.comm.a2a_var(hit, rcounts)
                 back = back.contiguous()
                 kept = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
                 self.comm.sync()
-                m = ctx.shard_select(sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
+                m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
                 sid = kept[:m].contiguous()
                 trace.append(sid.numel())
             self.comm.sync()
-            ctx.shard_mark(sid.data_ptr(), sid.numel())
+            self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
             self._tick("query_verify", t0)
             survivors.append(trace)
+            if len(trace) > 2 and not hasattr(self, "_fn1_pass_rate"):  # a lazy batch was measured: survivors of function 1 / first-probe survivors, all ranks
+                tot = self.comm.max_ints([trace[1], trace[0]])  # (max over ranks: a decision every rank takes alike)
+                self._fn1_pass_rate = tot[0] / max(tot[1], 1)
         self.stats["survivors"] = survivors
         if not union:
             return geom
@@ -422,15 +595,17 @@ class AddressSharded:
         # chunks are all-gathered (RCCL has no bitwise reduction; an all_gather of whole masks moved W mask sizes per rank)
         words = ctx.mask_words()
         chunk = (words + W - 1) // W
+        self.comm.phase = "mask union"
         mine = torch.empty(W * chunk, dtype=torch.int32, device=self.device)
-        ctx.mask_export_padded(mine.data_ptr(), W * chunk)
+        self._try(ctx.mask_export_padded, mine.data_ptr(), W * chunk)
+        self.comm.agree()
         parts = self.comm.a2a_equal(mine).contiguous()
         folded = torch.empty(chunk, dtype=torch.int32, device=self.device)
         self.comm.sync()
-        ctx.mask_or_blocks(parts.data_ptr(), W, chunk, folded.data_ptr())
+        self._try(ctx.mask_or_blocks, parts.data_ptr(), W, chunk, folded.data_ptr())
         allm = self.comm.all_gather(folded).contiguous()
         self.comm.sync()
-        ctx.mask_import(allm.data_ptr())
+        self._try(ctx.mask_import, allm.data_ptr())
         self._tick("mask_union", t0)
         self.stats["survivors"] = survivors
         return geom
@@ -452,35 +627,38 @@ class AddressSharded:
         self.insert(lo, hi)
         self.query(lo, hi, union=False)
         t0 = time.perf_counter()
-        n = ctx.pass2_marks()
+        self.comm.phase = "second pass: marked positions to the key owners"
+        zeros = [0] * W
+        none = {"true": 0, "false": 0, "table": 0}
+        n = self._try(ctx.pass2_marks)
         if records:
             rw = ctx.key_words() + 1
             rec = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
             owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            ctx.pass2_mark_records(W, rec.data_ptr(), owner.data_ptr())
+            self._try(ctx.pass2_mark_records, W, rec.data_ptr(), owner.data_ptr())
             perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            counts = ctx.shard_route(owner.data_ptr(), n, perm.data_ptr(), W)
+            counts = self._try(ctx.shard_route, owner.data_ptr(), n, perm.data_ptr(), W, default=zeros)
             send = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
-            ctx.shard_permute_rows(rec.data_ptr(), perm.data_ptr(), n, rw, send.data_ptr())
+            self._try(ctx.shard_permute_rows, rec.data_ptr(), perm.data_ptr(), n, rw, send.data_ptr())
             recv, _ = self.comm.a2a_var(send[:n * rw].contiguous(), [c * rw for c in counts])
             recv = recv.contiguous()
             self.comm.sync()
-            st = ctx.pass2_filter_records(recv.data_ptr(), recv.numel() // rw, abundance)
+            st = self._try(ctx.pass2_filter_records, recv.data_ptr(), recv.numel() // rw, abundance, default=dict(none))
             st["marks"] = n
             self.stats["pass2_positions_received"] = recv.numel() // rw
             self._tick("pass2_sharded", t0)
             return st
         pos = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        ctx.pass2_mark_owners(W, pos.data_ptr(), owner.data_ptr())
+        self._try(ctx.pass2_mark_owners, W, pos.data_ptr(), owner.data_ptr())
         perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        counts = ctx.shard_route(owner.data_ptr(), n, perm.data_ptr(), W)
+        counts = self._try(ctx.shard_route, owner.data_ptr(), n, perm.data_ptr(), W, default=zeros)
         send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
-        ctx.shard_permute64(pos.data_ptr(), perm.data_ptr(), n, send.data_ptr())
+        self._try(ctx.shard_permute64, pos.data_ptr(), perm.data_ptr(), n, send.data_ptr())
         recv, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
         recv = recv.contiguous()
         self.comm.sync()
-        st = ctx.pass2_filter_positions(recv.data_ptr(), recv.numel(), abundance)
+        st = self._try(ctx.pass2_filter_positions, recv.data_ptr(), recv.numel(), abundance, default=dict(none))
         st["marks"] = n
         self.stats["pass2_positions_received"] = recv.numel()
         self._tick("pass2_sharded", t0)
@@ -554,7 +732,23 @@ def merge_records(parts, rec_start, rec_length, k, n_junctions):
     return out
 
 
-def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None, cpu_baseline=None):
+def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None, cpu_baseline=None, e2e=None):
+    """Fail-fast wrapper: any exception on any rank ends THAT process with a non-zero exit code at once (the phase it was in on
+    stderr) -- under torch.distributed.run the agent then stops the other ranks; ranks blocked in a collective are ended by
+    their own watchdog (PhaseWatchdog).  No line is printed by a run that did not complete on every rank."""
+    try:
+        return _bench_main(args, rank, world, local_rank, backend_factory, golden, cpu_baseline, e2e)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write("twopaco_amd.dist: rank %d failed (%s: %s): exiting with code 4\n" % (rank, type(e).__name__, e))
+        sys.stderr.flush()
+        os._exit(4)  # not sys.exit: interpreter teardown would try to destroy a process group whose peers are gone
+
+
+def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None, cpu_baseline=None, e2e=None):
     """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload, one process per GPU over RCCL.
 
     The headline decomposition is the north star's at every N that is a power of two -- the Bloom filter sharded by bit
@@ -571,6 +765,8 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
 
     backend = os.environ.get("TPC_DIST_BACKEND", "nccl")  # "gloo": several ranks on one GPU (testing only)
     injected = backend_factory is not None
+    if getattr(args, "gpus", world) != world:  # the launcher's world must be the --gpus the line will claim
+        raise RuntimeError("bench.py --gpus %d was launched with WORLD_SIZE = %d" % (args.gpus, world))
     pow2 = world & (world - 1) == 0
     decomposition = getattr(args, "decomposition", "auto")
     if decomposition == "auto":
@@ -626,8 +822,18 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
             ctx_r.seq_upload(text)
             be = HipBackend(ctx_r)
             steps["ranges"] = lambda: sharded_step(be, dist, p["L"])
+    if dist.get_world_size() != world:
+        raise RuntimeError("process group of %d ranks, expected %d" % (dist.get_world_size(), world))
     dev = _dev(dist)
+    wd = PhaseWatchdog(rank)  # the bench's own barriers and reductions (the exchanges inside a step have theirs in _Comm)
     names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "shard_hash", "shard_apply"]
+
+    def guarded(name, fn, *a, **kw):
+        wd.enter(name)
+        try:
+            return fn(*a, **kw)
+        finally:
+            wd.leave()
 
     def timed(which):
         step = steps[which]
@@ -639,7 +845,7 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
             sh.t.clear()
             sh.stats["region_bytes_sent"] = 0
             moved0 = sh.comm.bytes_moved
-        dist.barrier()
+        guarded("bench: barrier before the timed steps", dist.barrier)
         if ctx is not None:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -650,12 +856,12 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
                     kms[n] += max(kctx.kernel_ms(n), 0.0) / args.steps
         if ctx is not None:
             torch.cuda.synchronize()
-        dist.barrier()
+        guarded("bench: barrier after the timed steps", dist.barrier)
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        guarded("bench: max of the step times", dist.all_reduce, dt, op=dist.ReduceOp.MAX)
         tot = torch.tensor([st["n_valid"], st["marks"]], dtype=torch.int64, device=dev)
         if which == "ranges" or sharded2:  # (address-sharded with the replicated second pass: every rank already holds the whole result)
-            dist.all_reduce(tot)
+            guarded("bench: sum of the per-rank counters", dist.all_reduce, tot)
         r = {"dt": float(dt.item()), "kms": kms, "result": {"candidate_marks": int(tot[1].item()), "junctions": st["junctions"], "junction_occurrences": int(tot[0].item())}}
         if which == "address":
             r["phase_ms"] = {k: v * 1e3 / args.steps for k, v in sh.t.items()}
@@ -685,52 +891,80 @@ def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None,
                 if rank == 0:
                     print("bench: %s decomposition: result differs from the reference golden (got, want): %r" % (which, bad), file=sys.stderr)
     dt = head["dt"]
-    if rank == 0 and ok:
-        kms = head["kms"]
-        qms = max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9)
-        # bytes rank 0's first-pass query moves by construction (bench.py: 6 uint64 entries per k-mer x 4 transfers, the
-        # packed text, one pass over the filter): ranges -> whole text hashed, 1/world of the entries, whole filter;
-        # address -> 1/world of the text, of the entries and of the filter
-        fb = (1 << p["L"]) // 8
-        design = (0.375 * n_kmers / world + 6 * n_kmers / world * 32 + fb / world) if address else (0.375 * n_kmers + 6 * n_kmers / world * 32 + fb)
-        out = {
-            "metric": "kmers_hashed_per_sec", "value": n_kmers * args.steps / dt, "unit": "k-mers/s", "n_gpus": world,
-            "ranks": dist.get_world_size(), "backend": "injected" if injected else ("rccl" if backend == "nccl" else backend),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload_desc,
-                       "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
-                       "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of packed level-1 regions per pass, per-function survivor probes; " % world) +
-                                      ({"records": "text sharded too; exact-filter table sharded by key hash ((key, prev|next) records to the key's owner), all_gather of the junction keys",
-                                        "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
-                                        "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
-                       if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
-            "junction_occurrences_per_sec": head["result"]["junction_occurrences"] * args.steps / dt,
-            "kernel_ms_rank0": kms,
-            "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0", "achieved": design / (qms * 1e-3) / 1e9,
-                         "peak": 8000.0, "unit": "GB/s", "frac": design / (qms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                         "algorithmic_bytes_per_launch": design, "launch_ms": qms} if ctx is not None else None,
-            "exchange_bytes_rank0_per_step": head.get("exchange_bytes"),
-            "region_bytes_sent_rank0_per_step": head.get("region_bytes_sent"),
-            "all_to_all_GBs_rank0": head.get("all_to_all_GBs"),
-            "phase_ms_rank0_per_step": head.get("phase_ms"),
-            "survivors_rank0": head.get("survivors"),
-            "result": head["result"],
-            "result_equals_reference_golden": True if golden else None,
-        }
-        if second is not None:
-            out["ranges"] = {"value": n_kmers * args.steps / second["dt"], "unit": "k-mers/s", "ms_per_step": second["dt"] / args.steps * 1e3,
-                             "decomposition": "%d vertex-hash ranges, one per GPU, no data-path exchange (DESIGN.md section 5.1)" % world,
-                             "kernel_ms_rank0": second["kms"], "result": second["result"]}
-        if cpu_baseline is not None and recs is not None:
-            out["cpu_baseline"] = cpu_baseline(recs, p)
-        try:  # librccl prints a version banner through C stdio, which would otherwise land behind the JSON line when the process ends
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
-    dist.barrier()
+    # Every rank gives its device back -- contexts closed, process group left -- before rank 0 runs the end-to-end leg: the
+    # `twopaco --gpus N` child process takes all N devices itself.  After this point no collective is issued: ranks other than 0
+    # leave (exit code 3 when the golden check failed), rank 0 finishes the line alone, so nobody waits in a barrier while a CPU
+    # baseline of a minute runs.
+    rccl_version = None
+    try:
+        if not injected and backend == "nccl":
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        pass
+    for c in (ctx, ctx_r):
+        if c is not None:
+            c.close()
+    if ctx is not None:
+        torch.cuda.empty_cache()
+    guarded("bench: barrier before leaving the process group", dist.barrier)
     dist.destroy_process_group()
     if not ok:
         sys.exit(3)
+    if rank != 0:
+        return 0
+    kms = head["kms"]
+    qms = max(kms["shard_apply"] + kms["shard_hash"] if address else kms["query"], 1e-9)
+    # bytes rank 0's first-pass query moves by construction (bench.py: 6 uint64 entries per k-mer x 4 transfers, the
+    # packed text, one pass over the filter): ranges -> whole text hashed, 1/world of the entries, whole filter;
+    # address -> 1/world of the text, of the entries and of the filter
+    fb = (1 << p["L"]) // 8
+    design = (0.375 * n_kmers / world + 6 * n_kmers / world * 32 + fb / world) if address else (0.375 * n_kmers + 6 * n_kmers / world * 32 + fb)
+    out = {
+        "metric": "kmers_hashed_per_sec", "value": n_kmers * args.steps / dt, "unit": "k-mers/s", "n_gpus": world,
+        "ranks": world, "backend": "injected" if injected else ("rccl" if backend == "nccl" else backend), "rccl_version": rccl_version,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload_desc,
+                   "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
+                   "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of packed level-1 regions per pass, per-function survivor probes; " % world) +
+                                  ({"records": "text sharded too; exact-filter table sharded by key hash ((key, prev|next) records to the key's owner), all_gather of the junction keys",
+                                    "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
+                                    "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
+                   if address else ("%d vertex-hash ranges, one per GPU (reference rounds run side by side); all-gather of junction keys over RCCL" % world)},
+        "junction_occurrences_per_sec": head["result"]["junction_occurrences"] * args.steps / dt,
+        "kernel_ms_rank0": kms,
+        "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0", "achieved": design / (qms * 1e-3) / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": design / (qms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": design, "launch_ms": qms} if ctx is not None else None,
+        "exchange_bytes_rank0_per_step": head.get("exchange_bytes"),
+        "region_bytes_sent_rank0_per_step": head.get("region_bytes_sent"),
+        "all_to_all_GBs_rank0": head.get("all_to_all_GBs"),
+        "phase_ms_rank0_per_step": head.get("phase_ms"),
+        "survivors_rank0": head.get("survivors"),
+        "collective_timeout_s": wd.timeout,
+        "result": head["result"],
+        "result_equals_reference_golden": True if golden else None,
+    }
+    if second is not None:
+        out["ranges"] = {"value": n_kmers * args.steps / second["dt"], "unit": "k-mers/s", "ms_per_step": second["dt"] / args.steps * 1e3,
+                         "decomposition": "%d vertex-hash ranges, one per GPU, no data-path exchange (DESIGN.md section 5.1)" % world,
+                         "kernel_ms_rank0": second["kms"], "result": second["result"]}
+    # the metric's second half at N GPUs: the C++ host end to end (`twopaco --gpus N`, host/multigpu.cpp: RCCL transport), fresh child
+    # processes on the FASTA files, output sha256 == the reference golden.  A failure here fails the run (no line).
+    if e2e is not None and recs is not None:
+        time.sleep(2.0)  # the other ranks' processes are on their way out: let the driver have their device memory back
+        out["e2e"] = e2e(recs, p, world)
+        if "error" in out["e2e"]:
+            sys.stderr.write("bench: end-to-end leg (twopaco --gpus %d) failed: %s\n" % (world, out["e2e"]["error"]))
+            sys.exit(4)
+        out["e2e_junction_occurrences_per_sec"] = out["e2e"]["e2e_junction_occurrences_per_sec"]
+        out["e2e_wall_s"] = out["e2e"]["e2e_wall_s"]
+    if cpu_baseline is not None and recs is not None:
+        out["cpu_baseline"] = cpu_baseline(recs, p)
+    try:  # librccl prints a version banner through C stdio, which would otherwise land behind the JSON line when the process ends
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    print(json.dumps(out), flush=True)
+    return 0
