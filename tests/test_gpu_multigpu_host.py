@@ -175,3 +175,61 @@ def test_cli_gpus_flag(tmp_path):
     assert "GPUs = 2" in r.stdout and "Distinct junctions = %d" % case["distinct"] in r.stdout
     bad = subprocess.run([exe, "-k", "9", "-f", "14", "--gpus", "3", os.path.join(GOLDEN, case["fasta"])], capture_output=True, text=True)
     assert bad.returncode == 1 and "power of two" in bad.stderr
+
+
+@pytest.mark.parametrize("name,ranks", [("rand6_k9_L24_r4", 2), ("c2_k29_L26_r3", 4), ("lk_k603_r2", 2)])
+def test_sharded_run_prints_the_reference_round_ranges(capi, tmp_path, name, ranks, monkeypatch):
+    """`twopaco --gpus N -r R`: the split pass (InitialFilterFillerWorker, VE.h:503-583, planner VE.h:206-254) runs on one device
+    in a context of its own while a whole scratch filter fits there, so the sharded run prints the SAME `Round n, lo:hi` lines
+    as the reference on collision-free goldens (where the histogram is order independent), besides writing its bytes.  With
+    TWOPACO_ANALYTIC_SPLIT=1 (what a run falls back to when the scratch filter does not fit) the ranges are the analytic
+    quantiles: other lines, the same bytes."""
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"], tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    log = _check(case, e, out)
+    assert [(r["low"], r["high"]) for r in log["rounds"]] == [(r["low"], r["high"]) for r in case["rounds"]]
+    assert [r["true"] for r in log["rounds"]] == [r["true"] for r in case["rounds"]]
+    e.close()
+    monkeypatch.setenv("TWOPACO_ANALYTIC_SPLIT", "1")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"], tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    assert "analytic quantiles" in e.log
+    e.close()
+
+
+def test_cli_sharded_filter_checkpoint_roundtrip(tmp_path):
+    """--save-filter / --load-filter with --gpus N: every rank's shard of every round goes to its own file
+    (<name>[.<round>].shard<r>of<N>) and comes back instead of the sharded insert; the reloaded run writes the golden bytes; a
+    checkpoint of another rank count, or made from other input files, is refused (the header carries the shard layout and a
+    fingerprint of the packed text)."""
+    case = CASES["rand6_k9_fp_r4"]
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "twopaco_amd", "bin", "twopaco")
+    fa = os.path.join(GOLDEN, case["fasta"])
+    ck = str(tmp_path / "bloom.ckpt")
+    # (f = 20 instead of the golden's saturated 14: the sharded pass has no fallback for a full filter; positions and ids do not depend on f)
+    base = [exe, "-k", str(case["k"]), "-f", "20", "-q", str(case["q"]), "-r", "2", "-t", "2", "--tmpdir", str(tmp_path), "--gpus", "2", "--emulate-ranks"]
+    out1, out2 = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    r = subprocess.run(base + ["--seed", str(case["seed"]), "--save-filter", ck, "-o", out1, fa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name in ("bloom.ckpt.shard0of2", "bloom.ckpt.shard1of2", "bloom.ckpt.1.shard0of2", "bloom.ckpt.1.shard1of2"):
+        assert os.path.exists(str(tmp_path / name)), name
+    r2 = subprocess.run(base + ["--load-filter", ck, "-o", out2, fa], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert open(out1, "rb").read() == open(out2, "rb").read()
+    rounds = lambda s: [ln for ln in s.splitlines() if ln.startswith("Round ")]
+    assert rounds(r.stdout) == rounds(r2.stdout) and len(rounds(r.stdout)) == 2
+    # one GPU wrote the same records (ids and positions do not depend on how the filter is cut)
+    out3 = str(tmp_path / "c.bin")
+    r3 = subprocess.run([exe, "-k", str(case["k"]), "-f", "20", "-q", str(case["q"]), "-r", "2", "--seed", str(case["seed"]), "--tmpdir", str(tmp_path), "-o", out3, fa],
+                        capture_output=True, text=True)
+    assert r3.returncode == 0 and open(out3, "rb").read() == open(out1, "rb").read()
+    # four ranks cannot take a two-rank checkpoint
+    bad = subprocess.run(base[:-3] + ["--gpus", "4", "--emulate-ranks", "--load-filter", ck, "-o", out2, fa], capture_output=True, text=True)
+    assert bad.returncode == 1 and "checkpoint" in bad.stderr
+    # another input: refused by the text fingerprint
+    other = os.path.join(GOLDEN, "c2.fa")
+    bad = subprocess.run(base + ["--load-filter", ck, "-o", out2, other], capture_output=True, text=True)
+    assert bad.returncode == 1 and "other input files" in bad.stderr

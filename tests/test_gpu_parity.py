@@ -668,6 +668,10 @@ def test_cli_filter_checkpoint_roundtrip(tmp_path):
     r3 = subprocess.run([exe, "-k", str(case["k"] + 2), "-f", str(case["L"]), "-q", str(case["q"]), "-r", str(case["n_rounds"]), "--load-filter", ck,
                          "-o", out2, "--tmpdir", str(tmp_path), fa], capture_output=True, text=True)
     assert r3.returncode == 1 and "other parameters" in r3.stderr
+    # a filter filled from OTHER input files is refused (the header carries the text's length, record count and a checksum): loaded
+    # silently it would drop junctions (Bloom false negatives)
+    r4 = subprocess.run(base + ["--load-filter", ck, "-o", out2, os.path.join(GOLDEN, "c2.fa")], capture_output=True, text=True)
+    assert r4.returncode == 1 and "other input files" in r4.stderr
 
 
 def test_cli_selftest_is_reproducible_with_seed(tmp_path):

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <stdexcept>
@@ -507,15 +508,18 @@ namespace TwoPaCo
 		const int W = net.Ranks();
 		uint64_t geom[16];
 		r.PhaseBegin();
-		// ---- insert (FilterFillerWorker)
-		LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_INSERT, lo, hi, geom), "shard_plan(insert)");
-		LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
-		r.Phase("plan");
-		for (uint64_t b = 0; b < geom[0]; b++)
+		// ---- insert (FilterFillerWorker); skipped when the shard came from a checkpoint
+		if (!r.filterLoaded)
 		{
-			HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
-			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
-			r.Phase("insert apply");
+			LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_INSERT, lo, hi, geom), "shard_plan(insert)");
+			LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
+			r.Phase("plan");
+			for (uint64_t b = 0; b < geom[0]; b++)
+			{
+				HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
+				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+				r.Phase("insert apply");
+			}
 		}
 
 		net.Barrier().Wait();  // every shard is complete before anyone probes it
@@ -533,9 +537,39 @@ namespace TwoPaCo
 			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
 			n = ReturnSurvivors(r, net, n);
 			r.Phase("survivors home");
-			// function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together
-			if (hashFunctions > 1) n = VerifyStep(r, net, n, 1, 1);
-			if (hashFunctions > 2) n = VerifyStep(r, net, n, 2, hashFunctions - 2);
+			// Lazy: function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together --
+			// two round trips.  Where most first-probe survivors are true second edges instead (the 62-genome workload: 54 of 58 M
+			// pass every probe) every survivor makes both trips, and one trip with all q - 1 addresses is cheaper: the share that
+			// passed function 1 in the first lazy batch, summed over the ranks (they must issue the same collectives), decides for
+			// every batch after it.  TWOPACO_VERIFY_ROUNDS = lazy | eager pins the choice.
+			if (r.verifyEager < 0)
+			{
+				const char * pin = std::getenv("TWOPACO_VERIFY_ROUNDS");
+				if (pin && std::string(pin) == "eager") r.verifyEager = 1;
+				else if (pin && std::string(pin) == "lazy") r.verifyEager = 0;
+			}
+
+			if (hashFunctions == 2 || (hashFunctions > 2 && r.verifyEager == 1))
+			{
+				n = VerifyStep(r, net, n, 1, hashFunctions - 1);
+			}
+			else if (hashFunctions > 2)
+			{
+				const uint64_t before = n;
+				n = VerifyStep(r, net, n, 1, 1);
+				if (r.verifyEager < 0)
+				{
+					const uint64_t mine[2] = { n, before };
+					std::vector<uint64_t> all;
+					net.ExchangeHost(r.rank, mine, 2, all);
+					uint64_t passed = 0, asked = 0;
+					for (int s = 0; s < W; s++) { passed += all[size_t(s) * 2]; asked += all[size_t(s) * 2 + 1]; }
+					if (asked > 0) r.verifyEager = passed * 2 > asked ? 1 : 0;
+				}
+
+				n = VerifyStep(r, net, n, 2, hashFunctions - 2);
+			}
+
 			LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");
 			r.Phase("verify + mark");
 		}

@@ -92,6 +92,8 @@ namespace TwoPaCo
 		// rank); false: union of the candidate masks, the single-GPU second pass on rank 0, which keeps the whole text
 		bool shardedSecondPass;
 		uint64_t regionBytesSent;
+		bool filterLoaded;  // this round's filter shard was restored from a checkpoint (tpc_filter_upload): ShardedFirstPass skips the insert
+		int verifyEager;  // survivor verification: -1 not decided yet, 0 lazy (function 1 alone, then the rest), 1 all q - 1 functions in one round trip
 		// TWOPACO_TIMING=1: host-clock milliseconds per phase of the first pass (every phase ends synchronised), printed by rank 0
 		std::vector<std::pair<std::string, double> > phaseMs;
 		std::chrono::steady_clock::time_point phaseT0;
@@ -99,7 +101,7 @@ namespace TwoPaCo
 		void PhaseBegin();
 		void Phase(const char * name);  // time since the previous Phase / PhaseBegin goes to `name`
 		void PhasePrint(const char * title);
-		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), phaseOn(false) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), filterLoaded(false), verifyEager(-1), phaseOn(false) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};

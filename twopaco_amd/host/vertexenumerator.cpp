@@ -108,9 +108,12 @@ namespace TwoPaCo
 			return h;
 		}
 
-		std::string FilterFileName(const std::string & base, size_t round)
+		// one file per round; a filter sharded by bit address over several GPUs: one file per round and rank
+		std::string FilterFileName(const std::string & base, size_t round, size_t shard = 0, size_t shards = 1)
 		{
-			return round == 0 ? base : base + "." + std::to_string(round);
+			std::string name = round == 0 ? base : base + "." + std::to_string(round);
+			if (shards > 1) name += ".shard" + std::to_string(shard) + "of" + std::to_string(shards);
+			return name;
 		}
 
 		void ReadFilterHeader(std::FILE * f, const std::string & name, FilterFileHeader & h, std::vector<uint64_t> & table)
@@ -246,18 +249,17 @@ namespace TwoPaCo
 
 				PhaseTimer timer;
 				std::vector<uint64_t> table;
-				if ((!options.saveFilter.empty() || !options.loadFilter.empty()) && sharded)
-				{
-					throw std::runtime_error("--save-filter / --load-filter need the whole filter on one GPU (not available with --gpus)");
-				}
-
+				// (a sharded run checkpoints every rank's shard in its own file, <name>[.<round>].shard<r>of<W>: the shard layout depends on
+				//  the number of ranks, so such a checkpoint reloads into a run with the same --gpus only)
+				const size_t ckptShards = sharded ? size_t(gpus) : 1;
 				if (!options.loadFilter.empty())
 				{
 					// the filter's bits mean something only under the hash tables they were set with: those come from the file
-					std::FILE * f = std::fopen(options.loadFilter.c_str(), "rb");
-					if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + options.loadFilter);
+					const std::string first = FilterFileName(options.loadFilter, 0, 0, ckptShards);
+					std::FILE * f = std::fopen(first.c_str(), "rb");
+					if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + first);
 					FilterFileHeader h;
-					try { ReadFilterHeader(f, options.loadFilter, h, table); } catch (...) { std::fclose(f); throw; }
+					try { ReadFilterHeader(f, first, h, table); } catch (...) { std::fclose(f); throw; }
 					std::fclose(f);
 					if (h.k != vertexLength || h.bits != filterSize || h.q != hashFunctions || h.rounds != rounds)
 					{
@@ -434,14 +436,34 @@ namespace TwoPaCo
 					binCounter.resize(BINS_COUNT + 1);
 					if (sharded)
 					{
-						// The split pass needs the whole filter as scratch, which no rank holds.  The vertex hash is the minimum of
-						// two well mixed L-bit hashes (density 2(1-x) over [0, 2^L)), so the histogram the pass would measure is
-						// known in expectation: bin b gets the mass of [b, b+1) * BIN_SIZE; the planner below then cuts equal shares.
-						const double bins = double(BINS_COUNT);
-						for (uint64_t b = 0; b < BINS_COUNT; b++)
+						// The split pass (InitialFilterFillerWorker, vertexenumerator.h:503-583) needs ONE whole filter as scratch, which no
+						// rank of a sharded run holds.  While a whole filter and the whole text still fit one device beside rank 0's shard
+						// (f = 40 and 100 human genomes: 128 + 75 GB of 288) the pass runs there, in a context of its own that is gone again
+						// before the rounds start: the histogram, hence the "Round n, lo:hi" lines, are then those of a one-GPU run.
+						bool measured = false;
+						if (!nothing && std::getenv("TWOPACO_ANALYTIC_SPLIT") == 0)
 						{
-							const double x0 = double(b) / bins, x1 = double(b + 1) / bins;
-							binCounter[b] = uint32_t(((1.0 - (1.0 - x1) * (1.0 - x1)) - (1.0 - (1.0 - x0) * (1.0 - x0))) * 4e9 / 2.0);
+							tpc_ctx * scratch = 0;
+							if (tpc_ctx_create(options.device, &scratch) == 0)
+							{
+								measured = tpc_set_params(scratch, int(vertexLength), int(filterSize), int(hashFunctions), table.data()) == 0 &&
+									tpc_seq_upload(scratch, text.bases.data(), text.nmask.data(), text.length) == 0 &&
+									tpc_pass1_split_hist(scratch, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()) == 0;
+								tpc_ctx_destroy(scratch);
+							}
+						}
+
+						if (!measured && !nothing)
+						{
+							// Otherwise the histogram is taken in expectation: the vertex hash is the minimum of two well mixed L-bit hashes
+							// (density 2(1-x) over [0, 2^L)), so bin b gets the mass of [b, b+1) * BIN_SIZE; the planner below cuts equal shares.
+							logStream << "(the split pass does not fit one GPU beside its filter shard: rounds cut at the analytic quantiles of the vertex hash)" << std::endl;
+							const double bins = double(BINS_COUNT);
+							for (uint64_t b = 0; b < BINS_COUNT; b++)
+							{
+								const double x0 = double(b) / bins, x1 = double(b + 1) / bins;
+								binCounter[b] = uint32_t(((1.0 - (1.0 - x1) * (1.0 - x1)) - (1.0 - (1.0 - x0) * (1.0 - x0))) * 4e9 / 2.0);
+							}
 						}
 					}
 					else if (!nothing) Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
@@ -461,7 +483,7 @@ namespace TwoPaCo
 					{
 						// the round's range is the one its filter was filled for (the split pass that chose it counts first-seen edges in
 						// arrival order, vertexenumerator.h:559-570: a rerun may cut a saturated filter's rounds a few bins away)
-						const std::string name = FilterFileName(options.loadFilter, round);
+						const std::string name = FilterFileName(options.loadFilter, round, 0, ckptShards);
 						std::FILE * f = std::fopen(name.c_str(), "rb");
 						if (!f) throw std::runtime_error("Can't open the Bloom filter checkpoint " + name);
 						FilterFileHeader h;
@@ -526,7 +548,22 @@ namespace TwoPaCo
 							{
 								try
 								{
+									// checkpoint: this rank's shard of the round's filter instead of the sharded insert (the query half of the
+									// pass is the same), or written out after it (the query does not touch the filter)
+									peers_[r].filterLoaded = !options.loadFilter.empty();
+									if (peers_[r].filterLoaded)
+									{
+										LoadFilter(FilterFileName(options.loadFilter, round, size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
+											peers_[r].ctx, uint32_t(r), uint32_t(ckptShards));
+									}
+
 									ShardedFirstPass(peers_[r], *net, int(hashFunctions), low, high);
+									if (!options.saveFilter.empty())
+									{
+										SaveFilter(FilterFileName(options.saveFilter, round, size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
+											peers_[r].ctx, uint32_t(r), uint32_t(ckptShards));
+									}
+
 									if (shardedPass2) ShardedSecondPass(peers_[r], *net, abundance, &roundCounters[size_t(r) * 4]);
 								}
 								catch (std::exception & e)
