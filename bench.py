@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 G_BYTES = 64           # HBM access granule of a scattered 4-byte access (SURVEY 8d planning value)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
 GOLDEN_SEED = 20240229  # tests/golden/make_golden.py: the seed the reference goldens were made with
-PMC_PROFILE = "r03_pmc_traffic.json"
+PMC_PROFILE = "r04_pmc_traffic.json"
 
 
 def launch_ranks(args, script=None):
@@ -234,8 +234,11 @@ def main():
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
-    ap.add_argument("--e2e-runs", type=int, default=10, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
-    ap.add_argument("--e2e-settle", type=float, default=0.0, help="seconds of sleep between two CLI runs (0: back to back)")
+    ap.add_argument("--e2e-runs", type=int, default=5, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
+    ap.add_argument("--e2e-settle", type=float, default=2.5,
+                    help="seconds between two CLI runs of the headline series: the driver wipes a finished process's device memory "
+                         "asynchronously and an allocation that is handed one of those blocks waits ~3 s for it (profiles/r04f_e2e_back_to_back.txt)")
+    ap.add_argument("--e2e-b2b-runs", type=int, default=6, help="runs of the second series, started right behind one another (reported as e2e_back_to_back; 0 = skip)")
     ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
                     help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
                          "power-of-two N), or vertex-hash ranges (the reference's rounds side by side, no data-path exchange).  auto: "
@@ -249,6 +252,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and os.environ.get("TPC_FORCE_DIST") and "RANK" not in os.environ:  # one rank without a launcher: its own rendezvous
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+        s.close()
     if world > 1 or os.environ.get("TPC_FORCE_DIST"):  # TPC_FORCE_DIST: exercise the distributed path with one rank
         from twopaco_amd import dist as tdist
         base = None
@@ -340,14 +348,21 @@ def main():
         else:
             pmc_tag = "stale: %s was collected on other kernel sources" % PMC_PROFILE
 
-    def roof(kernel, ms, design, traffic, survey_bytes):
+    def roof(kernel, ms, design, traffic, survey_bytes, floor_per_kmer):
         ach = design / (ms * 1e-3) / 1e9
+        floor = floor_per_kmer * n_kmers
         d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": traffic, "traffic_source": pmc_tag, "launch_ms": ms, "algorithmic_bytes_per_launch": design,
              "algorithmic_bytes_per_kmer": design / n_kmers,
              "measured_hbm_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
              "measured_hbm_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-             "survey_model_GBs": n_kmers * survey_bytes / (ms * 1e-3) / 1e9}
+             "survey_model_GBs": n_kmers * survey_bytes / (ms * 1e-3) / 1e9,
+             # the implementation-independent floor ("the word-level lower bound ... what a perfectly write-combined /
+             # bucketed implementation approaches"): every address crosses HBM once as an 8-byte word, plus the packed text.  `frac`
+             # above is priced with what THIS design moves, so a design change that moves fewer bytes lowers numerator and time
+             # together; frac_of_floor only moves when the pass gets faster.
+             "floor_bytes": floor, "floor_bytes_per_kmer": floor_per_kmer, "frac_of_floor": floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "bytes_over_floor": design / floor}
         return d
 
     out = {
@@ -367,18 +382,28 @@ def main():
         "result_equals_reference_golden": result_ok,
         "upload_s_pcie": upload_s,
         # the dominant kernel group of a step is the first-pass query (k_q_hash + k_q_split + k_q_lookup + k_q_verify)
-        "roofline": roof("first-pass query (k_q_hash, k_q_split, k_q_lookup / its share of k_apply_lookup, k_q_verify)", qry_ms, design_qry, traffic_qry, 0.375 + 6 * G_BYTES),
+        "roofline": roof("first-pass query (k_q_hash, k_q_split, k_q_lookup / its share of k_apply_lookup, k_q_verify)", qry_ms, design_qry, traffic_qry, 0.375 + 6 * G_BYTES, 0.375 + 6 * 8),
         # the north star's roofline kernel: first-pass Bloom insert
-        "roofline_insert": roof("first-pass insert (k_part_hash, k_part_split, k_part_apply / its share of k_apply_lookup)", ins_ms, design_ins, traffic_ins, 0.25 + q * 2 * G_BYTES),
+        "roofline_insert": roof("first-pass insert (k_part_hash, k_part_split, k_part_apply / its share of k_apply_lookup)", ins_ms, design_ins, traffic_ins, 0.25 + q * 2 * G_BYTES, 0.25 + 8 * q),
     }
     tmp = tempfile.mkdtemp(prefix="tpc_bench_")
     try:
         if args.e2e_runs > 0:
             files = write_fasta_files(recs, tmp)
+            time.sleep(args.e2e_settle)  # this process's own context (60 GB) has just been closed
             out["e2e"] = e2e_cli(files, p, golden, args.e2e_runs, tmp, settle_s=args.e2e_settle)
             if "error" in out["e2e"]:
                 print("bench: " + out["e2e"]["error"], file=sys.stderr)
                 sys.exit(4)
+            if args.e2e_b2b_runs > 0:  # the same CLI run started right behind its predecessor: p50 / max and the slowest run's own timers
+                b2b = e2e_cli(files, p, golden, args.e2e_b2b_runs, tmp, settle_s=0.0)
+                if "error" in b2b:
+                    print("bench: " + b2b["error"], file=sys.stderr)
+                    sys.exit(4)
+                out["e2e_back_to_back"] = {k: b2b[k] for k in ("e2e_wall_s_p50", "e2e_wall_s_min", "e2e_wall_s_max", "e2e_wall_s_all", "breakdown_ms",
+                                                              "slowest_run_breakdown_ms", "runs", "output_sha256_equals_reference")}
+                out["e2e_back_to_back"]["what"] = ("the same CLI runs with no pause between them: an allocation of a run that is handed device memory the driver is still "
+                                                    "wiping for the process before it waits for that wipe (~3 s for 59 GB; profiles/r04e_e2e_budget_sweep.txt)")
             out["e2e_junction_occurrences_per_sec"] = out["e2e"]["e2e_junction_occurrences_per_sec"]
             out["e2e_wall_s"] = out["e2e"]["e2e_wall_s"]
         if not args.no_cpu_baseline and args.cpu_baseline != "none":

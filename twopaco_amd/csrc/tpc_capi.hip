@@ -472,6 +472,11 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
     if (!strcmp(name, "pbuf_releases")) return c->stat_pbuf_releases;
     if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
+    if (!strcmp(name, "device_free_bytes") || !strcmp(name, "device_total_bytes")) {  // hipMemGetInfo of the context's device, now
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        return (int64_t)(name[7] == 'f' ? free_b : total_b);
+    }
     if (!strcmp(name, "round_marks")) return c->marks_valid ? (int64_t)c->n_marks : -1;  // set bits of the round mask (after tpc_pass2_filter)
     return -1;
 }

@@ -282,6 +282,9 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                 }
             }
         }
+        // (Round 4 also built an N-free fast path here -- a second copy of the loop for waves whose 64 runs hold no N: no 5-letter
+        //  codes, no window N count, no dummy-edge test, VE.h:1040-1058 being the rare case -- and measured it: 2.53 -> 2.80 ms.  The
+        //  ~12 instructions it saves per position cost 30 more spilled registers around the two loop bodies; profiles/r04f_*.)
 #pragma unroll 1
         for (int s = 0; s < TPC_RUN; s++) {  // not unrolled: one copy of the push and flush code
             // first character of the window and the character after it, as code | isN << 2 (two bit-field extracts and a v_lshl_or each)

@@ -556,6 +556,7 @@ class AddressSharded:
             sid, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
             sid = sid.contiguous()
             self.comm.sync()
+            t0 = self._tick("query_survivors_home", t0)
             trace = [n]
             # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange
             for fn, cnt in self._verify_rounds(n):
@@ -564,25 +565,31 @@ class AddressSharded:
                 addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
                 owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
                 self._try(ctx.shard_verify_addrs, fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
+                t0 = self._tick("query_verify_addrs", t0)
                 # owner-major send order from the library (tpc_shard_route), answers come back in that order
                 perm = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
                 counts = self._try(ctx.shard_route, owner.data_ptr(), n * cnt, perm.data_ptr(), W, default=zeros)
                 send = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
                 self._try(ctx.shard_permute64, addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
+                t0 = self._tick("query_verify_route", t0)
                 req, rcounts = self.comm.a2a_var(send, counts)
                 hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
                 self.comm.sync()
+                t0 = self._tick("query_verify_all_to_all", t0)
                 self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
+                t0 = self._tick("query_verify_probe", t0)
                 back, _ = self.comm.a2a_var(hit, rcounts)
                 back = back.contiguous()
                 kept = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
                 self.comm.sync()
+                t0 = self._tick("query_verify_all_to_all", t0)
                 m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
                 sid = kept[:m].contiguous()
                 trace.append(sid.numel())
+                t0 = self._tick("query_verify_select", t0)
             self.comm.sync()
             self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
-            self._tick("query_verify", t0)
+            self._tick("query_verify_mark", t0)
             survivors.append(trace)
             if len(trace) > 2 and not hasattr(self, "_fn1_pass_rate"):  # a lazy batch was measured: survivors of function 1 / first-probe survivors, all ranks
                 tot = self.comm.max_ints([trace[1], trace[0]])  # (max over ranks: a decision every rank takes alike)

@@ -295,6 +295,12 @@ namespace TwoPaCo
 						}
 
 						setupTimer.Lap("  setup thread: HIP start-up + context");
+						if (std::getenv("TWOPACO_TIMING"))
+						{
+							std::cerr << "[timing]   device memory free at context creation: " << double(tpc_get_stat(ctx_, "device_free_bytes")) / double(1ull << 30) << " of "
+								<< double(tpc_get_stat(ctx_, "device_total_bytes")) / double(1ull << 30) << " GiB" << std::endl;
+						}
+
 						// the kernels' code objects load on a third thread while the filter is allocated and the text goes up (started
 						// beside tpc_ctx_create instead it gains nothing: the runtime's start-up is serial, and stalls of 0.3 s were seen)
 						warm = std::thread([this]() { PhaseTimer warmTimer; tpc_warmup(ctx_); warmTimer.Lap("  warm-up thread: code objects"); });
