@@ -274,6 +274,19 @@ int tpc_shard_config(tpc_ctx *ctx, uint32_t rank, uint32_t world);
 int tpc_shard_plan(tpc_ctx *ctx, int pass, uint64_t lo, uint64_t hi, uint64_t *geom);
 int tpc_shard_hash(tpc_ctx *ctx, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions_dev, void *send_counts_dev,
                    uint64_t *n_overflow);
+/* Overlap of hashing and exchange (round 4).  The level-1 hash of a pass reads the text and writes the caller's send
+ * buffers, the pass' produced overflow list and (query) the round mask -- nothing the exchange or the apply of another batch, or of the
+ * other pass, touches: the query's hash does not depend on the round's insert at all (reference: CandidateCheckingWorker hashes the same
+ * windows FilterFillerWorker did, vertexenumerator.h:633-674 / 1035-1083).
+ *   tpc_shard_plan_both   plans insert and query of a round together: shared buffers sized for the larger need, both plans valid
+ *   tpc_shard_hash_begin  enqueues the hash of (pass, batch) on the context's second stream and returns at once; the send buffers
+ *                         must not be the ones an exchange still reads (double buffering is the caller's); one hash in flight per pass
+ *   tpc_shard_hash_end    waits for it; *n_overflow as tpc_shard_hash
+ * The overflow lists are two per pass: hashes append to the produced list (tpc_shard_overflow_get), tpc_shard_overflow_set fills the
+ * applied one, so a hash running under batch b's exchange cannot disturb the entries batch b's apply is about to consume. */
+int tpc_shard_plan_both(tpc_ctx *ctx, uint64_t lo, uint64_t hi, uint64_t *geom_insert /* [16] */, uint64_t *geom_query /* [16] */);
+int tpc_shard_hash_begin(tpc_ctx *ctx, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions_dev, void *send_counts_dev);
+int tpc_shard_hash_end(tpc_ctx *ctx, int pass, uint64_t *n_overflow);
 int tpc_shard_overflow_get(tpc_ctx *ctx, int pass, void *dst_dev, uint64_t n);
 int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t n);
 int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
@@ -324,6 +337,8 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *   test_sched_cap     tests only, process-wide: rounds per segment of the split kernels' round schedule (0 = what fits in LDS)
  *   test_fail_mallocs  tests only, process-wide: the next N second-pass / output allocations fail at their first attempt, as if
  *                      the device were full (they then give the partition buffers back and try again, see "pbuf_releases")
+ *   test_force_anyq    tests only, process-wide: 1 = the closed-form first-pass kernels that serve q = 17..64
+ *                      (csrc/tpc_pass1_anyq.hip) for every q, so that they can be checked on the goldens with q <= 16
  *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 60 % of the free device
  *                      memory when that is more; any number of batches, not only powers of two); part_min_tiles  smallest batch */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
@@ -331,7 +346,8 @@ int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
  * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "pbuf_releases" = times a second-pass or output allocation did not fit beside the first pass' partition buffers, which were then freed (the next first pass allocates them again); "round_marks" = candidate marks of the round the last
- * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does).
+ * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does);
+ * "device_free_bytes" / "device_total_bytes" = hipMemGetInfo of the context's device, now.
  * -1: unknown name. */
 int64_t tpc_get_stat(const tpc_ctx *ctx, const char *name);
 

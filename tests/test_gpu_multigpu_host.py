@@ -233,3 +233,35 @@ def test_cli_sharded_filter_checkpoint_roundtrip(tmp_path):
     other = os.path.join(GOLDEN, "c2.fa")
     bad = subprocess.run(base + ["--load-filter", ck, "-o", out2, other], capture_output=True, text=True)
     assert bad.returncode == 1 and "other input files" in bad.stderr
+
+
+@pytest.mark.parametrize("name,ranks", [("rand6_k9_L33", 2), ("c2_k51_r2", 4), ("rand6_k9_q12", 2), ("m2_small", 8), ("edge_k5", 2)])
+def test_emulated_ranks_hashes_overlapped(capi, tmp_path, name, ranks, monkeypatch):
+    """TWOPACO_OVERLAP=1: every level-1 hash but the first runs on the context's second stream under the exchange and apply of the
+    batch before it, and the query's first hash under the insert's last exchange (tpc_shard_plan_both / tpc_shard_hash_begin /
+    _end, produced and applied overflow lists kept apart): the reference's bytes and counters, as without it."""
+    monkeypatch.setenv("TWOPACO_OVERLAP", "1")
+    case = CASES[name]
+    out = str(tmp_path / "ov.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"], tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    log = _check(case, e, out)
+    if case["n_rounds"] == 1:
+        assert log["rounds"] == case["rounds"]
+    e.close()
+
+
+def test_m1_full_four_emulated_ranks_overlapped_in_batches(capi, tmp_path, monkeypatch):
+    """The same with several tile batches per rank and pass (a 64 MiB buffer budget: three batches of 256 tiles on each of the four
+    ranks), so that hashes really run under the exchange of the batch before them, with the skew path's early overflow fetch in
+    play: sha256 and every counter == the real reference's for BASELINE configs[1] at full size."""
+    monkeypatch.setenv("TWOPACO_OVERLAP", "1")
+    monkeypatch.setenv("TWOPACO_PART_BUDGET_GB", "0.0625")
+    monkeypatch.setenv("TWOPACO_TIMING", "1")
+    case = CASES["m1_full"]
+    out = str(tmp_path / "m1ov.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], tmpdir=str(tmp_path), out=out, seed=case["seed"],
+                        threads=8, gpus=4, emulate_ranks=True)
+    log = _check(case, e, out)
+    assert log["rounds"] == case["rounds"]
+    e.close()

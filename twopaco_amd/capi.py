@@ -24,7 +24,8 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
-               "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part"]
+               "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part",
+               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end"]
 
 _hip = None
 _host = None
@@ -83,6 +84,9 @@ def hip():
         L.tpc_shard_config.argtypes = [p, u32, u32]
         L.tpc_shard_plan.argtypes = [p, ci, u64, u64, p]
         L.tpc_shard_hash.argtypes = [p, ci, u64, u64, u64, p, p, p]
+        L.tpc_shard_plan_both.argtypes = [p, u64, u64, p, p]
+        L.tpc_shard_hash_begin.argtypes = [p, ci, u64, u64, u64, p, p]
+        L.tpc_shard_hash_end.argtypes = [p, ci, p]
         L.tpc_shard_overflow_get.argtypes = [p, ci, p, u64]
         L.tpc_shard_overflow_set.argtypes = [p, ci, p, u64]
         L.tpc_shard_apply.argtypes = [p, ci, u64, p, p, p]

@@ -82,7 +82,7 @@ struct tpc_ctx {
     int opt_slice_bits = 20;
     // partitioned insert
     bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
-    static constexpr int NPBUF = 12;  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
+    static constexpr int NPBUF = 18;  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3; sharded contexts: 12 / 13 the insert's APPLY-side overflow list + cursor, 14 / 15 the query's hash-side list, 16 / 17 its apply-side list (sh_ovf)
     void *pbuf[NPBUF] = {};   // shared by insert and query
     size_t pbytes[NPBUF] = {};
     std::vector<uint64_t> off2_uploaded, off3_uploaded;   // region offset tables currently in pbuf[8] / pbuf[11]
@@ -117,6 +117,14 @@ struct tpc_ctx {
     bool sh_have[2] = {false, false};
     uint64_t sh_per[2] = {0, 0}, sh_batches[2] = {0, 0};
     uint64_t sh_nsurv = 0;
+    // Overflow lists of a sharded pass, two per pass (round 4): the hash kernels append to the PRODUCED list (tpc_shard_overflow_get
+    // reads it), tpc_shard_overflow_set writes the gathered entries into the APPLIED list, which the apply side extends (level-2
+    // losses) and consumes (k_part_ovf / k_q_ovf).  With one list per pass a hash running under the previous batch's exchange
+    // (tpc_shard_hash_begin) would append to the list that exchange is about to overwrite.
+    bool sh_ovf_set[2] = {false, false};   // tpc_shard_overflow_set was called since the last apply of the pass
+    hipStream_t stream2 = nullptr;         // tpc_shard_hash_begin: the hash of a pass beside the main stream's work
+    bool sh_async[2] = {false, false};     // a hash of the pass is in flight on stream2
+    unsigned long long sh_ov_host[2][2] = {{0, 0}, {0, 0}};
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
@@ -413,6 +421,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
     if (c->iovf_off) (void)hipFree(c->iovf_off);
     for (int i = 0; i < TPC_K_COUNT; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1511,6 +1520,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         }
         const size_t need[6] = { 0, 0, tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl), pl.ovf_cap * sizeof(uint64_t), 32 * sizeof(unsigned long long) };
         for (int i = 2; i < 6; i++) if (!ensure_pbuf(c, i, need[i])) return fail(c, -10, "out of device memory for the partition buffers");
+        if (!ensure_pbuf(c, 12, need[4]) || !ensure_pbuf(c, 13, need[5])) return fail(c, -10, "out of device memory for the partition buffers");  // the apply-side list
         if (pl.b3 && (!ensure_pbuf(c, 9, tpc_part_buf3_bytes(pl)) || !ensure_pbuf(c, 10, tpc_part_cnt3_bytes(pl)))) return fail(c, -10, "out of device memory for the partition buffers");
         pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
         pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
@@ -1529,13 +1539,14 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
             if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");
         }
-        for (int i = 2; i < 12; i++) if (tpc_qpart_bytes(pl, i) && !ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");
+        for (int i = 2; i < 12; i++) if (i != 4 && i != 5 && tpc_qpart_bytes(pl, i) && !ensure_pbuf(c, i, tpc_qpart_bytes(pl, i))) return fail(c, -10, "out of device memory for the partition buffers");
+        for (int i = 14; i < 18; i++) if (!ensure_pbuf(c, i, tpc_qpart_bytes(pl, 4 + (i & 1)))) return fail(c, -10, "out of device memory for the partition buffers");  // the query's own overflow lists
         pl.buf3 = (uint64_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];
         if (pl.b3 && c->off3_uploaded != pl.off3_host) {
             HIPCHK(c, hipMemcpy(c->pbuf[11], pl.off3_host.data(), pl.off3_host.size() * 8, hipMemcpyHostToDevice));
             c->off3_uploaded = pl.off3_host;
         }
-        pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+        pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[14]; pl.ovf_cur = (unsigned long long *)c->pbuf[15];
         pl.surv = (uint64_t *)c->pbuf[6]; pl.surv_cur = (unsigned long long *)c->pbuf[7]; pl.off2 = (const uint64_t *)c->pbuf[8];
         if (c->off2_uploaded != pl.off2_host) {
             HIPCHK(c, hipMemcpy(c->pbuf[8], pl.off2_host.data(), pl.off2_host.size() * 8, hipMemcpyHostToDevice));
@@ -1557,29 +1568,58 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
     return 0;
 }
 
-int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions, void *send_counts, uint64_t *n_overflow)
+int tpc_shard_plan_both(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *geom_insert, uint64_t *geom_query)
+{   // both passes planned together: the shared level-2 / level-3 buffers hold the larger of the two needs and BOTH plans stay valid,
+    // so that the query's hash may run (tpc_shard_hash_begin) while the insert of the same round is still being exchanged and applied
+    int rc = tpc_shard_plan(c, TPC_SHARD_INSERT, lo, hi, geom_insert);
+    if (rc) return rc;
+    if ((rc = tpc_shard_plan(c, TPC_SHARD_QUERY, lo, hi, geom_query))) return rc;
+    TpcPartPlan &pl = c->sh_ipl;  // the query's plan may have grown (reallocated) what the insert's plan pointed at
+    pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
+    pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
+    if (tpc_part_buf2_bytes(pl) > c->pbytes[2] || tpc_part_cnt2_bytes(pl) > c->pbytes[3] || (pl.b3 && (tpc_part_buf3_bytes(pl) > c->pbytes[9] || tpc_part_cnt3_bytes(pl) > c->pbytes[10])))
+        return fail(c, -10, "partition buffers smaller than the insert's plan");
+    c->sh_have[TPC_SHARD_INSERT] = true;
+    return 0;
+}
+
+namespace {
+
+// The level-1 hash of one batch of a sharded pass.  async = false: on the context's stream, synchronised, *n_overflow set.
+// async = true (tpc_shard_hash_begin): enqueued on the context's second stream beside whatever the main stream is doing --
+// the hash reads the text and writes the caller's send buffers, the pass' PRODUCED overflow list and (query) the round mask,
+// nothing an exchange or an apply of another batch or of the other pass touches -- and tpc_shard_hash_end collects it.
+int shard_hash_impl(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions, void *send_counts, uint64_t *n_overflow, bool async)
 {
     if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
     if (!send_regions || !send_counts || batch >= c->sh_batches[pass]) return fail(c, -1, "bad arguments");
+    if (c->sh_async[pass]) return fail(c, -1, "a hash of this pass is still in flight: tpc_shard_hash_end first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (async && !c->stream2) HIPCHK(c, hipStreamCreate(&c->stream2));
+    hipStream_t st = async ? c->stream2 : c->stream;
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
     const uint64_t chunk = (tiles + W - 1) / W, c0 = std::min(tiles, c->sh_rank * chunk), c1 = std::min(tiles, c0 + chunk);
     const uint64_t t0 = c0 + batch * per;
     const uint64_t n = t0 < c1 ? std::min<uint64_t>(per, c1 - t0) : 0;
-    unsigned long long ov[2] = {0, 0};
+    unsigned long long *ov = c->sh_ov_host[pass];
+    ov[0] = ov[1] = 0;
+    TpcLaunch a = make_launch(c);
+    a.stream = st;
     if (pass == TPC_SHARD_INSERT) {
         TpcPartPlan pl = c->sh_ipl;
         pl.tile0 = t0; pl.n_tiles = n;
         pl.buf1 = (uint32_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
-        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
-        {
+        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), st));
+        if (async) {
+            if (tpc_launch_insert_part_hash(a, pl, lo, hi, gated, nullptr)) return fail(c, -1, "hash launch failed");
+        } else {
             Timed t(c, TPC_K_SHARD_HASH);
-            if (tpc_launch_insert_part_hash(make_launch(c), pl, lo, hi, gated, nullptr)) return fail(c, -1, "hash launch failed");
+            if (tpc_launch_insert_part_hash(a, pl, lo, hi, gated, nullptr)) return fail(c, -1, "hash launch failed");
         }
-        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 #ifdef TPC_BINS3_DEBUG
-        {
+        if (!async) {
             unsigned long long d[12];
             (void)hipMemcpy(d, pl.ovf_cur, sizeof d, hipMemcpyDeviceToHost);
             fprintf(stderr, "[bins3] insert hash: ring-lost %llu region-lost %llu retry-iterations %llu waited-and-stored %llu (overflow list %llu) ppr=%d cap1=%llu\n", d[8], d[9], d[10], d[11], d[0], pl.pos_per_round, (unsigned long long)pl.cap1);
@@ -1589,20 +1629,48 @@ int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t h
         TpcQPlan pl = c->sh_qpl;
         pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t0;  // positions in the entries are relative to this rank's batch
         pl.buf1 = (uint64_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
-        { int rc0 = materialize_reset(c); if (rc0) return rc0; }
-        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
-        HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+        // (the hash does not read the filter; the lookup of tpc_shard_apply materialises a pending reset before it probes)
+        if (!async) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+        HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), st));
+        if (!async) HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), st));  // (async: tpc_shard_apply zeroes the survivor cursors itself)
         // marks of this batch's survivors land anywhere in the batch, the hash kernel only rewrites this rank's tiles
-        if (batch == 0) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));
+        if (batch == 0) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), st));
         c->marks_valid = false; c->rmask_sums_valid = false;
-        {
+        if (async) {
+            if (tpc_launch_query_part_hash(a, pl, c->rmask, lo, hi, gated)) return fail(c, -1, "hash launch failed");
+        } else {
             Timed t(c, TPC_K_SHARD_HASH);
-            if (tpc_launch_query_part_hash(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "hash launch failed");
+            if (tpc_launch_query_part_hash(a, pl, c->rmask, lo, hi, gated)) return fail(c, -1, "hash launch failed");
         }
-        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     HIPCHK(c, hipGetLastError());
+    if (async) { c->sh_async[pass] = true; return 0; }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's collective runs on another stream
+    if (n_overflow) *n_overflow = ov[1] ? (1ull << 62) : (uint64_t)ov[0];
+    return 0;
+}
+
+}  // namespace
+
+int tpc_shard_hash(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions, void *send_counts, uint64_t *n_overflow)
+{
+    return shard_hash_impl(c, pass, batch, lo, hi, send_regions, send_counts, n_overflow, false);
+}
+
+int tpc_shard_hash_begin(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t hi, void *send_regions, void *send_counts)
+{
+    return shard_hash_impl(c, pass, batch, lo, hi, send_regions, send_counts, nullptr, true);
+}
+
+int tpc_shard_hash_end(tpc_ctx *c, int pass, uint64_t *n_overflow)
+{
+    if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY)) return -1;
+    if (!c->sh_async[pass]) return fail(c, -1, "no hash of this pass in flight (tpc_shard_hash_begin)");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->sh_async[pass] = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    const unsigned long long *ov = c->sh_ov_host[pass];
     if (n_overflow) *n_overflow = ov[1] ? (1ull << 62) : (uint64_t)ov[0];
     return 0;
 }
@@ -1613,7 +1681,7 @@ int tpc_shard_overflow_get(tpc_ctx *c, int pass, void *dst, uint64_t n)
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t cap = pass == TPC_SHARD_INSERT ? c->sh_ipl.ovf_cap : c->sh_qpl.ovf_cap;
     if (n > cap) return fail(c, -1, "overflow list holds at most %llu entries", (unsigned long long)cap);
-    if (n) HIPCHK(c, hipMemcpy(dst, c->pbuf[4], n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));
+    if (n) HIPCHK(c, hipMemcpy(dst, c->pbuf[pass == TPC_SHARD_INSERT ? 4 : 14], n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));  // the PRODUCED list
     return 0;
 }
 
@@ -1624,9 +1692,11 @@ int tpc_shard_overflow_set(tpc_ctx *c, int pass, const void *src, uint64_t n)
     const uint64_t cap = pass == TPC_SHARD_INSERT ? c->sh_ipl.ovf_cap : c->sh_qpl.ovf_cap;
     if (n > cap) return fail(c, -1, "gathered overflow lists (%llu entries) exceed the capacity %llu: skew beyond what the sharded path handles",
                              (unsigned long long)n, (unsigned long long)cap);
-    if (n) HIPCHK(c, hipMemcpy(c->pbuf[4], src, n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));
-    const unsigned long long cur[2] = {n, 0};
-    HIPCHK(c, hipMemcpy(c->pbuf[5], cur, sizeof cur, hipMemcpyHostToDevice));
+    const int list = pass == TPC_SHARD_INSERT ? 12 : 16;  // the APPLIED list: what the apply side extends and consumes
+    if (n) HIPCHK(c, hipMemcpy(c->pbuf[list], src, n * (pass == TPC_SHARD_INSERT ? 8 : 16), hipMemcpyDeviceToDevice));
+    unsigned long long cur[32] = {n, 0};
+    HIPCHK(c, hipMemcpy(c->pbuf[list + 1], cur, sizeof cur, hipMemcpyHostToDevice));
+    c->sh_ovf_set[pass] = true;
     return 0;
 }
 
@@ -1699,8 +1769,13 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
         roff1 = c->sh_off;
     }
     unsigned long long ov[2] = {0, 0};
+    // the apply side's own overflow list: the gathered entries when tpc_shard_overflow_set ran for this batch, empty otherwise
+    const int alist = pass == TPC_SHARD_INSERT ? 12 : 16;
+    if (!c->sh_ovf_set[pass]) HIPCHK(c, hipMemsetAsync(c->pbuf[alist + 1], 0, 32 * sizeof(unsigned long long), c->stream));
+    c->sh_ovf_set[pass] = false;
     if (pass == TPC_SHARD_INSERT) {
         TpcPartPlan pl = c->sh_ipl;
+        pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
         pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
         {
             Timed t(c, TPC_K_SHARD_APPLY);
@@ -1715,7 +1790,10 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
         return 0;
     }
     TpcQPlan pl = c->sh_qpl;
+    pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
     pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a query whose hash ran ahead of the round's insert: tpc_shard_hash_begin)
+    HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
     const uint64_t chunk = (tiles + W - 1) / W;
     pl.tile0_global = std::min(tiles, c->sh_rank * chunk) + batch * per;

@@ -985,6 +985,58 @@ k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
     }
 }
 
+// k_v_addrs for k <= 31, table form (as k_q_verify2): the edge's 2Q hashes in closed form from a table of pre-rotated letter hashes --
+// one 16-byte LDS read per letter and function for both strands instead of two rotations and two lookups: ~750 instead of
+// ~2500 vector instructions per survivor.  Same addresses and owners.
+template <int Q>
+__global__ void __launch_bounds__(256)
+k_v_addrs2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ sid_list, uint64_t n,
+           uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(smem);  // [k + 1][4][Q]: {rotl(h_i[c], k - t), rotl(h_i[3 - c], t)}
+    const int k = P.k, L = P.L;
+    for (int i = threadIdx.x; i < (k + 1) * 4 * Q; i += 256) {
+        const int t = i / (4 * Q), c = (i / Q) & 3, f = i % Q;
+        const uint64_t a = q_rotl_n(tab[f * 5 + c], L, (k - t) % L), b = q_rotl_n(tab[f * 5 + 3 - c], L, t % L);
+        s_t[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    __syncthreads();
+    const uint64_t wmask = (1ull << (2 * k)) - 1ull;  // k <= 31
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const uint64_t sid = sid_list[idx];
+        const int e = (int)(sid & 7), c = e & 3;
+        const uint64_t g = gbase + ((sid >> 3) & ((1ull << (30u - sh.log_world())) - 1ull));  // the source-rank bits are this rank's own
+        const uint64_t w = tpc_text_word(bases, g) & wmask;
+        uint64_t E = e < 4 ? ((w << 2) | (uint64_t)c) : (w | ((uint64_t)c << (2 * k)));  // in-edge c + v, out-edge v + c: first letter in the low bits
+        uint64_t p[Q], nn[Q];
+#pragma unroll
+        for (int i = 0; i < Q; i++) { p[i] = 0; nn[i] = 0; }
+        const uint4 *row = s_t;
+        for (int t = 0; t <= k; t++) {
+            const uint4 *r = row + ((uint32_t)E & 3u) * Q;
+            E >>= 2;
+            row += 4 * Q;
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                const uint4 x = r[i];
+                p[i] ^= ((uint64_t)x.y << 32) | x.x;
+                nn[i] ^= ((uint64_t)x.w << 32) | x.z;
+            }
+        }
+        const bool ng = tpc_pick_neg<Q>(p, nn);
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            if (i < fn || i >= fn + fn_count) continue;
+            const uint64_t ap = perm.fwd(ng ? nn[i] : p[i]);
+            bool mine;
+            addr_out[idx * fn_count + (i - fn)] = pt_local_addr(perm, sh, log_nb2, ap, mine);
+            owner_out[idx * fn_count + (i - fn)] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+        }
+    }
+}
+
 // the 64 survivor sub-lists as one contiguous list
 __global__ void k_surv_gather(const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t *__restrict__ out)
 {
@@ -1424,7 +1476,16 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
     const PtShard sh{pl.rank, pl.world};
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
-#define CALL(Q_) hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out)
+    const size_t table = (size_t)(a.P.k + 1) * 4 * a.P.q * 16;  // k_v_addrs2's letter table
+    const bool lean = a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN");
+#define CALL(Q_)                                                                                                                                         \
+    do {                                                                                                                                                 \
+        if (lean) {                                                                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_v_addrs2<Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);                             \
+            hipLaunchKernelGGL((k_v_addrs2<Q_>), grid, dim3(256), table, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out); \
+        } else                                                                                                                                           \
+            hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out); \
+    } while (0)
     switch (a.P.q) {
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;

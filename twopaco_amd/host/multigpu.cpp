@@ -341,7 +341,7 @@ namespace TwoPaCo
 		std::fprintf(stderr, "[timing]     %s (rank 0, ms):", title);
 		for (auto & p : phaseMs) std::fprintf(stderr, " %s %.1f;", p.first.c_str(), p.second);
 		size_t held = 0;
-		for (int i = 0; i < 16; i++) held += cap[i];
+		for (int i = 0; i < ShardedRank::BUFFERS; i++) held += cap[i];
 		std::fprintf(stderr, " exchange buffers held %.2f GB\n", double(held) / 1e9);
 		phaseMs.clear();
 	}
@@ -349,7 +349,7 @@ namespace TwoPaCo
 	void ShardedRank::Release()
 	{
 		(void)hipSetDevice(device);
-		for (int i = 0; i < 16; i++)
+		for (int i = 0; i < BUFFERS; i++)
 		{
 			if (buf[i]) (void)hipFree(buf[i]);
 			buf[i] = 0;
@@ -360,7 +360,9 @@ namespace TwoPaCo
 	// ------------------------------------------------------------------------------------------ the pass
 	namespace
 	{
-		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED, REC, REC2, GATHER };
+		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED, REC, REC2, GATHER, SEND_R2, SEND_C2 };
+
+		void Exchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, void * sendR, void * sendC, uint64_t overflow, bool overflowFetched);
 
 		// hash -> exchange -> (overflow lists) ; returns the receive buffers in r.buf[RECV_R], r.buf[RECV_C]
 		void HashAndExchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, uint64_t batch, uint64_t lo, uint64_t hi)
@@ -368,12 +370,28 @@ namespace TwoPaCo
 			const int W = net.Ranks();
 			void * sendR = r.Ensure(SEND_R, size_t(W) * geom[2]);
 			void * sendC = r.Ensure(SEND_C, size_t(W) * geom[3]);
-			void * recvR = r.Ensure(RECV_R, size_t(W) * geom[2]);
-			void * recvC = r.Ensure(RECV_C, size_t(W) * geom[3]);
 			uint64_t overflow = 0;
 			r.Phase("buffers");
 			LibCheck(r.ctx, tpc_shard_hash(r.ctx, pass, batch, lo, hi, sendR, sendC, &overflow), "shard_hash");
 			r.Phase(pass == TPC_SHARD_INSERT ? "insert hash" : "query hash");
+			Exchange(r, net, pass, geom, sendR, sendC, overflow, false);
+		}
+
+		// This rank's produced overflow entries of the batch just hashed, copied aside (r.buf[OVF_MINE]) before another hash of the
+		// same pass may append to the list (TWOPACO_OVERLAP: the next batch's hash runs under this batch's exchange).
+		void FetchOverflow(ShardedRank & r, int pass, const uint64_t * geom, uint64_t overflow)
+		{
+			if (overflow == 0 || overflow >= (uint64_t(1) << 62)) return;
+			char * mine = static_cast<char*>(r.Ensure(OVF_MINE, overflow * geom[6]));
+			LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
+		}
+
+		// everything between a batch's hash and its apply: counts, (packed) regions, overflow lists
+		void Exchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, void * sendR, void * sendC, uint64_t overflow, bool overflowFetched)
+		{
+			const int W = net.Ranks();
+			void * recvR = r.Ensure(RECV_R, size_t(W) * geom[2]);
+			void * recvC = r.Ensure(RECV_C, size_t(W) * geom[3]);
 			net.AllToAll(r.rank, sendC, recvC, geom[3]);
 			r.Phase("exchange counts");
 			if (r.compactExchange)
@@ -415,9 +433,27 @@ namespace TwoPaCo
 			if (most > 0)
 			{
 				const size_t eb = geom[6];
-				char * mine = static_cast<char*>(r.Ensure(OVF_MINE, most * eb));
+				char * mine = static_cast<char*>(r.buf[OVF_MINE]);
+				if (!overflowFetched || r.cap[OVF_MINE] < most * eb)
+				{
+					// (fetched early: the entries must survive the buffer growing to the all-gather's block size)
+					char * grown = 0;
+					if (overflowFetched && overflow)
+					{
+						HipCheck(hipMalloc(reinterpret_cast<void**>(&grown), most * eb), "overflow block");
+						HipCheck(hipMemcpy(grown, mine, overflow * eb, hipMemcpyDeviceToDevice), "overflow block");
+					}
+
+					mine = static_cast<char*>(r.Ensure(OVF_MINE, most * eb));
+					if (grown)
+					{
+						HipCheck(hipMemcpy(mine, grown, overflow * eb, hipMemcpyDeviceToDevice), "overflow block");
+						(void)hipFree(grown);
+					}
+					else if (!overflowFetched) LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
+				}
+
 				char * gathered = static_cast<char*>(r.Ensure(OVF_ALL, size_t(W) * most * eb));
-				LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
 				net.AllGather(r.rank, mine, gathered, most * eb);
 				// compact the blocks (each holds all[s] valid entries) to the front of `gathered`
 				uint64_t total = all[0];
@@ -503,13 +539,90 @@ namespace TwoPaCo
 		}
 	}
 
+	namespace
+	{
+		// survivors of the first probe of one query batch: home, verified, marked (shared by both forms of the pass)
+		void VerifyBatch(ShardedRank & r, Transport & net, int hashFunctions, uint64_t n);
+		void MaskUnion(ShardedRank & r, Transport & net);
+
+		// TWOPACO_OVERLAP=1: the same pass with every level-1 hash but the first running on the context's second stream under the
+		// exchange and the apply of the batch before it (tpc_shard_hash_begin / _end, two send-buffer pairs) -- and the query's FIRST
+		// hash under the insert's LAST exchange: the query's level 1 does not depend on the filter, only its lookup does (the
+		// reference's workers never wait on each other for the filter either, vertexenumerator.h:1086-1092).  Same bytes on the
+		// wire, same filter, same marks (tests/test_gpu_multigpu_host.py); what it buys on real links is for the first multi-GPU
+		// box to say -- the hash kernels hold whole CUs (1024 threads, ~150 KB of LDS), so RCCL's send / receive workgroups
+		// compete with them for CUs.
+		void OverlappedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi)
+		{
+			const int W = net.Ranks();
+			uint64_t gi[16], gq[16];
+			r.PhaseBegin();
+			LibCheck(r.ctx, tpc_shard_plan_both(r.ctx, lo, hi, gi, gq), "shard_plan_both");
+			LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
+			r.Phase("plan");
+			int slot = 0;
+			auto sendBuffers = [&](int which, const uint64_t * geom, void * & R, void * & C)
+			{
+				R = r.Ensure(which ? SEND_R2 : SEND_R, size_t(W) * geom[2]);
+				C = r.Ensure(which ? SEND_C2 : SEND_C, size_t(W) * geom[3]);
+			};
+
+			void * curR = 0, * curC = 0, * nextR = 0, * nextC = 0;
+			uint64_t overflow = 0;
+			sendBuffers(slot, gi, curR, curC);
+			LibCheck(r.ctx, tpc_shard_hash(r.ctx, TPC_SHARD_INSERT, 0, lo, hi, curR, curC, &overflow), "shard_hash");
+			r.Phase("insert hash");
+			for (uint64_t b = 0; b < gi[0]; b++)
+			{
+				FetchOverflow(r, TPC_SHARD_INSERT, gi, overflow);
+				const bool more = b + 1 < gi[0];
+				sendBuffers(slot ^ 1, more ? gi : gq, nextR, nextC);
+				if (more) LibCheck(r.ctx, tpc_shard_hash_begin(r.ctx, TPC_SHARD_INSERT, b + 1, lo, hi, nextR, nextC), "shard_hash_begin");
+				else LibCheck(r.ctx, tpc_shard_hash_begin(r.ctx, TPC_SHARD_QUERY, 0, lo, hi, nextR, nextC), "shard_hash_begin(query)");
+				Exchange(r, net, TPC_SHARD_INSERT, gi, curR, curC, overflow, true);
+				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+				r.Phase("insert apply");
+				if (more) LibCheck(r.ctx, tpc_shard_hash_end(r.ctx, TPC_SHARD_INSERT, &overflow), "shard_hash_end");
+				slot ^= 1;
+				curR = nextR; curC = nextC;
+			}
+
+			net.Barrier().Wait();  // every shard is complete before anyone probes it
+			r.Phase("barrier");
+			LibCheck(r.ctx, tpc_shard_hash_end(r.ctx, TPC_SHARD_QUERY, &overflow), "shard_hash_end(query)");
+			r.Phase("query hash (under the insert)");
+			for (uint64_t b = 0; b < gq[0]; b++)
+			{
+				FetchOverflow(r, TPC_SHARD_QUERY, gq, overflow);
+				const bool more = b + 1 < gq[0];
+				if (more)
+				{
+					sendBuffers(slot ^ 1, gq, nextR, nextC);
+					LibCheck(r.ctx, tpc_shard_hash_begin(r.ctx, TPC_SHARD_QUERY, b + 1, lo, hi, nextR, nextC), "shard_hash_begin");
+				}
+
+				Exchange(r, net, TPC_SHARD_QUERY, gq, curR, curC, overflow, true);
+				uint64_t n = 0;
+				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+				r.Phase("query apply");
+				VerifyBatch(r, net, hashFunctions, n);
+				if (more) LibCheck(r.ctx, tpc_shard_hash_end(r.ctx, TPC_SHARD_QUERY, &overflow), "shard_hash_end");
+				slot ^= 1;
+				curR = nextR; curC = nextC;
+			}
+
+			r.PhasePrint("sharded first pass (hashes overlapped)");
+		}
+	}
+
 	void ShardedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi)
 	{
-		const int W = net.Ranks();
 		uint64_t geom[16];
-		r.PhaseBegin();
+		const bool overlapped = std::getenv("TWOPACO_OVERLAP") != 0 && !r.filterLoaded;
+		if (overlapped) OverlappedFirstPass(r, net, hashFunctions, lo, hi);
+		if (!overlapped) r.PhaseBegin();
 		// ---- insert (FilterFillerWorker); skipped when the shard came from a checkpoint
-		if (!r.filterLoaded)
+		if (!r.filterLoaded && !overlapped)
 		{
 			LibCheck(r.ctx, tpc_shard_plan(r.ctx, TPC_SHARD_INSERT, lo, hi, geom), "shard_plan(insert)");
 			LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
@@ -522,6 +635,8 @@ namespace TwoPaCo
 			}
 		}
 
+		if (!overlapped)
+		{
 		net.Barrier().Wait();  // every shard is complete before anyone probes it
 		r.Phase("barrier");
 		// ---- query (CandidateCheckingWorker)
@@ -533,6 +648,21 @@ namespace TwoPaCo
 			uint64_t n = 0;
 			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
 			r.Phase("query apply");
+			VerifyBatch(r, net, hashFunctions, n);
+		}
+
+		r.PhasePrint("sharded first pass");
+		}
+
+		if (r.shardedSecondPass) return;  // the marks stay on the rank that found them (ShardedSecondPass)
+		MaskUnion(r, net);
+	}
+
+	namespace
+	{
+		void VerifyBatch(ShardedRank & r, Transport & net, int hashFunctions, uint64_t n)
+		{
+			const int W = net.Ranks();
 			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
 			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
 			n = ReturnSurvivors(r, net, n);
@@ -574,9 +704,10 @@ namespace TwoPaCo
 			r.Phase("verify + mark");
 		}
 
-		r.PhasePrint("sharded first pass");
-		if (r.shardedSecondPass) return;  // the marks stay on the rank that found them (ShardedSecondPass)
 		// ---- union of the candidate masks: OR all-reduce by word ranges
+		void MaskUnion(ShardedRank & r, Transport & net)
+		{
+		const int W = net.Ranks();
 		const uint64_t words = tpc_mask_words(r.ctx);
 		const uint64_t chunk = (words + W - 1) / W;
 		uint32_t * mine = static_cast<uint32_t*>(r.Ensure(SEND_R, size_t(W) * chunk * 4));
@@ -587,7 +718,9 @@ namespace TwoPaCo
 		LibCheck(r.ctx, tpc_mask_or_blocks(r.ctx, parts, uint32_t(W), chunk, folded), "mask_or_blocks");
 		net.AllGather(r.rank, folded, mine, chunk * 4);
 		LibCheck(r.ctx, tpc_mask_import(r.ctx, mine), "mask_import");
+		}
 	}
+
 	void ShardedSecondPass(ShardedRank & r, Transport & net, uint64_t abundance, uint64_t counters[4])
 	{
 		const int W = net.Ranks();

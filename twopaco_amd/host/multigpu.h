@@ -84,8 +84,9 @@ namespace TwoPaCo
 		int device;
 		tpc_ctx * ctx;
 		// device scratch owned by the rank (grown on demand, freed by Release)
-		void * buf[16];
-		size_t cap[16];
+		enum { BUFFERS = 18 };
+		void * buf[BUFFERS];
+		size_t cap[BUFFERS];
 		// exact-size exchange of the level-1 regions (tpc_shard_pack / tpc_shard_apply_packed); false: equal blocks
 		bool compactExchange;
 		// second pass with the exact filter's table sharded by key hash (ShardedSecondPass; the text is then sharded on every
@@ -101,7 +102,7 @@ namespace TwoPaCo
 		void PhaseBegin();
 		void Phase(const char * name);  // time since the previous Phase / PhaseBegin goes to `name`
 		void PhasePrint(const char * title);
-		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), filterLoaded(false), verifyEager(-1), phaseOn(false) { for (int i = 0; i < 16; i++) { buf[i] = 0; cap[i] = 0; } }
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), filterLoaded(false), verifyEager(-1), phaseOn(false) { for (int i = 0; i < BUFFERS; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};
