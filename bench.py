@@ -235,9 +235,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--e2e-runs", type=int, default=5, help="runs of the twopaco CLI for the end-to-end figure (0 = skip)")
-    ap.add_argument("--e2e-settle", type=float, default=2.5,
+    ap.add_argument("--e2e-settle", type=float, default=3.5,
                     help="seconds between two CLI runs of the headline series: the driver wipes a finished process's device memory "
-                         "asynchronously and an allocation that is handed one of those blocks waits ~3 s for it (profiles/r04f_e2e_back_to_back.txt)")
+                         "asynchronously (~3 s for the 59 GB of one run) and an allocation that is handed one of those blocks waits for it (profiles/r04f_e2e_back_to_back.txt)")
     ap.add_argument("--e2e-b2b-runs", type=int, default=6, help="runs of the second series, started right behind one another (reported as e2e_back_to_back; 0 = skip)")
     ap.add_argument("--decomposition", default="auto", choices=["auto", "ranges", "address"],
                     help="multi-GPU: the Bloom filter sharded by bit address with an all-to-all per pass (the north-star decomposition; "
