@@ -206,6 +206,38 @@ def test_second_pass_allocations_take_back_the_partition_buffers(capi, tmp_path)
     ctx.close()
 
 
+def test_reservation_made_before_the_upload_is_given_back_when_the_text_does_not_fit(capi, tmp_path):
+    """The CLI's setup thread reserves the partition buffers (tpc_reserve) BEFORE the text is uploaded.  On a nearly full device the
+    upload's allocations then fail beside that reservation: they go through the same give-back path as the second pass' (ADVICE
+    round 3: tpc_seq_upload used plain hipMalloc and failed with out-of-memory where the run used to work).  Simulated with
+    test_fail_mallocs: the upload frees the reservation, succeeds, and the run's counters and bytes are the oracle's."""
+    case = [c for c in CASES if c["name"] == "rand6_k9_L24_r4"][0]
+    o = _oracle_for(case, tmp_path)
+    o.enumerate(rounds=1, abundance=MAXU)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", 10)):
+        ctx.set_option(opt, val)
+    ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+    assert capi.hip().tpc_reserve(ctx._h, 50_000_000) == 0  # sized for a text far larger than the one that follows
+    before = ctx.stat("pbuf_releases")
+    try:
+        ctx.set_option("test_fail_mallocs", 1)
+        ctx.seq_upload(text)
+    finally:
+        ctx.set_option("test_fail_mallocs", 0)
+    assert ctx.stat("pbuf_releases") == before + 1
+    ctx.run_begin()
+    ctx.filter_reset()
+    ctx.pass1_insert()
+    st = o.round_stats(0)
+    assert ctx.pass1_query() == st["marks"]
+    assert ctx.stat("insert_path") % 10 in (2, 3) and ctx.stat("query_path") % 10 in (2, 3)
+    assert ctx.pass2_filter(MAXU) == {"true": st["true"], "false": st["false"], "table": st["table"]}
+    assert ctx.junctions_finalize() == case["distinct"] and (ctx.junction_keys() == o.keys).all()
+    ctx.close()
+
+
 def test_test_first_variant_same_filter(capi, tmp_path):
     case = [c for c in CASES if c["name"] == "rand6_k9_fp"][0]
     text = capi.PackedText.from_fasta(case_files(case, tmp_path))

@@ -695,6 +695,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // vertex-hash range), so a round can cover more positions before the rings fill
     int ppr = (int)(budget / (1024 * q * std::max(frac, 1.0 / 64)));  // k_part_hash: 1024 threads (two tiles) x pos_per_round
     pl.pos_per_round = std::max(1, std::min(32, ppr));
+    if (const char *e = getenv("TPC_PPR_INSERT")) pl.pos_per_round = std::max(1, std::min(32, atoi(e)));  // measurements: positions per ring round
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     // a workgroup takes ceil(pairs / nwg1) tile pairs: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t pairs = (pl.n_tiles + 1) / 2, pairs_wg = (pairs + pl.nwg1 - 1) / pl.nwg1;
