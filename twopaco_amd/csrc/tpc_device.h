@@ -108,6 +108,16 @@ __device__ __forceinline__ uint64_t tpc_text_word(const uint64_t *__restrict__ b
     return (lo >> (2u * o)) | (hi << (64u - 2u * o));
 }
 
+// The same with ONE 16-byte request (an 8-byte aligned dwordx4 load; the packed text is padded, so the second word always exists):
+// the per-survivor kernels wait for scattered accesses, and two 8-byte loads of neighbouring words are two requests.
+typedef uint64_t tpc_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ uint64_t tpc_text_word_x2(const uint64_t *__restrict__ bases, uint64_t g)
+{
+    const uint32_t o = (uint32_t)g & 31u;
+    const tpc_u64x2 v = *reinterpret_cast<const tpc_u64x2 *>(bases + (g >> 5));
+    return o ? (v.x >> (2u * o)) | (v.y << (64u - 2u * o)) : v.x;
+}
+
 // Reverse the 32 two-bit groups of a word and complement them (A<->T, C<->G = code ^ 3).
 __device__ __forceinline__ uint64_t tpc_revcomp_word(uint64_t x)
 {

@@ -498,7 +498,94 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 // ------------------------------------------------------------------------------------------ C
 // One workgroup per slice.  Survivors (entry >> 31 = edge | position << 3) are staged in LDS and
 // appended to sub-list (blockIdx % QS_LISTS) with one global atomic per flush.
-constexpr int QL_STAGE = 3072;
+constexpr int QL_STAGE = 2048;
+constexpr int QL_BUCKETS = 1024;  // = PT_APPLY_THREADS: one counting-sort bucket per thread
+constexpr size_t QL_LDS = (size_t)QL_STAGE * 12 + (size_t)QL_BUCKETS * 4 + 128 + 64;  // staged ids + their slice offsets + histogram + scan scratch + control
+
+// Survivors of a slice's first probe, staged in LDS and appended to the workgroup's survivor sub-list GROUPED BY ADDRESS (round 4).
+// All occurrences of an edge -- the same (k+1)-mer at its position in every genome that has it -- probe the same address, reach
+// the same slice and survive together; k_q_verify then probes functions 1..q-1 of the SAME q-1 addresses once per occurrence
+// (the 62-genome workload: 54 M true second edges among 58 M survivors, ~11 occurrences each).  The lookup appended them in
+// arrival order, i.e. spread over the flush; a counting sort by the high bits of the slice offset (one LDS atomic per survivor)
+// puts equal addresses next to each other, so the 64 lanes of a verifying wave ask for a handful of distinct filter words instead
+// of 4 x 64.  Nothing downstream depends on the order of a sub-list.
+struct SurvStage {
+    uint64_t *sid;     // [QL_STAGE]
+    uint32_t *key;     // [QL_STAGE] slice offset of the hit
+    uint32_t *hist;    // [QL_BUCKETS]
+    uint32_t *scan;    // [32]
+    uint32_t *ctl;     // [0] staged count, [2..3] flush base
+    uint64_t *my_list;
+    unsigned long long *surv_cur;
+    uint64_t surv_cap;
+    int list, shift;   // bucket = key >> shift
+    __device__ __forceinline__ unsigned char *carve(unsigned char *p, int slice_bits)
+    {
+        sid = reinterpret_cast<uint64_t *>(p);
+        key = reinterpret_cast<uint32_t *>(sid + QL_STAGE);
+        hist = key + QL_STAGE;
+        scan = hist + QL_BUCKETS;
+        ctl = scan + 32;
+        shift = slice_bits > 10 ? slice_bits - 10 : 0;
+        return reinterpret_cast<unsigned char *>(ctl + 16);
+    }
+    __device__ __forceinline__ void push(uint64_t id, uint32_t a)
+    {
+        const uint32_t slot = atomicAdd(&ctl[0], 1u);
+        if (slot < (uint32_t)QL_STAGE) { sid[slot] = id; key[slot] = a; }
+        else {  // staging full (dense hits): straight to the sub-list
+            const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
+            if (o < surv_cap) my_list[o] = id; else surv_cur[QS_LISTS] = 1ull;
+        }
+    }
+    __device__ __forceinline__ void flush()  // all PT_APPLY_THREADS threads
+    {
+        static_assert(QL_BUCKETS == PT_APPLY_THREADS && QL_STAGE == 2 * PT_APPLY_THREADS, "one bucket and two staged entries per thread");
+        __syncthreads();
+        const uint32_t m = min(ctl[0], (uint32_t)QL_STAGE);
+        if (m) {  // (uniform)
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t b[2] = {0, 0}, rank[2] = {0, 0};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t i = threadIdx.x + u * PT_APPLY_THREADS;
+                if (i < m) { b[u] = min(key[i] >> shift, (uint32_t)QL_BUCKETS - 1u); rank[u] = atomicAdd(&hist[b[u]], 1u); }
+            }
+            __syncthreads();
+            uint32_t total;
+            const uint32_t off = pt_block_excl_scan<PT_APPLY_THREADS>(hist[threadIdx.x], scan, total);
+            __syncthreads();
+            hist[threadIdx.x] = off;
+            if (threadIdx.x == 0) {
+                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
+                ctl[2] = (uint32_t)base; ctl[3] = (uint32_t)(base >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t i = threadIdx.x + u * PT_APPLY_THREADS;
+                if (i < m) {
+                    const uint64_t at = base + hist[b[u]] + rank[u];
+                    if (at < surv_cap) my_list[at] = sid[i];
+                    else surv_cur[QS_LISTS] = 1ull;  // sub-list overflow -> host falls back
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ctl[0] = 0;
+        }
+        __syncthreads();
+    }
+    // after a region: flush once the staging area is more than half full
+    __device__ __forceinline__ void maybe_flush()
+    {
+        __syncthreads();
+        const uint32_t staged = min(ctl[0], (uint32_t)QL_STAGE);
+        __syncthreads();  // everyone has read the count before anyone stages more
+        if (staged > QL_STAGE / 2) flush();
+    }
+};
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
            const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh)
@@ -506,58 +593,30 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
-    uint64_t *stage = reinterpret_cast<uint64_t *>(slice + ((words + 3u) & ~3u));
-    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(stage + QL_STAGE);  // [0] staged count, [2..3] flush base
+    SurvStage st;
+    st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits);
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     // whole filter: natural position of permuted slice blockIdx; shard: compact [local bucket][b2]
     const uint32_t *src_slice = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
     if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
     else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
-    if (threadIdx.x == 0) s_ctl[0] = 0;
+    if (threadIdx.x == 0) st.ctl[0] = 0;
     __syncthreads();
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
-    const int list = blockIdx.x % QS_LISTS;
-    uint64_t *my_list = surv + (uint64_t)list * surv_cap;
-    auto flush = [&]() {  // all threads
-        __syncthreads();
-        const uint32_t m = min(s_ctl[0], (uint32_t)QL_STAGE);
-        if (m) {
-            if (threadIdx.x == 0) {
-                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
-                s_ctl[2] = (uint32_t)base; s_ctl[3] = (uint32_t)(base >> 32);
-            }
-            __syncthreads();
-            const uint64_t base = (uint64_t)s_ctl[2] | ((uint64_t)s_ctl[3] << 32);
-            for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
-                if (base + i < surv_cap) my_list[base + i] = stage[i];
-                else surv_cur[QS_LISTS] = 1ull;  // sub-list overflow -> host falls back
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_ctl[0] = 0;
-        }
-        __syncthreads();
-    };
+    st.list = blockIdx.x % QS_LISTS;
+    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
         pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, [&](uint64_t v) {
             const uint32_t a = (uint32_t)v & slice_mask;
-            if ((slice[a >> 5] >> (a & 31u)) & 1u) {
-                const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
-                if (slot < (uint32_t)QL_STAGE) stage[slot] = v >> QE_E_SHIFT;
-                else {  // staging full (dense hits): straight to the sub-list
-                    const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
-                    if (o < surv_cap) my_list[o] = v >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
-                }
-            }
+            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
         });
-        __syncthreads();
-        const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
-        __syncthreads();  // everyone has read the count before anyone stages more
-        if (staged > QL_STAGE / 2) flush();
+        st.maybe_flush();
     }
-    flush();
+    st.flush();
 }
 
 // ------------------------------------------------------------------------------------------ C'
@@ -572,8 +631,9 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
-    uint64_t *stage = reinterpret_cast<uint64_t *>(slice + ((words + 3u) & ~3u));
-    uint32_t *s_ctl = reinterpret_cast<uint32_t *>(stage + QL_STAGE);
+    SurvStage st;
+    st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits);
+    uint32_t *s_ctl = st.ctl;
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
@@ -612,48 +672,20 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
     // ---- lookup (k_q_lookup) against the slice still in LDS
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
-    const int list = blockIdx.x % QS_LISTS;
-    uint64_t *my_list = surv + (uint64_t)list * surv_cap;
-    auto flush = [&]() {  // all threads
-        __syncthreads();
-        const uint32_t m = min(s_ctl[0], (uint32_t)QL_STAGE);
-        if (m) {
-            if (threadIdx.x == 0) {
-                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
-                s_ctl[2] = (uint32_t)base; s_ctl[3] = (uint32_t)(base >> 32);
-            }
-            __syncthreads();
-            const uint64_t base = (uint64_t)s_ctl[2] | ((uint64_t)s_ctl[3] << 32);
-            for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
-                if (base + i < surv_cap) my_list[base + i] = stage[i];
-                else surv_cur[QS_LISTS] = 1ull;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_ctl[0] = 0;
-        }
-        __syncthreads();
-    };
+    st.list = blockIdx.x % QS_LISTS;
+    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     for (uint32_t j = 0; j < qwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
         auto probe = [&](uint64_t v) {
             const uint32_t a = (uint32_t)v & slice_mask;
-            if ((slice[a >> 5] >> (a & 31u)) & 1u) {
-                const uint32_t slot = atomicAdd(&s_ctl[0], 1u);
-                if (slot < (uint32_t)QL_STAGE) stage[slot] = v >> QE_E_SHIFT;
-                else {  // staging full (dense hits): straight to the sub-list
-                    const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
-                    if (o < surv_cap) my_list[o] = v >> QE_E_SHIFT; else surv_cur[QS_LISTS] = 1ull;
-                }
-            }
+            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
         };
         if (j == 0) q0.finish(probe);
         else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]), probe);
-        __syncthreads();
-        const uint32_t staged = min(s_ctl[0], (uint32_t)QL_STAGE);
-        __syncthreads();
-        if (staged > QL_STAGE / 2) flush();
+        st.maybe_flush();
     }
-    flush();
+    st.flush();
 }
 
 // Region-overflow entries: first probe straight from the filter; hits join sub-list 0.
@@ -810,13 +842,13 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
     // kernel waits for scattered accesses, not for arithmetic: twice the loads in flight per lane)
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t sid_n = idx < n ? my[idx] : 0;
-    uint64_t w_n = idx < n ? tpc_text_word(bases, gbase + (sid_n >> 3)) : 0;
+    uint64_t w_n = idx < n ? tpc_text_word_x2(bases, gbase + (sid_n >> 3)) : 0;
     for (; idx < n; idx += stride) {
         const uint64_t sid = sid_n;
         const uint64_t w = w_n & wmask;
         if (idx + stride < n) {
             sid_n = my[idx + stride];
-            w_n = tpc_text_word(bases, gbase + (sid_n >> 3));
+            w_n = tpc_text_word_x2(bases, gbase + (sid_n >> 3));
         }
         const int e = (int)(sid & 7), c = e & 3;
         const uint64_t g = gbase + (sid >> 3);
@@ -1008,7 +1040,7 @@ k_v_addrs2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
         const uint64_t sid = sid_list[idx];
         const int e = (int)(sid & 7), c = e & 3;
         const uint64_t g = gbase + ((sid >> 3) & ((1ull << (30u - sh.log_world())) - 1ull));  // the source-rank bits are this rank's own
-        const uint64_t w = tpc_text_word(bases, g) & wmask;
+        const uint64_t w = tpc_text_word_x2(bases, g) & wmask;
         uint64_t E = e < 4 ? ((w << 2) | (uint64_t)c) : (w | ((uint64_t)c << (2 * k)));  // in-edge c + v, out-edge v + c: first letter in the low bits
         uint64_t p[Q], nn[Q];
 #pragma unroll
@@ -1381,7 +1413,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
-        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (pl.b3)
             hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
@@ -1409,7 +1441,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
-        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)QL_STAGE * 8 + 64;
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_apply_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
                            ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
