@@ -1043,7 +1043,7 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
     uint64_t full = 1024;
     while (full < 2 * n_marks + 2) full <<= 1;
     uint64_t cap = 1024;
-    while (cap < n_marks / 4 + 2) cap <<= 1;
+    while (cap < n_marks / 4 + 2) cap <<= 1;  // (marks / 8 and / 16 measured the same on M2: k_filter2 0.946 -> 0.943 / 0.944 ms)
     uint64_t tp = 0, used = 0;
     c->stat_filter2_retries = 0;
     for (;;) {

@@ -498,9 +498,9 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 // ------------------------------------------------------------------------------------------ C
 // One workgroup per slice.  Survivors (entry >> 31 = edge | position << 3) are staged in LDS and
 // appended to sub-list (blockIdx % QS_LISTS) with one global atomic per flush.
-constexpr int QL_STAGE = 2048;
+constexpr int QL_STAGE = 3072;
 constexpr int QL_BUCKETS = 1024;  // = PT_APPLY_THREADS: one counting-sort bucket per thread
-constexpr size_t QL_LDS = (size_t)QL_STAGE * 12 + (size_t)QL_BUCKETS * 4 + 128 + 64;  // staged ids + their slice offsets + histogram + scan scratch + control
+constexpr size_t QL_LDS = (size_t)QL_STAGE * 8 + (size_t)QL_BUCKETS * 4 + 128 + 64;  // staged ids (their bucket in the spare high bits) + histogram + scan scratch + control
 
 // Survivors of a slice's first probe, staged in LDS and appended to the workgroup's survivor sub-list GROUPED BY ADDRESS (round 4).
 // All occurrences of an edge -- the same (k+1)-mer at its position in every genome that has it -- probe the same address, reach
@@ -508,22 +508,22 @@ constexpr size_t QL_LDS = (size_t)QL_STAGE * 12 + (size_t)QL_BUCKETS * 4 + 128 +
 // (the 62-genome workload: 54 M true second edges among 58 M survivors, ~11 occurrences each).  The lookup appended them in
 // arrival order, i.e. spread over the flush; a counting sort by the high bits of the slice offset (one LDS atomic per survivor)
 // puts equal addresses next to each other, so the 64 lanes of a verifying wave ask for a handful of distinct filter words instead
-// of 4 x 64.  Nothing downstream depends on the order of a sub-list.
+// of 4 x 64.  Nothing downstream depends on the order of a sub-list.  A staged entry is the 33-bit survivor id with its bucket
+// in bits 40..49 (no second array: the 32 KB beside a 128 KB slice hold 3072 entries, as before the grouping).
 struct SurvStage {
+    static constexpr int ID_BITS = 40;
     uint64_t *sid;     // [QL_STAGE]
-    uint32_t *key;     // [QL_STAGE] slice offset of the hit
     uint32_t *hist;    // [QL_BUCKETS]
     uint32_t *scan;    // [32]
     uint32_t *ctl;     // [0] staged count, [2..3] flush base
     uint64_t *my_list;
     unsigned long long *surv_cur;
     uint64_t surv_cap;
-    int list, shift;   // bucket = key >> shift
+    int list, shift;   // bucket = slice offset >> shift
     __device__ __forceinline__ unsigned char *carve(unsigned char *p, int slice_bits)
     {
         sid = reinterpret_cast<uint64_t *>(p);
-        key = reinterpret_cast<uint32_t *>(sid + QL_STAGE);
-        hist = key + QL_STAGE;
+        hist = reinterpret_cast<uint32_t *>(sid + QL_STAGE);
         scan = hist + QL_BUCKETS;
         ctl = scan + 32;
         shift = slice_bits > 10 ? slice_bits - 10 : 0;
@@ -532,7 +532,7 @@ struct SurvStage {
     __device__ __forceinline__ void push(uint64_t id, uint32_t a)
     {
         const uint32_t slot = atomicAdd(&ctl[0], 1u);
-        if (slot < (uint32_t)QL_STAGE) { sid[slot] = id; key[slot] = a; }
+        if (slot < (uint32_t)QL_STAGE) sid[slot] = id | ((uint64_t)min(a >> shift, (uint32_t)QL_BUCKETS - 1u) << ID_BITS);
         else {  // staging full (dense hits): straight to the sub-list
             const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
             if (o < surv_cap) my_list[o] = id; else surv_cur[QS_LISTS] = 1ull;
@@ -540,17 +540,20 @@ struct SurvStage {
     }
     __device__ __forceinline__ void flush()  // all PT_APPLY_THREADS threads
     {
-        static_assert(QL_BUCKETS == PT_APPLY_THREADS && QL_STAGE == 2 * PT_APPLY_THREADS, "one bucket and two staged entries per thread");
+        constexpr int PER = QL_STAGE / PT_APPLY_THREADS;
+        static_assert(QL_BUCKETS == PT_APPLY_THREADS && QL_STAGE % PT_APPLY_THREADS == 0, "one bucket per thread, whole entries per thread");
         __syncthreads();
         const uint32_t m = min(ctl[0], (uint32_t)QL_STAGE);
         if (m) {  // (uniform)
             hist[threadIdx.x] = 0;
             __syncthreads();
-            uint32_t b[2] = {0, 0}, rank[2] = {0, 0};
+            uint64_t e[PER];
+            uint32_t rank[PER];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < PER; u++) {
                 const uint32_t i = threadIdx.x + u * PT_APPLY_THREADS;
-                if (i < m) { b[u] = min(key[i] >> shift, (uint32_t)QL_BUCKETS - 1u); rank[u] = atomicAdd(&hist[b[u]], 1u); }
+                e[u] = 0; rank[u] = 0;
+                if (i < m) { e[u] = sid[i]; rank[u] = atomicAdd(&hist[(uint32_t)(e[u] >> ID_BITS)], 1u); }
             }
             __syncthreads();
             uint32_t total;
@@ -564,11 +567,11 @@ struct SurvStage {
             __syncthreads();
             const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < PER; u++) {
                 const uint32_t i = threadIdx.x + u * PT_APPLY_THREADS;
                 if (i < m) {
-                    const uint64_t at = base + hist[b[u]] + rank[u];
-                    if (at < surv_cap) my_list[at] = sid[i];
+                    const uint64_t at = base + hist[(uint32_t)(e[u] >> ID_BITS)] + rank[u];
+                    if (at < surv_cap) my_list[at] = e[u] & ((1ull << ID_BITS) - 1ull);
                     else surv_cur[QS_LISTS] = 1ull;  // sub-list overflow -> host falls back
                 }
             }
@@ -586,6 +589,7 @@ struct SurvStage {
         if (staged > QL_STAGE / 2) flush();
     }
 };
+
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
            const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh)
