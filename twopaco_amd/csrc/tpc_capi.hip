@@ -882,7 +882,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 pl.tile0_global = t0;
                 pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
-                HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+                HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
                 if (fused && t0 == 0) {  // the first batch's lookup kernel also builds and writes the filter slices; later batches read them
                     TpcQPlan p1 = pl;
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
@@ -899,7 +899,23 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                 HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
-                if (t0 + per < tiles) { HIPCHK(c, hipStreamSynchronize(c->stream)); overflowed = f1[1] != 0 || f2 != 0; }
+                if (t0 + per < tiles) {
+                    // Grouping the survivors by address pays when they are true second edges (every genome's occurrence of an edge probes
+                    // the same words); a batch whose first-probe survivors were mostly Bloom false positives -- a well-filled filter: full
+                    // configs[3] marks 2 % of them -- has nothing to bring together, and the next batch's lookup skips the sort.  The
+                    // batch's marks (a count over its words of the round mask: 0.03 ms) against its survivors say which it was.
+                    // (Counting the passes inside k_q_verify2 -- one more register, an atomic per wave -- cost that kernel 2.26 -> 2.6 ms.)
+                    unsigned long long sc[TPC_SURV_CUR_WORDS], batch_marks = 0;
+                    const uint64_t w0 = t0 * 512, wn = std::min<uint64_t>(pl.n_tiles * 512, c->n_words > w0 ? c->n_words - w0 : 0);
+                    if (wn) tpc_launch_mask_count(c->stream, c->rmask + w0, wn, c->block_sums, c->counters + 3);
+                    HIPCHK(c, hipMemcpyAsync(sc, pl.surv_cur, sizeof sc, hipMemcpyDeviceToHost, c->stream));
+                    if (wn) HIPCHK(c, hipMemcpyAsync(&batch_marks, c->counters + 3, sizeof batch_marks, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    overflowed = f1[1] != 0 || f2 != 0;
+                    unsigned long long surv = 0;
+                    for (int i = 0; i < 64; i++) surv += std::min<unsigned long long>(sc[i], pl.surv_cap);
+                    if (surv > 0) pl.group_survivors = batch_marks * 4 >= surv;
+                }
             }
             tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
         }
@@ -1632,7 +1648,7 @@ int shard_hash_impl(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t 
         // (the hash does not read the filter; the lookup of tpc_shard_apply materialises a pending reset before it probes)
         if (!async) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
         HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), st));
-        if (!async) HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), st));  // (async: tpc_shard_apply zeroes the survivor cursors itself)
+        if (!async) HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), st));  // (async: tpc_shard_apply zeroes the survivor cursors itself)
         // marks of this batch's survivors land anywhere in the batch, the hash kernel only rewrites this rank's tiles
         if (batch == 0) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), st));
         c->marks_valid = false; c->rmask_sums_valid = false;
@@ -1793,7 +1809,7 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
     pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
     pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
     { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a query whose hash ran ahead of the round's insert: tpc_shard_hash_begin)
-    HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
     const uint64_t chunk = (tiles + W - 1) / W;
     pl.tile0_global = std::min(tiles, c->sh_rank * chunk) + batch * per;

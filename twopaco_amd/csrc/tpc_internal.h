@@ -96,7 +96,9 @@ struct TpcQPlan {
     const uint64_t *rbuf1 = nullptr;
     const uint32_t *rcnt1 = nullptr;
     const uint64_t *roff1 = nullptr;  // packed receive buffer, as in TpcPartPlan
+    bool group_survivors = true;      // the lookup appends its survivors grouped by address (tpc_qpartition.hip:SurvStage)
 };
+#define TPC_SURV_CUR_WORDS 72  // surv_cur: [0..63] sub-list cursors, [64] overflow flag
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
 bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0);

@@ -520,6 +520,7 @@ struct SurvStage {
     unsigned long long *surv_cur;
     uint64_t surv_cap;
     int list, shift;   // bucket = slice offset >> shift
+    int group;         // 0: append in arrival order (no sort: a batch whose survivors are mostly Bloom false positives has no equal addresses to bring together)
     __device__ __forceinline__ unsigned char *carve(unsigned char *p, int slice_bits)
     {
         sid = reinterpret_cast<uint64_t *>(p);
@@ -544,7 +545,20 @@ struct SurvStage {
         static_assert(QL_BUCKETS == PT_APPLY_THREADS && QL_STAGE % PT_APPLY_THREADS == 0, "one bucket per thread, whole entries per thread");
         __syncthreads();
         const uint32_t m = min(ctl[0], (uint32_t)QL_STAGE);
-        if (m) {  // (uniform)
+        if (m && !group) {  // (uniform) arrival order
+            if (threadIdx.x == 0) {
+                const unsigned long long base = atomicAdd(&surv_cur[list], (unsigned long long)m);
+                ctl[2] = (uint32_t)base; ctl[3] = (uint32_t)(base >> 32);
+            }
+            __syncthreads();
+            const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
+            for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
+                if (base + i < surv_cap) my_list[base + i] = sid[i] & ((1ull << ID_BITS) - 1ull);
+                else surv_cur[QS_LISTS] = 1ull;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) ctl[0] = 0;
+        } else if (m) {  // (uniform)
             hist[threadIdx.x] = 0;
             __syncthreads();
             uint64_t e[PER];
@@ -592,13 +606,14 @@ struct SurvStage {
 
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh)
+           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh, int group)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
     SurvStage st;
     st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits);
+    st.group = group;
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     // whole filter: natural position of permuted slice blockIdx; shard: compact [local bucket][b2]
@@ -630,13 +645,14 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
                const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
-               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm)
+               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
     SurvStage st;
     st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits);
+    st.group = group;
     uint32_t *s_ctl = st.ctl;
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
@@ -1386,7 +1402,7 @@ size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
     case 4: return pl.ovf_cap * 16;
     case 5: return 32 * sizeof(unsigned long long);
     case 6: return (size_t)QS_LISTS * pl.surv_cap * 8;
-    case 7: return (QS_LISTS + 1) * sizeof(unsigned long long);
+    case 7: return TPC_SURV_CUR_WORDS * sizeof(unsigned long long);  // 64 cursors, the overflow flag
     case 8: return pl.off2_host.size() * 8;
     case 9: return (size_t)pl.buf3_entries * 8;
     case 10: return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * 4 : 0;
@@ -1421,10 +1437,10 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (pl.b3)
             hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
-                               pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
+                               pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0);
         else
             hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                               pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh);
+                               pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
                        sh, pl.b2 + pl.b3);
@@ -1448,7 +1464,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_apply_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
-                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm);
+                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
     return 0;
