@@ -292,7 +292,29 @@ int tpc_shard_overflow_set(tpc_ctx *ctx, int pass, const void *src_dev, uint64_t
 int tpc_shard_apply(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev, uint64_t *n_survivors);
 int tpc_shard_pack(tpc_ctx *ctx, int pass, const void *send_regions_dev, const void *send_counts_dev, void *packed_dev, uint64_t *bytes_per_dest_host);
 int tpc_shard_apply_packed(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_packed_dev, const void *recv_counts_dev, uint64_t *n_survivors);
+/* tpc_shard_apply with this rank's own block read in place: block `rank` of the receive buffers is never touched (the host layer need not
+ * copy it), the entries this rank hashed for its own slices are taken from the send buffers tpc_shard_hash filled -- same block index,
+ * same layout.  world == 1: the receive buffers may be null.  Option "shard_tight_regions" (default 1) sizes the level-1 regions of the
+ * sharded passes at their expected fill + 6 sigma (+ the gate's share in a multi-round pass) instead of the one-GPU 1.3 x: the equal
+ * blocks then carry a few per cent of slack and the packing pass (tpc_shard_pack: a read and a write of every entry) can be skipped. */
+int tpc_shard_apply_inplace(tpc_ctx *ctx, int pass, uint64_t batch, const void *recv_regions_dev, const void *recv_counts_dev,
+                            const void *send_regions_dev, const void *send_counts_dev, uint64_t *n_survivors);
 int tpc_shard_survivors(tpc_ctx *ctx, uint64_t *sid_dev);
+/* The verification's bookkeeping in fused form (what the calls above do in three or four steps each; same protocol, same results):
+ *   tpc_shard_survivors_home  the survivors of the last tpc_shard_apply grouped by the rank that hashed their position, into send_dev
+ *                             (n entries, the n tpc_shard_apply returned); counts_host[r] = survivors for rank r (variable all_to_all
+ *                             of 8 bytes each); tmp_dev: n uint64 of scratch, unused when world == 1
+ *   tpc_shard_verify_send     shard-local bit addresses of hash functions fn .. fn+fn_count-1 of every survivor id in sid_dev, already in
+ *                             owner-major send order: send_dev[n * fn_count], perm_dev[i * fn_count + j] = slot of survivor i's j-th
+ *                             probe, counts_host[r] = probes for rank r; tmp_dev: n * fn_count uint64 of scratch.  world == 1: the
+ *                             natural order is the send order; tmp_dev and perm_dev are not used (pass perm_dev = NULL on)
+ *   tpc_shard_finish          last round of a batch: the candidate mark of every survivor whose fn_count answers (hit_dev, in send
+ *                             order; perm_dev NULL = natural order) are all 1 -- tpc_shard_select + tpc_shard_mark without the list
+ *                             in between; *n_marked = how many passed.  tpc_shard_select takes perm_dev = NULL the same way. */
+int tpc_shard_survivors_home(tpc_ctx *ctx, uint64_t *tmp_dev, uint64_t *send_dev, uint64_t *counts_host);
+int tpc_shard_verify_send(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *tmp_dev, uint64_t *send_dev, uint32_t *perm_dev,
+                          uint64_t *counts_host);
+int tpc_shard_finish(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n, int fn_count, const uint8_t *hit_dev, const uint32_t *perm_dev, uint64_t *n_marked);
 int tpc_shard_survivor_sources(tpc_ctx *ctx, const uint64_t *sid_dev, uint64_t n, int32_t *source_dev);
 int tpc_shard_verify_addrs(tpc_ctx *ctx, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *addr_dev, int32_t *owner_dev);
 int tpc_shard_probe(tpc_ctx *ctx, const uint64_t *addr_dev, uint64_t n, uint8_t *hit_dev);

@@ -191,14 +191,17 @@ def test_key_sharded_pass2_synthetic(tmp_path):
     assert sum(g["step_marks"] for g in gathered) == int(np.unpackbits(gathered[0]["rounds"][0]["mask"].view(np.uint8)).sum())
 
 
-def test_compacted_exchange_moves_fewer_bytes(tmp_path):
-    """The exact-size exchange (tpc_shard_pack / tpc_shard_apply_packed) and the equal-block exchange give the same filter,
-    masks and ids; the packed one puts fewer region bytes on the wire (the fixed-capacity regions are about 3/4 full)."""
+def test_exchange_forms_agree_and_tight_regions_move_fewer_bytes(tmp_path):
+    """The three forms of the level-1 exchange give the same filter, masks and ids: packed to the exact sizes (tpc_shard_pack /
+    tpc_shard_apply_packed), equal blocks of tightly sized regions with the own block read in place (tpc_shard_apply_inplace; the
+    default below eight ranks), and the same with the one-GPU slack of 1.3 x (option shard_tight_regions = 0).  Bytes that leave a
+    rank: packed <= tight < 0.9 x loose."""
     from twopaco_amd import synth
     recs, _ = synth.workload("m1", scale=0.02)
     base = {"workload": "m1", "scale": 0.02, "k": 25, "L": 28, "q": 5, "seed": 12, "ranges": [(0, 1 << 28)], "abundance": (1 << 64) - 1,
             "options": {"slice_bits": 14}}
-    specs = [dict(base, compact_exchange=True), dict(base, compact_exchange=False)]
+    specs = [dict(base, compact_exchange=True), dict(base, compact_exchange=False),
+             dict(base, compact_exchange=False, options={"slice_bits": 14, "shard_tight_regions": 0})]
     o = O.Oracle(25, 28, 5, O.seed_table(12, 5, 28))
     letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
     for r in recs:
@@ -206,8 +209,8 @@ def test_compacted_exchange_moves_fewer_bytes(tmp_path):
     results = run(specs, 2, tmp_path)
     for sp, gathered in zip(specs, results):
         check(sp, o, gathered, 2)
-    packed, equal = results[0][0]["region_bytes_sent"], results[1][0]["region_bytes_sent"]
-    assert 0 < packed < 0.9 * equal, (packed, equal)
+    packed, tight, loose = (results[i][0]["region_bytes_sent"] for i in range(3))
+    assert 0 < packed <= tight < 0.9 * loose, (packed, tight, loose)
 
 
 @pytest.mark.parametrize("world", [2, 4])

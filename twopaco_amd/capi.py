@@ -25,7 +25,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part",
-               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end"]
+               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish"]
 
 _hip = None
 _host = None
@@ -98,6 +98,10 @@ def hip():
         L.tpc_shard_permute_rows.argtypes = [p, p, p, u64, ci, p]
         L.tpc_shard_pack.argtypes = [p, ci, p, p, p, p]
         L.tpc_shard_apply_packed.argtypes = [p, ci, u64, p, p, p]
+        L.tpc_shard_apply_inplace.argtypes = [p, ci, u64, p, p, p, p, p]
+        L.tpc_shard_survivors_home.argtypes = [p, p, p, p]
+        L.tpc_shard_verify_send.argtypes = [p, ci, ci, p, u64, p, p, p, p]
+        L.tpc_shard_finish.argtypes = [p, p, u64, ci, p, p, p]
         L.tpc_shard_survivors.argtypes = [p, p]
         L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
         L.tpc_shard_survivor_sources.argtypes = [p, p, u64, p]
@@ -442,6 +446,30 @@ class Context:
         n = ctypes.c_uint64(0)
         self._ck(hip().tpc_shard_apply_packed(self._h, which, batch, recv_packed_ptr, recv_counts_ptr, ctypes.byref(n)))
         return n.value
+
+    def shard_apply_inplace(self, which, batch, recv_regions_ptr, recv_counts_ptr, send_regions_ptr, send_counts_ptr):
+        """tpc_shard_apply with this rank's own block read from the send buffers (the receive buffers' block `rank` is never read)."""
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_apply_inplace(self._h, which, batch, recv_regions_ptr, recv_counts_ptr, send_regions_ptr, send_counts_ptr, ctypes.byref(n)))
+        return n.value
+
+    def shard_survivors_home(self, tmp_ptr, send_ptr, world):
+        """Survivors of the last shard_apply grouped by the rank that hashed them; returns the count for every rank."""
+        out = (ctypes.c_uint64 * world)()
+        self._ck(hip().tpc_shard_survivors_home(self._h, tmp_ptr, send_ptr, out))
+        return [int(x) for x in out]
+
+    def shard_verify_send(self, fn, fn_count, sid_ptr, n, tmp_ptr, send_ptr, perm_ptr, world):
+        """Probe addresses of functions fn.. in owner-major send order (+ the slot of every probe); returns the count for every rank."""
+        out = (ctypes.c_uint64 * world)()
+        self._ck(hip().tpc_shard_verify_send(self._h, fn, fn_count, sid_ptr, n, tmp_ptr, send_ptr, perm_ptr, out))
+        return [int(x) for x in out]
+
+    def shard_finish(self, sid_ptr, n, fn_count, hit_ptr, perm_ptr):
+        """Marks every survivor whose fn_count answers are all 1; returns how many."""
+        m = ctypes.c_uint64(0)
+        self._ck(hip().tpc_shard_finish(self._h, sid_ptr, n, fn_count, hit_ptr, perm_ptr, ctypes.byref(m)))
+        return m.value
 
     def shard_survivors(self, sid_ptr):
         self._ck(hip().tpc_shard_survivors(self._h, sid_ptr))

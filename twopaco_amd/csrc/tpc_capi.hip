@@ -87,6 +87,7 @@ struct tpc_ctx {
     size_t pbytes[NPBUF] = {};
     std::vector<uint64_t> off2_uploaded, off3_uploaded;   // region offset tables currently in pbuf[8] / pbuf[11]
     int opt_part_levels = 0;   // 0 auto (three levels when L - slice_bits > 18), 2, 3
+    int opt_shard_tight = 1;   // sharded passes: level-1 regions at the expected fill + 6 sigma (they travel whole); 0 = the one-GPU slack of 1.3 x
     // what the last insert / query actually ran (tpc_get_stat)
     int stat_path[2] = {0, 0};       // 1 direct kernel, 2 / 3 partitioned with that many levels (+10: partitioned, then completed by the direct kernel)
     int64_t stat_batches[2] = {0, 0};
@@ -437,6 +438,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "query_mode")) { c->opt_query_mode = (int)value; return 0; }
     if (!strcmp(name, "part_budget_bytes")) { c->opt_part_budget = value; return 0; }
     if (!strcmp(name, "part_levels")) { c->opt_part_levels = (int)value; return 0; }
+    if (!strcmp(name, "shard_tight_regions")) { c->opt_shard_tight = value ? 1 : 0; c->sh_have[0] = c->sh_have[1] = false; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
@@ -1530,7 +1532,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         TpcPartPlan &pl = c->sh_ipl;
         for (uint64_t batches = 1;; batches = next_batches(batches)) {
             per = (per_total + batches - 1) / batches;
-            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->opt_part_levels))
+            if (!tpc_part_plan_sharded(c->P.L, c->P.q, c->opt_slice_bits, per, frac, c->sh_rank, c->sh_world, pl, c->opt_part_levels, c->opt_shard_tight != 0))
                 return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
             if ((int64_t)(2 * tpc_part_buf1_bytes(pl) + tpc_part_buf2_bytes(pl) + tpc_part_buf3_bytes(pl)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles) break;
         }
@@ -1550,7 +1552,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
             uint32_t log_w = 0;
             while ((1u << log_w) < c->sh_world) ++log_w;
             const bool fits = per * (uint64_t)(512 * TPC_RUN) <= (1ull << (30 - log_w));  // survivor ids: source rank + position relative to its batch in 30 bits
-            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, c->opt_part_levels);
+            const bool ok = fits && tpc_qpart_plan_sharded(c->P.L, c->opt_slice_bits, per, gated ? std::min(1.0, m * 1.15) : 1.0, c->sh_rank, c->sh_world, pl, c->opt_part_levels, c->opt_shard_tight != 0);
             if (!ok && fits) return fail(c, -1, "no sharded partition geometry for L=%d, slice_bits=%d, world=%u", c->P.L, c->opt_slice_bits, c->sh_world);
             if (ok && ((int64_t)(2 * tpc_qpart_bytes(pl, 0) + tpc_qpart_bytes(pl, 2) + tpc_qpart_bytes(pl, 9)) <= part_budget(c) || (int64_t)per <= c->opt_part_min_tiles)) break;
             if (per <= 1) return fail(c, -1, "text too large for the sharded query geometry");
@@ -1735,7 +1737,8 @@ bool ensure_shard_offsets(tpc_ctx *c, uint32_t n_regions)
     return true;
 }
 
-int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors);
+int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors,
+                     const void *own_regions = nullptr, const void *own_counts = nullptr);
 
 }  // namespace
 
@@ -1747,6 +1750,14 @@ int tpc_shard_apply(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regio
 int tpc_shard_apply_packed(tpc_ctx *c, int pass, uint64_t batch, const void *recv_packed, const void *recv_counts, uint64_t *n_survivors)
 {
     return shard_apply_impl(c, pass, batch, recv_packed, recv_counts, true, n_survivors);
+}
+
+int tpc_shard_apply_inplace(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, const void *send_regions,
+                            const void *send_counts, uint64_t *n_survivors)
+{   // block `rank` of the receive buffers is never read: the entries this rank hashed for itself are taken from the send buffers
+    if (!c || !send_regions || !send_counts) return fail(c, -1, "bad arguments");
+    if (c->sh_world == 1) return shard_apply_impl(c, pass, batch, send_regions, send_counts, false, n_survivors);  // nothing was exchanged
+    return shard_apply_impl(c, pass, batch, recv_regions, recv_counts, false, n_survivors, send_regions, send_counts);
 }
 
 int tpc_shard_pack(tpc_ctx *c, int pass, const void *send_regions, const void *send_counts, void *packed, uint64_t *bytes_per_dest)
@@ -1772,7 +1783,8 @@ int tpc_shard_pack(tpc_ctx *c, int pass, const void *send_regions, const void *s
 
 namespace {
 
-int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors)
+int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regions, const void *recv_counts, bool packed, uint64_t *n_survivors,
+                     const void *own_regions, const void *own_counts)
 {
     if (!c || (pass != TPC_SHARD_INSERT && pass != TPC_SHARD_QUERY) || !c->sh_have[pass]) return fail(c, -1, "tpc_shard_plan for this pass first");
     if (!recv_regions || !recv_counts || batch >= c->sh_batches[pass]) return fail(c, -1, "bad arguments");
@@ -1793,6 +1805,7 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
         TpcPartPlan pl = c->sh_ipl;
         pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
         pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
+        pl.rown1 = (const uint32_t *)own_regions; pl.rowncnt1 = (const uint32_t *)own_counts;
         {
             Timed t(c, TPC_K_SHARD_APPLY);
             if (tpc_launch_insert_part_apply(make_launch(c), pl, c->filter_zero_pending)) return fail(c, -1, "apply launch failed");
@@ -1808,6 +1821,7 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
     TpcQPlan pl = c->sh_qpl;
     pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
     pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
+    pl.rown1 = (const uint64_t *)own_regions; pl.rowncnt1 = (const uint32_t *)own_counts;
     { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a query whose hash ran ahead of the round's insert: tpc_shard_hash_begin)
     HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
@@ -1911,6 +1925,94 @@ int tpc_shard_survivor_sources(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n, 
     return 0;
 }
 
+namespace {
+
+// owner routing of n tagged items (owner = (v >> shift) & (world - 1)) from src to dst in owner-major order; counted: the per-owner
+// counts already sit in route_scratch[0..63] (a producer kernel accumulated them), else a counting pass runs first
+int route64(tpc_ctx *c, const uint64_t *src, uint64_t n, int shift, uint64_t keep, bool counted, uint32_t *perm_dev, uint64_t *dst, uint64_t *counts_host)
+{
+    unsigned long long *d = c->route_scratch;  // [0..63] counts, [64..127] cursors
+    if (!counted) {
+        HIPCHK(c, hipMemsetAsync(d, 0, 128 * sizeof(unsigned long long), c->stream));
+        tpc_launch_route64(c->stream, src, n, shift, c->sh_world - 1, keep, d, d + 64, perm_dev, dst, 0);
+    }
+    unsigned long long h[64], cur[64];
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long acc = 0;
+    for (int i = 0; i < 64; i++) { cur[i] = acc; acc += h[i]; if ((uint32_t)i < c->sh_world) counts_host[i] = h[i]; }
+    if (acc != n) return fail(c, -1, "owner routing: counted %llu of %llu items", acc, (unsigned long long)n);
+    HIPCHK(c, hipMemcpyAsync(d + 64, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));
+    tpc_launch_route64(c->stream, src, n, shift, c->sh_world - 1, keep, d, d + 64, perm_dev, dst, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+int tpc_shard_survivors_home(tpc_ctx *c, uint64_t *tmp_dev, uint64_t *send_dev, uint64_t *counts_host)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || !counts_host || (c->sh_nsurv && (!send_dev || (c->sh_world > 1 && !tmp_dev)))) return fail(c, -1, "bad arguments");
+    if (c->sh_world > 64) return fail(c, -1, "routing supports at most 64 ranks");
+    if (c->sh_nsurv > 0xFFFFFFFFull) return fail(c, -1, "too many items to route at once");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t r = 0; r < c->sh_world; r++) counts_host[r] = 0;
+    if (!c->sh_nsurv) return 0;
+    if (c->sh_world == 1) {  // everything was hashed here
+        tpc_launch_surv_gather(make_launch(c), c->sh_qpl, send_dev);
+        counts_host[0] = c->sh_nsurv;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    tpc_launch_surv_gather(make_launch(c), c->sh_qpl, tmp_dev);
+    uint32_t lw = 0;
+    while ((1u << lw) < c->sh_world) ++lw;
+    // the rank that hashed the survivor's position: the top log2(world) bits of its 30-bit position field (k_q_hash<SHARDED>)
+    return route64(c, tmp_dev, c->sh_nsurv, 3 + 30 - (int)lw, ~0ull, false, nullptr, send_dev, counts_host);
+}
+
+int tpc_shard_verify_send(tpc_ctx *c, int fn, int fn_count, const uint64_t *sid_dev, uint64_t n, uint64_t *tmp_dev, uint64_t *send_dev, uint32_t *perm_dev,
+                          uint64_t *counts_host)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || !counts_host || fn_count < 1) return fail(c, -1, "bad arguments");
+    const bool one = c->sh_world == 1;
+    if (n && (!sid_dev || !send_dev || (!one && (!tmp_dev || !perm_dev)))) return fail(c, -1, "bad arguments");
+    if (c->sh_world > 64) return fail(c, -1, "routing supports at most 64 ranks");
+    const uint64_t total = n * (uint64_t)fn_count;
+    if (total > 0xFFFFFFFFull) return fail(c, -1, "too many items to route at once");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint32_t r = 0; r < c->sh_world; r++) counts_host[r] = 0;
+    if (!n) return 0;
+    unsigned long long *d = c->route_scratch;
+    if (!one) HIPCHK(c, hipMemsetAsync(d, 0, 128 * sizeof(unsigned long long), c->stream));
+    // one rank: every probe is this rank's own, the natural order is the send order (tags are zero)
+    if (tpc_launch_verify_addrs(make_launch(c), c->sh_qpl, fn, fn_count, sid_dev, n, one ? send_dev : tmp_dev, nullptr, one ? nullptr : d))
+        return fail(c, -1, "bad hash function range %d+%d", fn, fn_count);
+    if (one) {
+        counts_host[0] = total;
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    return route64(c, tmp_dev, total, TPC_V_OWNER_SHIFT, (1ull << TPC_V_OWNER_SHIFT) - 1ull, true, perm_dev, send_dev, counts_host);
+}
+
+int tpc_shard_finish(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n, int fn_count, const uint8_t *hit_dev, const uint32_t *perm_dev, uint64_t *n_marked)
+{
+    if (!c || !c->sh_have[TPC_SHARD_QUERY] || fn_count < 1 || (n && (!sid_dev || !hit_dev))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, sizeof(unsigned long long), c->stream));
+    tpc_launch_finish(c->stream, c->sh_qpl, sid_dev, n, fn_count, hit_dev, perm_dev, c->rmask, c->counters + 3);
+    c->marks_valid = false; c->rmask_sums_valid = false;
+    HIPCHK(c, hipGetLastError());
+    uint64_t m = 0;
+    const int rc = read_counter(c, 3, &m);
+    if (n_marked) *n_marked = m;
+    return rc;
+}
+
 int tpc_shard_route(tpc_ctx *c, const int32_t *owner_dev, uint64_t n, uint32_t *perm_dev, uint64_t *counts_host)
 {
     if (!c || !counts_host || (n && (!owner_dev || !perm_dev))) return fail(c, -1, "bad arguments");
@@ -1945,7 +2047,7 @@ int tpc_shard_permute64(tpc_ctx *c, const uint64_t *src_dev, const uint32_t *per
 int tpc_shard_select(tpc_ctx *c, const uint64_t *sid_dev, uint64_t n, int fn_count, const uint8_t *hit_dev, const uint32_t *perm_dev, uint64_t *sid_out_dev,
                      uint64_t *n_out)
 {
-    if (!c || !n_out || fn_count < 1 || (n && (!sid_dev || !hit_dev || !perm_dev || !sid_out_dev))) return fail(c, -1, "bad arguments");
+    if (!c || !n_out || fn_count < 1 || (n && (!sid_dev || !hit_dev || !sid_out_dev))) return fail(c, -1, "bad arguments");  // perm_dev may be null: natural order
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, sizeof(unsigned long long), c->stream));
     tpc_launch_select(c->stream, sid_dev, n, fn_count, hit_dev, perm_dev, sid_out_dev, c->counters + 3);

@@ -50,6 +50,8 @@ struct TpcPartPlan {
     uint32_t rank = 0, world = 1;
     const uint32_t *rbuf1 = nullptr, *rcnt1 = nullptr;
     const uint64_t *roff1 = nullptr;  // packed receive buffer: first entry of every received level-1 region (else region index * cap1)
+    // this rank's own block read where tpc_shard_hash wrote it (tpc_shard_apply_inplace): the send buffers, same region index
+    const uint32_t *rown1 = nullptr, *rowncnt1 = nullptr;
 };
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch; levels 0 = auto
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl);
@@ -58,7 +60,7 @@ size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf3_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl);
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels = 0);
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels = 0, bool tight = false);
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
                                   unsigned long long *n_kmers);
 // the two halves of the above, for the sharded path (an all_to_all of the level-1 regions sits between them)
@@ -96,12 +98,14 @@ struct TpcQPlan {
     const uint64_t *rbuf1 = nullptr;
     const uint32_t *rcnt1 = nullptr;
     const uint64_t *roff1 = nullptr;  // packed receive buffer, as in TpcPartPlan
+    const uint64_t *rown1 = nullptr;  // own block in place, as in TpcPartPlan
+    const uint32_t *rowncnt1 = nullptr;
     bool group_survivors = true;      // the lookup appends its survivors grouped by address (tpc_qpartition.hip:SurvStage)
 };
 #define TPC_SURV_CUR_WORDS 72  // surv_cur: [0..63] sub-list cursors, [64] overflow flag
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0);
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0, bool tight = false);
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 // deferred apply: the insert stops after its level-2 binning (tpc_launch_insert_part_split), the query's lookup builds the slices itself
 int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl);   // level 2 (and 3) only
@@ -125,7 +129,13 @@ int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t 
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl);
 // sharded verification of first-probe survivors (survivor id = edge | position << 3, batch relative)
 int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out);  // 64 sub-lists -> one list (sum of min(surv_cur, surv_cap) entries)
-int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out);
+int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out,
+                            unsigned long long *owner_counts = nullptr);
+#define TPC_V_OWNER_SHIFT 56  // tagged probe addresses (owner_out == nullptr): owner rank above the shard-local bit address
+int tpc_launch_finish(hipStream_t s, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, int fn_count, const uint8_t *hit, const uint32_t *perm, uint32_t *rmask,
+                      unsigned long long *n_marked);
+int tpc_launch_route64(hipStream_t s, const uint64_t *v, uint64_t n, int shift, uint32_t omask, uint64_t keep, unsigned long long *counts, unsigned long long *cursor,
+                       uint32_t *perm, uint64_t *dst, int phase);
 int tpc_launch_shard_probe(const TpcLaunch &a, const uint64_t *addr, uint64_t n, uint8_t *hit);
 int tpc_launch_shard_mark(const TpcLaunch &a, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, uint32_t *rmask);
 

@@ -379,8 +379,8 @@ template <bool SHARDED>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
              uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads,
-             uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1)
-{   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
+             uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1, const uint32_t *__restrict__ own1, const uint32_t *__restrict__ owncnt1)
+{   // own1 / owncnt1 (sharded, optional): the block of source rank == this rank is read from the send buffers it was hashed into   // prev_wpb == 0: the input is level 1's output, regions [workgroup][bucket].  prev_wpb > 0: the input is the output of
     // another k_part_split (three-level geometry): this bucket is (b1, b2) of that level, its regions are [b1][j][b2].
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
@@ -396,6 +396,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
         return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl;
     };
+    auto mine = [=](uint32_t vw) { return SHARDED && own1 && !prev_wpb && vw / nwg1 == sh.rank; };
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     const int shift1 = L - LOG_NB1;
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
@@ -417,7 +418,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     uint32_t va[LOADS], vb[LOADS];
     for (uint32_t skip = 0;; skip += sched_cap) {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<PS_THREADS>(
-            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { const uint32_t vw = j + t * wpb; return (mine(vw) ? owncnt1 : cnt1)[r1(vw)]; }));
         const uint32_t n_seg = min(total - min(total, skip), sched_cap);
         auto round_at = [&](uint32_t r) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
@@ -427,8 +428,9 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
         };
         auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * PS_THREADS + threadIdx.x < x.n; };
         auto load = [&](uint32_t (&dst)[LOADS], const Round &x) {
-            const uint64_t ri = r1(j + x.t * wpb);
-            const uint32_t *src = buf1 + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
+            const uint32_t vw = j + x.t * wpb;
+            const uint64_t ri = r1(vw);
+            const uint32_t *src = (mine(vw) ? own1 : buf1) + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
 #pragma unroll
             for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * PS_THREADS + threadIdx.x : 0u];
         };
@@ -574,18 +576,19 @@ int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
     if (pl.world > 1) {
         (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1, pl.rown1, pl.rowncnt1);
     } else {
         (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
-                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1);
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     }
     if (pl.b3) {  // third level: bucket (b1, b2), input = the regions written above
         const int loads3 = split_loads(pl.b3);
         pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)loads3 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
         (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
-                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap, (const uint64_t *)nullptr);
+                           pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap, (const uint64_t *)nullptr,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     }
     return 0;
 }
@@ -659,7 +662,9 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, 
 }
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions are sized for the entries of all ranks
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels)
+// tight: level-1 regions sized at the expected fill + 6 sigma instead of 1.3 x + 8 sigma -- the regions of a sharded pass travel
+// whole (equal-block all_to_all: no packing pass), so slack is wire bytes; what does not fit goes the overflow list's way
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
@@ -701,7 +706,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     const uint64_t pairs = (pl.n_tiles + 1) / 2, pairs_wg = (pairs + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)(2 * pairs_wg) / (double)std::max<uint64_t>(pl.n_tiles, 1));
     const double avg1 = a_max * share1 / (double)(1 << pl.b1);
-    pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
+    pl.cap1 = ((uint64_t)(tight ? avg1 * std::min(frac, 1.0) + 6 * std::sqrt(avg1 * std::min(frac, 1.0)) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
     const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     pl.wpb3 = 1;

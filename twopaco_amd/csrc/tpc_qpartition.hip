@@ -405,8 +405,10 @@ template <bool SHARDED, bool RB>
 __global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
-          PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1)
-{   // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
+          PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1,
+          const uint64_t *__restrict__ own1, const uint32_t *__restrict__ owncnt1)
+{   // own1 / owncnt1 (sharded, optional): the block of source rank == this rank is read from the send buffers it was hashed into
+    // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 4;
@@ -428,6 +430,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         if (prev_wpb) return ((((uint64_t)(bl >> log_prev_nb2) * prev_wpb) + vw) << log_prev_nb2) + (bl & ((1u << log_prev_nb2) - 1u));
         return SHARDED ? pt_r1_recv(sh, NB1, nwg1, vw / nwg1, vw % nwg1, bl) : (uint64_t)vw * NB1 + bl;
     };
+    auto mine = [=](uint32_t vw) { return SHARDED && own1 && !prev_wpb && vw / nwg1 == sh.rank; };
     const int shift1 = L - LOG_NB1;
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
     // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
@@ -448,7 +451,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     uint64_t va[LOADS], vb[LOADS], vc[LOADS];
     for (uint32_t skip = 0;; skip += sched_cap) {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)pt_build_schedule<QS_THREADS>(
-            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { return cnt1[r1(j + t * wpb)]; }));
+            nreg, step, skip, sched_cap, s_cnt, s_sched, s_scan, [&](uint32_t t) { const uint32_t vw = j + t * wpb; return (mine(vw) ? owncnt1 : cnt1)[r1(vw)]; }));
         const uint32_t n_seg = min(total - min(total, skip), sched_cap);
         auto round_at = [&](uint32_t r) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sched[min(r, n_seg - 1u)]);
@@ -458,8 +461,9 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         };
         auto valid = [&](const Round &x, int i) { return i < loads && x.base + i * QS_THREADS + threadIdx.x < x.n; };
         auto load = [&](uint64_t (&dst)[LOADS], const Round &x) {
-            const uint64_t ri = r1(j + x.t * wpb);
-            const uint64_t *src = buf1 + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
+            const uint32_t vw = j + x.t * wpb;
+            const uint64_t ri = r1(vw);
+            const uint64_t *src = (mine(vw) ? own1 : buf1) + (off1 ? off1[ri] : ri * cap1);  // off1: the regions arrived packed (compacted exchange)
 #pragma unroll
             for (int i = 0; i < LOADS; i++) dst[i] = src[valid(x, i) ? x.base + i * QS_THREADS + threadIdx.x : 0u];
         };
@@ -977,6 +981,8 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
 }
 
 // ------------------------------------------------------------------------------------------ sharded verification
+constexpr int RT_CHUNK = 4096, RT_MAXW = 64;  // owner routing: items per workgroup round, most ranks
+constexpr int V_OWNER_SHIFT = TPC_V_OWNER_SHIFT;  // tagged probe addresses: owner rank above the shard-local bit address (< 2^41)
 // With the filter sharded by bit address the q-1 remaining probes of a survivor live on other ranks:
 // k_v_addrs gives, for hash functions fn .. fn+fn_count-1, the (owner rank, address inside the owner's
 // shard) of every survivor's edge; the host layer exchanges them, k_v_probe answers on the owner, the
@@ -986,9 +992,12 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
 template <int Q>
 __global__ void __launch_bounds__(256)
 k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ sid_list, uint64_t n,
-          uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
-{
+          uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out,
+          unsigned long long *owner_counts)
+{   // owner_out == nullptr: the owner rides in bits 56.. of the address (V_OWNER_SHIFT) and owner_counts[o] += probes for owner o
     __shared__ uint64_t s_h[Q * 5], s_hk[Q * 5];
+    __shared__ uint32_t s_own[RT_MAXW];
+    if (threadIdx.x < RT_MAXW) s_own[threadIdx.x] = 0;
     if (threadIdx.x < Q * 5) { s_h[threadIdx.x] = tab[threadIdx.x]; s_hk[threadIdx.x] = tab[TPC_TAB_HK + threadIdx.x]; }
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1031,9 +1040,20 @@ k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
             if (i < fn || i >= fn + fn_count) continue;
             const uint64_t ap = perm.fwd(ng ? nn[i] : p[i]);
             bool mine;
-            addr_out[idx * fn_count + (i - fn)] = pt_local_addr(perm, sh, log_nb2, ap, mine);
-            owner_out[idx * fn_count + (i - fn)] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+            const uint64_t la = pt_local_addr(perm, sh, log_nb2, ap, mine);
+            const uint32_t own = ((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1);
+            if (owner_out) {
+                addr_out[idx * fn_count + (i - fn)] = la;
+                owner_out[idx * fn_count + (i - fn)] = (int32_t)own;
+            } else {
+                addr_out[idx * fn_count + (i - fn)] = la | ((uint64_t)own << V_OWNER_SHIFT);
+                if (owner_counts) atomicAdd(&s_own[own & (RT_MAXW - 1)], 1u);
+            }
         }
+    }
+    if (owner_counts) {
+        __syncthreads();
+        if (threadIdx.x < RT_MAXW && s_own[threadIdx.x]) atomicAdd(&owner_counts[threadIdx.x], (unsigned long long)s_own[threadIdx.x]);
     }
 }
 
@@ -1043,10 +1063,13 @@ k_v_addrs(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
 template <int Q>
 __global__ void __launch_bounds__(256)
 k_v_addrs2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ sid_list, uint64_t n,
-           uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out)
-{
+           uint64_t gbase, PtPerm perm, PtShard sh, int log_nb2, int fn, int fn_count, uint64_t *__restrict__ addr_out, int32_t *__restrict__ owner_out,
+           unsigned long long *owner_counts)
+{   // owner_out == nullptr: tagged addresses and owner counts, as k_v_addrs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *s_t = reinterpret_cast<uint4 *>(smem);  // [k + 1][4][Q]: {rotl(h_i[c], k - t), rotl(h_i[3 - c], t)}
+    __shared__ uint32_t s_own[RT_MAXW];
+    if (threadIdx.x < RT_MAXW) s_own[threadIdx.x] = 0;
     const int k = P.k, L = P.L;
     for (int i = threadIdx.x; i < (k + 1) * 4 * Q; i += 256) {
         const int t = i / (4 * Q), c = (i / Q) & 3, f = i % Q;
@@ -1083,9 +1106,20 @@ k_v_addrs2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
             if (i < fn || i >= fn + fn_count) continue;
             const uint64_t ap = perm.fwd(ng ? nn[i] : p[i]);
             bool mine;
-            addr_out[idx * fn_count + (i - fn)] = pt_local_addr(perm, sh, log_nb2, ap, mine);
-            owner_out[idx * fn_count + (i - fn)] = (int32_t)(((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1));
+            const uint64_t la = pt_local_addr(perm, sh, log_nb2, ap, mine);
+            const uint32_t own = ((uint32_t)(ap >> perm.slice_bits) >> log_nb2) & (sh.world - 1);
+            if (owner_out) {
+                addr_out[idx * fn_count + (i - fn)] = la;
+                owner_out[idx * fn_count + (i - fn)] = (int32_t)own;
+            } else {
+                addr_out[idx * fn_count + (i - fn)] = la | ((uint64_t)own << V_OWNER_SHIFT);
+                if (owner_counts) atomicAdd(&s_own[own & (RT_MAXW - 1)], 1u);
+            }
         }
+    }
+    if (owner_counts) {
+        __syncthreads();
+        if (threadIdx.x < RT_MAXW && s_own[threadIdx.x]) atomicAdd(&owner_counts[threadIdx.x], (unsigned long long)s_own[threadIdx.x]);
     }
 }
 
@@ -1121,7 +1155,6 @@ __global__ void k_v_mark(const uint64_t *__restrict__ sid_list, uint64_t n, uint
 // ---- owner routing of the survivor probes (the host layer only moves the buffers) -------------------------
 // perm[i] = slot of item i in the owner-major send order.  Each workgroup ranks a chunk of items in LDS (one LDS
 // atomic per item) and reserves its share of every owner's range with one global atomic per owner and chunk.
-constexpr int RT_CHUNK = 4096, RT_MAXW = 64;
 __global__ void __launch_bounds__(256)
 k_route_count(const int32_t *__restrict__ owner, uint64_t n, unsigned long long *counts)
 {
@@ -1177,26 +1210,116 @@ __global__ void k_permute_rows(const uint64_t *__restrict__ src, const uint32_t 
     }
 }
 
-// survivors whose fn_count answers (in send order: hit[perm[...]]) are all 1; order of the output is not significant
+// all fn_count answers of survivor i are 1.  The answers arrive in SEND order: hit[perm[i * fn_count + t]]; perm == nullptr: the send
+// order was the natural one (one rank).  Every load is issued before any is tested.
+__device__ __forceinline__ bool v_all_hit(const uint8_t *__restrict__ hit, const uint32_t *__restrict__ perm, uint64_t i, int fn_count)
+{
+    const uint64_t b = i * (uint64_t)fn_count;
+    uint32_t acc = 1;
+    if (!perm) {
+        if (fn_count == 4) return *reinterpret_cast<const uint32_t *>(hit + b) == 0x01010101u;
+        for (int t = 0; t < fn_count; t++) acc &= hit[b + t];
+        return acc != 0;
+    }
+    constexpr int U = 4;
+    for (int t0 = 0; t0 < fn_count; t0 += U) {
+        uint32_t slot[U], h[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) slot[u] = t0 + u < fn_count ? perm[b + t0 + u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; u++) h[u] = slot[u] != 0xFFFFFFFFu ? hit[slot[u]] : 1u;
+#pragma unroll
+        for (int u = 0; u < U; u++) acc &= h[u];
+    }
+    return acc != 0;
+}
+
+// survivors whose fn_count answers are all 1; order of the output is not significant.  Compaction per wave: a ballot, one global
+// atomic per wave and round (no workgroup barrier: the waves run independently).
 __global__ void __launch_bounds__(256)
 k_select(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8_t *__restrict__ hit, const uint32_t *__restrict__ perm,
          uint64_t *__restrict__ out, unsigned long long *n_out)
 {
-    __shared__ uint32_t s_cnt;
-    __shared__ unsigned long long s_base;
-    for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < n; c0 += (uint64_t)gridDim.x * 256) {
-        if (threadIdx.x == 0) s_cnt = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint64_t i = i0 + lane;
+        const bool keep = i < n && v_all_hit(hit, perm, i, fn_count);
+        const uint64_t id = keep ? sid[i] : 0ull;
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) out[base + __popcll(m & ((1ull << lane) - 1ull))] = id;
+    }
+}
+
+// last round of a batch: select and mark in one pass (no list of the kept ids); *n_marked += survivors that passed
+__global__ void __launch_bounds__(256)
+k_v_finish(const uint64_t *__restrict__ sid, uint64_t n, int fn_count, const uint8_t *__restrict__ hit, const uint32_t *__restrict__ perm,
+           uint64_t gbase, uint64_t posmask, uint32_t *rmask, unsigned long long *n_marked)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!v_all_hit(hit, perm, i, fn_count)) continue;
+        const uint64_t g = gbase + ((sid[i] >> 3) & posmask);
+        atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
+        mine++;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_marked, (unsigned long long)mine);
+}
+
+// owner routing of tagged 64-bit items in one go: the owner is ((v >> shift) & omask); counts[o] (exclusive cursors set by the caller)
+// give every owner its range of dst; dst[slot] = v & keep, perm[i] = slot (perm may be null).  The ranking is k_route_scatter's.
+__global__ void __launch_bounds__(256)
+k_route_scatter64(const uint64_t *__restrict__ v, uint64_t n, int shift, uint32_t omask, uint64_t keep, unsigned long long *cursor,
+                  uint32_t *__restrict__ perm, uint64_t *__restrict__ dst)
+{
+    __shared__ uint32_t h[RT_MAXW];
+    __shared__ unsigned long long base[RT_MAXW];
+    for (uint64_t c0 = (uint64_t)blockIdx.x * RT_CHUNK; c0 < n; c0 += (uint64_t)gridDim.x * RT_CHUNK) {
+        if (threadIdx.x < RT_MAXW) h[threadIdx.x] = 0;
         __syncthreads();
-        const uint64_t i = c0 + threadIdx.x;
-        bool keep = i < n;
-        for (int t = 0; keep && t < fn_count; t++) keep = hit[perm[i * fn_count + t]] != 0;
-        const uint32_t r = keep ? atomicAdd(&s_cnt, 1u) : 0u;
+        uint32_t rank[RT_CHUNK / 256];
+        int own[RT_CHUNK / 256];
+        uint64_t val[RT_CHUNK / 256];
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 256; u++) {
+            const uint64_t i = c0 + (uint64_t)u * 256 + threadIdx.x;
+            val[u] = i < n ? v[i] : 0ull;
+            own[u] = i < n ? (int)((uint32_t)(val[u] >> shift) & omask & (RT_MAXW - 1)) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 256; u++) rank[u] = own[u] >= 0 ? atomicAdd(&h[own[u]], 1u) : 0u;
         __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_out, (unsigned long long)s_cnt);
+        if (threadIdx.x < RT_MAXW && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]);
         __syncthreads();
-        if (keep) out[s_base + r] = sid[i];
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 256; u++) {
+            const uint64_t i = c0 + (uint64_t)u * 256 + threadIdx.x;
+            if (own[u] >= 0) {
+                const uint64_t slot = base[own[u]] + rank[u];
+                dst[slot] = val[u] & keep;
+                if (perm) perm[i] = (uint32_t)slot;
+            }
+        }
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_route_count64(const uint64_t *__restrict__ v, uint64_t n, int shift, uint32_t omask, unsigned long long *counts)
+{
+    __shared__ uint32_t h[RT_MAXW];
+    if (threadIdx.x < RT_MAXW) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[(uint32_t)(v[i] >> shift) & omask & (RT_MAXW - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < RT_MAXW && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
 // 512 bins per level (f = 37, 38 at the default slice size): the barrier-free rings (k_q_hash / k_q_split<.., RB = true>)
@@ -1252,7 +1375,7 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 // one level of k_q_split: log_nb1 bits already binned, log_nb2 bits binned here; nvw source regions per bucket
 void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, int low_bits, int loads, uint32_t nwg1, uint32_t wpb, uint32_t nvw,
                    const uint64_t *buf1, const uint32_t *cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *off2, QOverflow ovf, PtShard sh,
-                   uint32_t prev_wpb, int log_prev_nb2, const uint64_t *off1, unsigned grid)
+                   uint32_t prev_wpb, int log_prev_nb2, const uint64_t *off1, unsigned grid, const uint64_t *own1 = nullptr, const uint32_t *owncnt1 = nullptr)
 {
     const bool rb = q_use_rbins(log_nb2);
     const size_t lds_base = (rb ? RBins<uint64_t, QS_THREADS>::lds_bytes(log_nb2) : Bins3<uint64_t, QS_THREADS>::lds_bytes(log_nb2)) + ((size_t)8 << log_nb2) + 64 + 128;
@@ -1264,7 +1387,7 @@ void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, i
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_q_split<S, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
         hipLaunchKernelGGL((k_q_split<S, R>), dim3(grid), dim3(QS_THREADS), lds, a.stream, log_nb1, log_nb2, a.P.L, low_bits, loads, nwg1, wpb, buf1, cnt1, cap1,   \
-                           buf2, cnt2, off2, ovf, sh, prev_wpb, log_prev_nb2, nreg_cap, sched_cap, off1);                                    \
+                           buf2, cnt2, off2, ovf, sh, prev_wpb, log_prev_nb2, nreg_cap, sched_cap, off1, own1, owncnt1);                     \
     } while (0)
     if (sharded) { if (rb) TPC_QSPLIT_GO(true, true); else TPC_QSPLIT_GO(true, false); }
     else { if (rb) TPC_QSPLIT_GO(false, true); else TPC_QSPLIT_GO(false, false); }
@@ -1302,7 +1425,7 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPl
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions cover the slices this rank owns and are sized
 // for the entries of all ranks
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels)
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
@@ -1347,7 +1470,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
     const double avg1 = a_max * share1 / (double)(1 << pl.b1);
-    pl.cap1 = ((uint64_t)(avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
+    pl.cap1 = ((uint64_t)(tight ? avg1 * std::min(frac, 1.0) + 6 * std::sqrt(avg1 * std::min(frac, 1.0)) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;  // tight: as in tpc_part_plan_sharded
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
     pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
     const PtPerm pm = pt_make_perm(slice_bits, F);
@@ -1426,7 +1549,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
         launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, low_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2,
-                      ovf, sh, 0u, 0, pl.roff1, (unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));
+                      ovf, sh, 0u, 0, pl.roff1, (unsigned)(((1u << pl.b1) / pl.world) * pl.wpb), pl.rown1, pl.rowncnt1);
         if (pl.b3)  // third level: bucket (b1, b2); the middle regions are uniform (cap2 entries each)
             launch_qsplit(a, false, pl.b1 + pl.b2, pl.b3, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.wpb, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3,
                           ovf, sh, pl.wpb, pl.b2, nullptr, (unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3));
@@ -1520,8 +1643,8 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32
 }
 
 int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out,
-                            int32_t *owner_out)
-{
+                            int32_t *owner_out, unsigned long long *owner_counts)
+{   // owner_out == nullptr: tagged addresses (owner << V_OWNER_SHIFT) and, when owner_counts is given, the probes per owner
     if (fn < 0 || fn_count < 1 || fn + fn_count > a.P.q) return -1;
     if (n == 0) return 0;
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
@@ -1534,9 +1657,9 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
     do {                                                                                                                                                 \
         if (lean) {                                                                                                                                      \
             (void)hipFuncSetAttribute((const void *)k_v_addrs2<Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);                             \
-            hipLaunchKernelGGL((k_v_addrs2<Q_>), grid, dim3(256), table, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out); \
+            hipLaunchKernelGGL((k_v_addrs2<Q_>), grid, dim3(256), table, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out, owner_counts); \
         } else                                                                                                                                           \
-            hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out); \
+            hipLaunchKernelGGL((k_v_addrs<Q_>), grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, sid, n, gbase, perm, sh, pl.b2 + pl.b3, fn, fn_count, addr_out, owner_out, owner_counts); \
     } while (0)
     switch (a.P.q) {
     case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;
@@ -1601,6 +1724,25 @@ int tpc_launch_permute_rows(hipStream_t s, const uint64_t *src, const uint32_t *
 int tpc_launch_select(hipStream_t s, const uint64_t *sid, uint64_t n, int fn_count, const uint8_t *hit, const uint32_t *perm, uint64_t *out, unsigned long long *n_out)
 {
     if (n) hipLaunchKernelGGL(k_select, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, sid, n, fn_count, hit, perm, out, n_out);
+    return 0;
+}
+
+int tpc_launch_finish(hipStream_t s, const TpcQPlan &pl, const uint64_t *sid, uint64_t n, int fn_count, const uint8_t *hit, const uint32_t *perm, uint32_t *rmask,
+                      unsigned long long *n_marked)
+{
+    uint32_t lw = 0;
+    while ((1u << lw) < pl.world) ++lw;
+    if (n) hipLaunchKernelGGL(k_v_finish, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, sid, n, fn_count, hit, perm,
+                              pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), (1ull << (30u - lw)) - 1ull, rmask, n_marked);
+    return 0;
+}
+
+int tpc_launch_route64(hipStream_t s, const uint64_t *v, uint64_t n, int shift, uint32_t omask, uint64_t keep, unsigned long long *counts, unsigned long long *cursor,
+                       uint32_t *perm, uint64_t *dst, int phase)
+{   // phase 0: counts[o] += items of owner o; phase 1: scatter by the cursors
+    if (n == 0) return 0;
+    if (phase == 0) hipLaunchKernelGGL(k_route_count64, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, v, n, shift, omask, counts);
+    else hipLaunchKernelGGL(k_route_scatter64, dim3((unsigned)std::min<uint64_t>((n + RT_CHUNK - 1) / RT_CHUNK, 4096)), dim3(256), 0, s, v, n, shift, omask, keep, cursor, perm, dst);
     return 0;
 }
 

@@ -242,19 +242,23 @@ class _Comm:
 
     CHUNK = 1 << 28  # bytes per peer and message: multi-GiB all_to_all_single calls arrived truncated under RCCL (zeros past a point)
 
-    def a2a_equal(self, send):
+    def a2a_equal(self, send, skip_self=False):
         """Block d of `send` goes to rank d; block s of the result came from rank s.  Over RCCL: grouped send/recv of at
-        most CHUNK bytes per peer (what a C++ host issues as ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd)."""
+        most CHUNK bytes per peer (what a C++ host issues as ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd).
+        skip_self: the caller reads its own block from `send` (tpc_shard_apply_inplace); block `rank` of the result is then
+        undefined (not copied)."""
         torch = self.torch
         self.sync()
-        self.bytes_moved += send.numel() * send.element_size()
+        if self.world == 1:
+            return send  # one rank: the block is already where it is read
+        self.bytes_moved += send.numel() * send.element_size() * ((self.world - 1) / self.world if skip_self else 1)
         self._enter("all_to_all(equal)")
         try:
-            return self._a2a_equal(send)
+            return self._a2a_equal(send, skip_self)
         finally:
             self._leave()
 
-    def _a2a_equal(self, send):
+    def _a2a_equal(self, send, skip_self=False):
         torch = self.torch
         if not self.p2p:
             s = self._in(send)
@@ -275,7 +279,8 @@ class _Comm:
             ops = []
             for p in range(self.world):
                 if p == self.rank:
-                    recv[p, c0:c1].copy_(sb[p, c0:c1])
+                    if not skip_self:
+                        recv[p, c0:c1].copy_(sb[p, c0:c1])
                 else:
                     ops.append(self.dist.P2POp(self.dist.isend, sb[p, c0:c1], p))
                     ops.append(self.dist.P2POp(self.dist.irecv, recv[p, c0:c1], p))
@@ -286,17 +291,21 @@ class _Comm:
         self.sync()  # inside the watchdog's phase: over RCCL the waits above only order the stream
         return out
 
-    def a2a_var(self, send, counts):
-        """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source)."""
+    def a2a_var(self, send, counts, out=None):
+        """`send` holds counts[d] elements for rank d, in rank order.  Returns (received, counts per source).  out(numel, dtype): where
+        to receive (device path); one rank: nothing moves and `send` itself is returned."""
         torch = self.torch
         self.sync()
+        if self.world == 1:
+            self._agreed([self.rc], "all_to_all(variable)")
+            return send, [int(counts[0])]
         self._enter("all_to_all(variable)")
         try:
-            return self._a2a_var(send, counts)
+            return self._a2a_var(send, counts, out)
         finally:
             self._leave()
 
-    def _a2a_var(self, send, counts):
+    def _a2a_var(self, send, counts, out=None):
         torch = self.torch
         # the count exchange carries every rank's failure flag: {count, rc} per peer, so all ranks agree before any payload moves
         # (a rank whose local work failed sends zero counts and rc = 1; nobody is left waiting for its data)
@@ -326,7 +335,7 @@ class _Comm:
             return out, rcl
         # RCCL: grouped send/recv, at most CHUNK bytes per peer and message
         send = self._in(send)
-        r = torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
+        r = out(sum(rcl), send.dtype) if out is not None and self.direct else torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
         step = max(1, self.CHUNK // send.element_size())
         so, ro = [0], [0]
         for p in range(self.world):
@@ -418,11 +427,19 @@ class AddressSharded:
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
     list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
 
-    def __init__(self, ctx, dist, device, compact=True, configure=True):
+    def __init__(self, ctx, dist, device, compact=None, configure=True):
         import torch
         self.ctx, self.torch = ctx, torch
-        self.compact = compact  # exact-size exchange of the level-1 regions (tpc_shard_pack) instead of equal blocks
         self.comm = _Comm(dist, device)
+        # compact: exact-size exchange of the level-1 regions (tpc_shard_pack: a read and a write of every entry, then a variable
+        # all_to_all) instead of the equal blocks moved as they are, the own block read in place (tpc_shard_apply_inplace).  The
+        # regions are sized at the expected fill + 6 sigma + 128 entries (option shard_tight_regions): a few per cent of slack up to
+        # four ranks, ~12 % at eight (a region then holds 3.6 K entries on the 62-genome workload), where the wire is what a pass
+        # waits for: packing pays there and not below.  TPC_SHARD_EXCHANGE = packed / equal overrides.
+        if compact is None:
+            mode = os.environ.get("TPC_SHARD_EXCHANGE", "auto")
+            compact = mode == "packed" or (mode == "auto" and self.comm.world >= 8)
+        self.compact = bool(compact)
         self.device = device
         self.rank, self.world = self.comm.rank, self.comm.world
         if configure:  # False: the caller did it before tpc_seq_upload (needed for option text_window to take effect)
@@ -455,6 +472,13 @@ class AddressSharded:
             self._bufs[name] = b
         return b[:nbytes]
 
+    def _out_buf(self, name):
+        """Receive-buffer provider for _Comm.a2a_var: a named persistent buffer instead of a fresh allocation per call."""
+        def alloc(numel, dtype):
+            size = self.torch.empty(0, dtype=dtype).element_size()
+            return self._buf(name, max(numel, 1) * size).view(dtype)[:numel]
+        return alloc
+
     def _exchange(self, which, geom, batch, lo, hi):
         W = self.world
         send_r = self._buf("send_r", W * geom["region_block_bytes"])
@@ -478,10 +502,11 @@ class AddressSharded:
             recv_r = recv_r.view(self.torch.uint8)
             if recv_r.numel() == 0:
                 recv_r = self._buf("recv_empty", 16)
-            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + sum(nbytes)
+            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + sum(nbytes) - nbytes[self.rank]  # what leaves this rank
         else:
-            recv_r = self.comm.a2a_equal(send_r)
-            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + send_r.numel()
+            # equal blocks as they are; this rank's own block stays where it was hashed (one rank: nothing moves at all)
+            recv_r = self.comm.a2a_equal(send_r, skip_self=True) if W > 1 else None
+            self.stats["region_bytes_sent"] = self.stats.get("region_bytes_sent", 0) + send_r.numel() * (W - 1) // W
         self.comm.sync()
         t0 = self._tick(tag + "_all_to_all", t0)
         # skew path: entries that did not fit their level-1 region, for any owner
@@ -500,7 +525,13 @@ class AddressSharded:
             self.comm.sync()
             self._try(self.ctx.shard_overflow_set, which, cat.data_ptr(), cat.numel() // eb)
         self.comm.sync()
-        return recv_r, recv_c
+        return recv_r, recv_c, send_r, send_c
+
+    def _apply(self, which, b, x):
+        recv_r, recv_c, send_r, send_c = x
+        if self.compact:
+            return self._try(self.ctx.shard_apply_packed, which, b, recv_r.data_ptr(), recv_c.data_ptr())
+        return self._try(self.ctx.shard_apply_inplace, which, b, recv_r.data_ptr() if recv_r is not None else 0, recv_c.data_ptr(), send_r.data_ptr(), send_c.data_ptr())
 
     def insert(self, lo=0, hi=None):
         self.comm.phase = "insert plan"
@@ -508,9 +539,9 @@ class AddressSharded:
         self.comm.agree()  # every rank has a plan (the batch geometry must agree) before the first exchange
         self._try(self.ctx.filter_reset)
         for b in range(geom["batches"]):
-            recv_r, recv_c = self._exchange(INSERT, geom, b, lo, hi)
+            x = self._exchange(INSERT, geom, b, lo, hi)
             t0 = time.perf_counter()
-            self._try(self.ctx.shard_apply_packed if self.compact else self.ctx.shard_apply, INSERT, b, recv_r.data_ptr(), recv_c.data_ptr())
+            self._apply(INSERT, b, x)
             self._tick("insert_apply", t0)
         return geom
 
@@ -538,58 +569,55 @@ class AddressSharded:
         survivors = []
         zeros = [0] * W
         for b in range(geom["batches"]):
-            recv_r, recv_c = self._exchange(QUERY, geom, b, lo, hi)
+            x = self._exchange(QUERY, geom, b, lo, hi)
             t0 = time.perf_counter()
-            n = self._try(ctx.shard_apply_packed if self.compact else ctx.shard_apply, QUERY, b, recv_r.data_ptr(), recv_c.data_ptr())
+            n = self._apply(QUERY, b, x)
             t0 = self._tick("query_apply", t0)
             self.comm.phase = "query batch %d: survivors home" % b
-            sid = torch.empty(n, dtype=torch.int64, device=self.device)
-            self._try(ctx.shard_survivors, sid.data_ptr())
             # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
-            # their text is: a rank then needs only its own chunk of the packed text
-            src = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            self._try(ctx.shard_survivor_sources, sid.data_ptr(), n, src.data_ptr())
-            perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            counts = self._try(ctx.shard_route, src.data_ptr(), n, perm.data_ptr(), W, default=zeros)
-            send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
-            self._try(ctx.shard_permute64, sid.data_ptr(), perm.data_ptr(), n, send.data_ptr())
-            sid, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
-            sid = sid.contiguous()
+            # their text is: a rank then needs only its own chunk of the packed text.  The library groups them by that rank.
+            home = self._buf("v_home", max(n, 1) * 8).view(torch.int64)
+            tmp = self._buf("v_tmp", max(n, 1) * 8 if W > 1 else 8).view(torch.int64)
+            counts = self._try(ctx.shard_survivors_home, tmp.data_ptr(), home.data_ptr(), W, default=zeros)
+            sid, _ = self.comm.a2a_var(home[:n], counts, out=self._out_buf("v_sid"))
             self.comm.sync()
             t0 = self._tick("query_survivors_home", t0)
             trace = [n]
-            # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange
-            for fn, cnt in self._verify_rounds(n):
+            # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange -- or all at once (_verify_rounds)
+            rounds = self._verify_rounds(n)
+            for ri, (fn, cnt) in enumerate(rounds):
                 self.comm.phase = "query batch %d: probes of functions %d..%d" % (b, fn, fn + cnt - 1)
                 n = sid.numel()
-                addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
-                owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
-                self._try(ctx.shard_verify_addrs, fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
-                t0 = self._tick("query_verify_addrs", t0)
-                # owner-major send order from the library (tpc_shard_route), answers come back in that order
-                perm = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
-                counts = self._try(ctx.shard_route, owner.data_ptr(), n * cnt, perm.data_ptr(), W, default=zeros)
-                send = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
-                self._try(ctx.shard_permute64, addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
-                t0 = self._tick("query_verify_route", t0)
-                req, rcounts = self.comm.a2a_var(send, counts)
-                hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
+                # probe addresses in owner-major send order + the slot of every probe (answers come back in that order)
+                send = self._buf("v_send", max(n * cnt, 1) * 8).view(torch.int64)
+                tmp = self._buf("v_tmp", max(n * cnt, 1) * 8 if W > 1 else 8).view(torch.int64)
+                perm = self._buf("v_perm", max(n * cnt, 1) * 4 if W > 1 else 4).view(torch.int32)
+                counts = self._try(ctx.shard_verify_send, fn, cnt, sid.data_ptr(), n, tmp.data_ptr(), send.data_ptr(), perm.data_ptr(), W, default=zeros)
+                t0 = self._tick("query_verify_addrs_route", t0)
+                req, rcounts = self.comm.a2a_var(send[:n * cnt], counts, out=self._out_buf("v_req"))
+                hit = self._buf("v_hit", max(req.numel(), 1))
                 self.comm.sync()
                 t0 = self._tick("query_verify_all_to_all", t0)
                 self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
                 t0 = self._tick("query_verify_probe", t0)
-                back, _ = self.comm.a2a_var(hit, rcounts)
-                back = back.contiguous()
-                kept = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+                back, _ = self.comm.a2a_var(hit[:req.numel()], rcounts, out=self._out_buf("v_back"))
                 self.comm.sync()
                 t0 = self._tick("query_verify_all_to_all", t0)
-                m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
-                sid = kept[:m].contiguous()
-                trace.append(sid.numel())
-                t0 = self._tick("query_verify_select", t0)
+                perm_ptr = perm.data_ptr() if W > 1 else 0  # one rank: natural order
+                if ri + 1 == len(rounds):  # the last round marks what passed
+                    m = self._try(ctx.shard_finish, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr)
+                    trace.append(m)
+                    t0 = self._tick("query_verify_finish", t0)
+                else:
+                    kept = self._buf("v_kept%d" % (ri & 1), max(n, 1) * 8).view(torch.int64)
+                    m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr, kept.data_ptr())
+                    sid = kept[:m]
+                    trace.append(m)
+                    t0 = self._tick("query_verify_select", t0)
+            if not rounds:  # a single hash function: the first probe was the only one
+                self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
+                t0 = self._tick("query_verify_finish", t0)
             self.comm.sync()
-            self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
-            self._tick("query_verify_mark", t0)
             survivors.append(trace)
             if len(trace) > 2 and not hasattr(self, "_fn1_pass_rate"):  # a lazy batch was measured: survivors of function 1 / first-probe survivors, all ranks
                 tot = self.comm.max_ints([trace[1], trace[0]])  # (max over ranks: a decision every rank takes alike)

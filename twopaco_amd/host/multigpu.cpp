@@ -99,18 +99,19 @@ namespace TwoPaCo
 			LoopbackTransport(const std::vector<int> & devices) : Transport(int(devices.size())), devices_(devices), send_(devices.size()), counts_(devices.size()) {}
 			const char * Name() const { return "loopback (device-to-device copies inside the process)"; }
 
-			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
+			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes, bool skipSelf)
 			{
 				send_[rank] = send;
 				barrier_.Wait();
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
 				for (int s = 0; s < ranks_; s++)
 				{
+					if (skipSelf && s == rank) continue;
 					HipCheck(hipMemcpy(static_cast<char*>(recv) + size_t(s) * blockBytes, static_cast<const char*>(send_[s]) + size_t(rank) * blockBytes,
 						blockBytes, hipMemcpyDeviceToDevice), "loopback all-to-all copy");
 				}
 
-				if (rank == 0) bytesMoved_ += uint64_t(ranks_) * blockBytes;
+				if (rank == 0) bytesMoved_ += uint64_t(ranks_ - (skipSelf ? 1 : 0)) * blockBytes;
 				barrier_.Wait();  // nobody reuses a send buffer before every peer has copied from it
 			}
 
@@ -218,7 +219,7 @@ namespace TwoPaCo
 			// messages are cut up (a multi-GiB all_to_all arrived truncated in the torch.distributed driver; dist.py does the same).
 			static const size_t CHUNK = size_t(1) << 28;
 
-			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes)
+			void AllToAll(int rank, const void * send, void * recv, size_t blockBytes, bool skipSelf)
 			{
 				Agree();
 				HipCheck(hipSetDevice(devices_[rank]), "hipSetDevice");
@@ -228,6 +229,7 @@ namespace TwoPaCo
 					Check(api_.GroupStart(), "ncclGroupStart");
 					for (int p = 0; p < ranks_; p++)
 					{
+						if (skipSelf && p == rank) continue;
 						Check(api_.Send(static_cast<const char*>(send) + size_t(p) * blockBytes + c0, n, ncclUint8, p, comms_[rank], streams_[rank]), "ncclSend");
 						Check(api_.Recv(static_cast<char*>(recv) + size_t(p) * blockBytes + c0, n, ncclUint8, p, comms_[rank], streams_[rank]), "ncclRecv");
 					}
@@ -236,7 +238,7 @@ namespace TwoPaCo
 				}
 
 				HipCheck(hipStreamSynchronize(streams_[rank]), "all-to-all");
-				if (rank == 0) bytesMoved_ += uint64_t(ranks_) * blockBytes;
+				if (rank == 0) bytesMoved_ += uint64_t(ranks_ - (skipSelf ? 1 : 0)) * blockBytes;
 			}
 
 			void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes)
@@ -386,6 +388,13 @@ namespace TwoPaCo
 			LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
 		}
 
+		// levels 2-3 over what Exchange left in r.buf[RECV_R] / [RECV_C] (and, unpacked, this rank's own block in the send buffers)
+		void Apply(ShardedRank & r, int pass, uint64_t batch, const void * sendR, const void * sendC, uint64_t * survivors)
+		{
+			if (r.compactExchange) LibCheck(r.ctx, tpc_shard_apply_packed(r.ctx, pass, batch, r.buf[RECV_R], r.buf[RECV_C], survivors), "shard_apply_packed");
+			else LibCheck(r.ctx, tpc_shard_apply_inplace(r.ctx, pass, batch, r.buf[RECV_R], r.buf[RECV_C], sendR, sendC, survivors), "shard_apply_inplace");
+		}
+
 		// everything between a batch's hash and its apply: counts, (packed) regions, overflow lists
 		void Exchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, void * sendR, void * sendC, uint64_t overflow, bool overflowFetched)
 		{
@@ -409,7 +418,7 @@ namespace TwoPaCo
 				{
 					sendUnits[s] = bytes[s] / 16;
 					recvUnits[s] = all[size_t(s) * W + r.rank] / 16;
-					r.regionBytesSent += bytes[s];
+					if (s != r.rank) r.regionBytesSent += bytes[s];  // what leaves this rank
 				}
 
 				net.AllToAllV(r.rank, packed, sendUnits.data(), recvR, recvUnits.data(), 16);
@@ -417,8 +426,10 @@ namespace TwoPaCo
 			}
 			else
 			{
-				net.AllToAll(r.rank, sendR, recvR, geom[2]);
-				r.regionBytesSent += uint64_t(W) * geom[2];
+				// the equal blocks as they are (tight regions: tpc_shard_plan); this rank's own block stays where it was hashed
+				net.AllToAll(r.rank, sendR, recvR, geom[2], true);
+				r.regionBytesSent += uint64_t(W - 1) * geom[2];
+				r.Phase(pass == TPC_SHARD_INSERT ? "insert all-to-all" : "query all-to-all");
 			}
 
 			// skew path: entries that did not fit their level-1 region travel as one all-gathered list
@@ -580,7 +591,7 @@ namespace TwoPaCo
 				if (more) LibCheck(r.ctx, tpc_shard_hash_begin(r.ctx, TPC_SHARD_INSERT, b + 1, lo, hi, nextR, nextC), "shard_hash_begin");
 				else LibCheck(r.ctx, tpc_shard_hash_begin(r.ctx, TPC_SHARD_QUERY, 0, lo, hi, nextR, nextC), "shard_hash_begin(query)");
 				Exchange(r, net, TPC_SHARD_INSERT, gi, curR, curC, overflow, true);
-				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+				Apply(r, TPC_SHARD_INSERT, b, curR, curC, 0);
 				r.Phase("insert apply");
 				if (more) LibCheck(r.ctx, tpc_shard_hash_end(r.ctx, TPC_SHARD_INSERT, &overflow), "shard_hash_end");
 				slot ^= 1;
@@ -603,7 +614,7 @@ namespace TwoPaCo
 
 				Exchange(r, net, TPC_SHARD_QUERY, gq, curR, curC, overflow, true);
 				uint64_t n = 0;
-				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+				Apply(r, TPC_SHARD_QUERY, b, curR, curC, &n);
 				r.Phase("query apply");
 				VerifyBatch(r, net, hashFunctions, n);
 				if (more) LibCheck(r.ctx, tpc_shard_hash_end(r.ctx, TPC_SHARD_QUERY, &overflow), "shard_hash_end");
@@ -630,7 +641,7 @@ namespace TwoPaCo
 			for (uint64_t b = 0; b < geom[0]; b++)
 			{
 				HashAndExchange(r, net, TPC_SHARD_INSERT, geom, b, lo, hi);
-				LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_INSERT, b, r.buf[RECV_R], r.buf[RECV_C], 0), "shard_apply(insert)");
+				Apply(r, TPC_SHARD_INSERT, b, r.buf[SEND_R], r.buf[SEND_C], 0);
 				r.Phase("insert apply");
 			}
 		}
@@ -646,7 +657,7 @@ namespace TwoPaCo
 		{
 			HashAndExchange(r, net, TPC_SHARD_QUERY, geom, b, lo, hi);
 			uint64_t n = 0;
-			LibCheck(r.ctx, (r.compactExchange ? tpc_shard_apply_packed : tpc_shard_apply)(r.ctx, TPC_SHARD_QUERY, b, r.buf[RECV_R], r.buf[RECV_C], &n), "shard_apply(query)");
+			Apply(r, TPC_SHARD_QUERY, b, r.buf[SEND_R], r.buf[SEND_C], &n);
 			r.Phase("query apply");
 			VerifyBatch(r, net, hashFunctions, n);
 		}

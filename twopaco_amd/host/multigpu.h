@@ -52,8 +52,9 @@ namespace TwoPaCo
 		Transport(int ranks) : ranks_(ranks), barrier_(ranks), scratch_(size_t(ranks) * 64) {}
 		virtual ~Transport() {}
 		int Ranks() const { return ranks_; }
-		// block d of `send` goes to rank d; block s of `recv` came from rank s
-		virtual void AllToAll(int rank, const void * send, void * recv, size_t blockBytes) = 0;
+		// block d of `send` goes to rank d; block s of `recv` came from rank s.  skipSelf: the caller reads its own block from `send`
+		// (tpc_shard_apply_inplace), block `rank` of `recv` is left alone
+		virtual void AllToAll(int rank, const void * send, void * recv, size_t blockBytes, bool skipSelf = false) = 0;
 		// sendCounts[d] elements for rank d (contiguous, rank order); recvCounts[s] elements from rank s
 		virtual void AllToAllV(int rank, const void * send, const uint64_t * sendCounts, void * recv, const uint64_t * recvCounts, size_t elemBytes) = 0;
 		virtual void AllGather(int rank, const void * send, void * recv, size_t bytes) = 0;

@@ -393,8 +393,13 @@ namespace TwoPaCo
 					logStream << "GPUs = " << gpus << " (Bloom filter sharded by bit address; transport: " << net->Name() << ")" << std::endl;
 					peers_.resize(gpus);
 					peers_[0].rank = 0; peers_[0].device = devices[0]; peers_[0].ctx = ctx_;
-					// testing knob: TWOPACO_EQUAL_EXCHANGE=1 moves the level-1 regions as equal fixed-capacity blocks instead of packed
-					const bool compact = std::getenv("TWOPACO_EQUAL_EXCHANGE") == 0;
+					// The level-1 regions travel as equal blocks (sized tightly: tpc_shard_plan; the own block is read in place) up to four
+					// ranks and packed to their exact sizes from eight on, where the wire is what a pass waits for and a region is small
+					// enough for its 6-sigma slack to be ~12 %.  TWOPACO_EXCHANGE=packed / equal overrides (TWOPACO_EQUAL_EXCHANGE=1: equal).
+					const char * exch = std::getenv("TWOPACO_EXCHANGE");
+					bool compact = gpus >= 8;
+					if (exch && !std::strcmp(exch, "packed")) compact = true;
+					if ((exch && !std::strcmp(exch, "equal")) || std::getenv("TWOPACO_EQUAL_EXCHANGE") != 0) compact = false;
 					for (int r = 0; r < gpus; r++)
 					{
 						peers_[r].compactExchange = compact;
