@@ -113,7 +113,7 @@ def addr_worker(rank, world, port, spec, result_path):
         if windowed:
             if world > 1 and len(text.bases) > 8 * 512 * world:  # (a window is whole 512-word tiles + a halo: only meaningful on texts of many tiles)
                 assert ctx.stat("text_words") < len(text.bases) * (1.0 / world + 0.25) + 600, (ctx.stat("text_words"), len(text.bases))
-        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True), configure=not windowed)
+        sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True), configure=not windowed, fused=sp.get("fused_verify", True))
         out = {"rounds": []}
         for lo, hi in sp["ranges"]:
             geom = sh.insert(lo, hi)

@@ -239,6 +239,7 @@ def test_address_sharded_randomized(world, tmp_path):
         cut = sorted(int(x) for x in rng.integers(0, size, 2))
         specs.append({"records": recs, "k": k, "L": L, "q": q, "seed": int(rng.integers(1, 1 << 40)), "ranges": [(0, size), (cut[0], cut[1])],
                       "abundance": (1 << 64) - 1, "compact_exchange": trial % 3 != 2,  # both the exact-size and the equal-block exchange
+                      "fused_verify": trial % 2 == 0,  # the fused verification calls and the step-by-step ones
                       "options": {"slice_bits": slice_bits, "part_min_tiles": 1, "part_budget_bytes": int(rng.choice([40 << 30, 1 << 20]))}})
     results = run(specs, world, tmp_path)
     for sp, gathered in zip(specs, results):

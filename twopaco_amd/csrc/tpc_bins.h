@@ -56,6 +56,21 @@ __host__ __device__ __forceinline__ uint64_t pt_r1_recv(PtShard sh, uint32_t nb1
 // address belongs to another rank.
 __host__ __device__ __forceinline__ uint64_t pt_local_addr(const struct PtPerm &perm, PtShard sh, int log_nb2, uint64_t a_perm, bool &mine);
 
+// Densest level-1 bucket of the function-0 addresses relative to the mean: they are the smaller of two uniform values, density
+// 2 (1 - x) over the slices, and bucket b collects the slices slice_of((b << (F - b1)) | j) -- evenly mixed when there are many
+// slices per bucket, visibly not when there are few (F = 6: 8 slices per bucket).  Tight level-1 regions are sized for this bucket.
+inline double pt_bucket_peak(const PtPerm &pm, int F, int b1)
+{
+    const double S = (double)((uint64_t)1 << F);
+    double peak = 0;
+    for (uint32_t b = 0; b < (1u << b1); b++) {
+        double d = 0;
+        for (uint32_t j = 0; j < (1u << (F - b1)); j++) d += 2.0 * (1.0 - ((double)pm.slice_of((b << (F - b1)) | j) + 0.5) / S) / S;
+        peak = d > peak ? d : peak;
+    }
+    return peak * (double)(1u << b1);
+}
+
 inline PtPerm pt_make_perm(int slice_bits, int F)
 {
     PtPerm p;

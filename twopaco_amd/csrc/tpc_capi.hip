@@ -396,6 +396,7 @@ int tpc_ctx_create(int device, tpc_ctx **out)
     tpc_ctx *c = new tpc_ctx();
     c->device = device;
     c->dbg_ovf = getenv("TPC_DEBUG_OVF") != nullptr; c->dbg_phases = getenv("TPC_PROFILE_PHASES") != nullptr; c->dbg_timing = getenv("TWOPACO_TIMING") != nullptr; c->no_lean = getenv("TPC_NO_LEAN") != nullptr;
+    if (const char *e = getenv("TPC_SHARD_TIGHT")) c->opt_shard_tight = atoi(e) ? 1 : 0;  // measurements: the one-GPU region slack on a sharded context
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
     for (int i = 0; i < TPC_K_COUNT; i++) {
         if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { delete c; return -5; }

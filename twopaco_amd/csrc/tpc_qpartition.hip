@@ -1470,11 +1470,12 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
     const double avg1 = a_max * share1 / (double)(1 << pl.b1);
-    pl.cap1 = ((uint64_t)(tight ? avg1 * std::min(frac, 1.0) + 6 * std::sqrt(avg1 * std::min(frac, 1.0)) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;  // tight: as in tpc_part_plan_sharded
-    pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
-    pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
+    const double avg1t = avg1 * std::min(frac, 1.0) * pt_bucket_peak(pm, F, pl.b1);  // tight, as in tpc_part_plan_sharded: every query address is a function-0 address
+    pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
+    pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
+    pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
     // Region sizes of the LAST level: a region is one filter slice, and every query address is a function-0
     // address whose density over the slices falls linearly from 2x to 0 (tpc_bins.h).  With three levels the
     // middle regions each collect 2^b3 slices spread over the whole filter by the permutation: uniform.

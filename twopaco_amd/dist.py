@@ -427,7 +427,7 @@ class AddressSharded:
     Overflowing level-1 regions (skewed addresses) travel as an all-gathered list; beyond the
     list capacity the library fails loudly (there is no direct-kernel fallback on a sharded filter)."""
 
-    def __init__(self, ctx, dist, device, compact=None, configure=True):
+    def __init__(self, ctx, dist, device, compact=None, configure=True, fused=None):
         import torch
         self.ctx, self.torch = ctx, torch
         self.comm = _Comm(dist, device)
@@ -440,6 +440,8 @@ class AddressSharded:
             mode = os.environ.get("TPC_SHARD_EXCHANGE", "auto")
             compact = mode == "packed" or (mode == "auto" and self.comm.world >= 8)
         self.compact = bool(compact)
+        # fused: the verification's bookkeeping through the library's fused calls (_verify) or step by step (_verify_unfused)
+        self.fused = os.environ.get("TPC_VERIFY_FUSED", "1") != "0" if fused is None else bool(fused)
         self.device = device
         self.rank, self.world = self.comm.rank, self.comm.world
         if configure:  # False: the caller did it before tpc_seq_upload (needed for option text_window to take effect)
@@ -490,6 +492,7 @@ class AddressSharded:
         t0 = self._tick(tag + "_hash", t0)
         # one tiny all-reduce BEFORE anything moves: the largest overflow list of the batch and every rank's failure flag
         m = self.comm.max_ints([n_ovf])[0]
+        self.stats["overflow_entries"] = self.stats.get("overflow_entries", 0) + (n_ovf if n_ovf < (1 << 62) else 0)
         if m >= (1 << 62):
             raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
         recv_c = self.comm.a2a_equal(send_c)
@@ -560,6 +563,108 @@ class AddressSharded:
             return [(1, q - 1)]
         return [(1, 1), (2, q - 2)]
 
+    def _verify(self, b, n, t0):
+        """Survivors of batch b's first probe: home, verified against functions 1..q-1, marked -- through the library's fused calls
+        (tpc_shard_survivors_home / _verify_send / _finish).  Returns the survivor counts after every step."""
+        torch, ctx, W = self.torch, self.ctx, self.world
+        zeros = [0] * W
+        self.comm.phase = "query batch %d: survivors home" % b
+        # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
+        # their text is: a rank then needs only its own chunk of the packed text.  The library groups them by that rank.
+        home = self._buf("v_home", max(n, 1) * 8).view(torch.int64)
+        tmp = self._buf("v_tmp", max(n, 1) * 8 if W > 1 else 8).view(torch.int64)
+        counts = self._try(ctx.shard_survivors_home, tmp.data_ptr(), home.data_ptr(), W, default=zeros)
+        sid, _ = self.comm.a2a_var(home[:n], counts, out=self._out_buf("v_sid"))
+        self.comm.sync()
+        t0 = self._tick("query_survivors_home", t0)
+        trace = [n]
+        # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange -- or all at once (_verify_rounds)
+        rounds = self._verify_rounds(n)
+        for ri, (fn, cnt) in enumerate(rounds):
+            self.comm.phase = "query batch %d: probes of functions %d..%d" % (b, fn, fn + cnt - 1)
+            n = sid.numel()
+            # probe addresses in owner-major send order + the slot of every probe (answers come back in that order)
+            send = self._buf("v_send", max(n * cnt, 1) * 8).view(torch.int64)
+            tmp = self._buf("v_tmp", max(n * cnt, 1) * 8 if W > 1 else 8).view(torch.int64)
+            perm = self._buf("v_perm", max(n * cnt, 1) * 4 if W > 1 else 4).view(torch.int32)
+            counts = self._try(ctx.shard_verify_send, fn, cnt, sid.data_ptr(), n, tmp.data_ptr(), send.data_ptr(), perm.data_ptr(), W, default=zeros)
+            t0 = self._tick("query_verify_addrs_route", t0)
+            req, rcounts = self.comm.a2a_var(send[:n * cnt], counts, out=self._out_buf("v_req"))
+            hit = self._buf("v_hit", max(req.numel(), 1))
+            self.comm.sync()
+            t0 = self._tick("query_verify_all_to_all", t0)
+            self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
+            t0 = self._tick("query_verify_probe", t0)
+            back, _ = self.comm.a2a_var(hit[:req.numel()], rcounts, out=self._out_buf("v_back"))
+            self.comm.sync()
+            t0 = self._tick("query_verify_all_to_all", t0)
+            perm_ptr = perm.data_ptr() if W > 1 else 0  # one rank: natural order
+            if ri + 1 == len(rounds):  # the last round marks what passed
+                m = self._try(ctx.shard_finish, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr)
+                trace.append(m)
+                t0 = self._tick("query_verify_finish", t0)
+            else:
+                kept = self._buf("v_kept%d" % (ri & 1), max(n, 1) * 8).view(torch.int64)
+                m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr, kept.data_ptr())
+                sid = kept[:m]
+                trace.append(m)
+                t0 = self._tick("query_verify_select", t0)
+        if not rounds:  # a single hash function: the first probe was the only one
+            self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
+            t0 = self._tick("query_verify_finish", t0)
+        self.comm.sync()
+        return trace
+
+    def _verify_unfused(self, b, n, t0):
+        """The same protocol through the individual calls (tpc_shard_survivors, _survivor_sources, _route, _permute64, _verify_addrs,
+        _select, _mark) -- what a host written against them does; kept so that both forms stay under the parity tests."""
+        torch, ctx, W = self.torch, self.ctx, self.world
+        zeros = [0] * W
+        self.comm.phase = "query batch %d: survivors home" % b
+        sid = torch.empty(n, dtype=torch.int64, device=self.device)
+        self._try(ctx.shard_survivors, sid.data_ptr())
+        src = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self._try(ctx.shard_survivor_sources, sid.data_ptr(), n, src.data_ptr())
+        perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        counts = self._try(ctx.shard_route, src.data_ptr(), n, perm.data_ptr(), W, default=zeros)
+        send = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        self._try(ctx.shard_permute64, sid.data_ptr(), perm.data_ptr(), n, send.data_ptr())
+        sid, _ = self.comm.a2a_var(send[:n].contiguous(), counts)
+        sid = sid.contiguous()
+        self.comm.sync()
+        t0 = self._tick("query_survivors_home", t0)
+        trace = [n]
+        for fn, cnt in self._verify_rounds(n):
+            self.comm.phase = "query batch %d: probes of functions %d..%d" % (b, fn, fn + cnt - 1)
+            n = sid.numel()
+            addr = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
+            owner = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
+            self._try(ctx.shard_verify_addrs, fn, cnt, sid.data_ptr(), n, addr.data_ptr(), owner.data_ptr())
+            perm = torch.empty(n * cnt, dtype=torch.int32, device=self.device)
+            counts = self._try(ctx.shard_route, owner.data_ptr(), n * cnt, perm.data_ptr(), W, default=zeros)
+            send = torch.empty(n * cnt, dtype=torch.int64, device=self.device)
+            self._try(ctx.shard_permute64, addr.data_ptr(), perm.data_ptr(), n * cnt, send.data_ptr())
+            t0 = self._tick("query_verify_addrs_route", t0)
+            req, rcounts = self.comm.a2a_var(send, counts)
+            hit = torch.empty(req.numel(), dtype=torch.uint8, device=self.device)
+            self.comm.sync()
+            t0 = self._tick("query_verify_all_to_all", t0)
+            self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
+            t0 = self._tick("query_verify_probe", t0)
+            back, _ = self.comm.a2a_var(hit, rcounts)
+            back = back.contiguous()
+            kept = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+            self.comm.sync()
+            t0 = self._tick("query_verify_all_to_all", t0)
+            m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm.data_ptr(), kept.data_ptr())
+            sid = kept[:m].contiguous()
+            trace.append(sid.numel())
+            t0 = self._tick("query_verify_select", t0)
+        self.comm.sync()
+        self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
+        self._tick("query_verify_finish", t0)
+        return trace
+
     def query(self, lo=0, hi=None, union=True):
         """union = False: every rank keeps only the marks of the positions it hashed (for the key-sharded second pass)."""
         torch, ctx, W = self.torch, self.ctx, self.world
@@ -573,51 +678,7 @@ class AddressSharded:
             t0 = time.perf_counter()
             n = self._apply(QUERY, b, x)
             t0 = self._tick("query_apply", t0)
-            self.comm.phase = "query batch %d: survivors home" % b
-            # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
-            # their text is: a rank then needs only its own chunk of the packed text.  The library groups them by that rank.
-            home = self._buf("v_home", max(n, 1) * 8).view(torch.int64)
-            tmp = self._buf("v_tmp", max(n, 1) * 8 if W > 1 else 8).view(torch.int64)
-            counts = self._try(ctx.shard_survivors_home, tmp.data_ptr(), home.data_ptr(), W, default=zeros)
-            sid, _ = self.comm.a2a_var(home[:n], counts, out=self._out_buf("v_sid"))
-            self.comm.sync()
-            t0 = self._tick("query_survivors_home", t0)
-            trace = [n]
-            # function 1 alone (drops the Bloom false positives), then functions 2..q-1 in one exchange -- or all at once (_verify_rounds)
-            rounds = self._verify_rounds(n)
-            for ri, (fn, cnt) in enumerate(rounds):
-                self.comm.phase = "query batch %d: probes of functions %d..%d" % (b, fn, fn + cnt - 1)
-                n = sid.numel()
-                # probe addresses in owner-major send order + the slot of every probe (answers come back in that order)
-                send = self._buf("v_send", max(n * cnt, 1) * 8).view(torch.int64)
-                tmp = self._buf("v_tmp", max(n * cnt, 1) * 8 if W > 1 else 8).view(torch.int64)
-                perm = self._buf("v_perm", max(n * cnt, 1) * 4 if W > 1 else 4).view(torch.int32)
-                counts = self._try(ctx.shard_verify_send, fn, cnt, sid.data_ptr(), n, tmp.data_ptr(), send.data_ptr(), perm.data_ptr(), W, default=zeros)
-                t0 = self._tick("query_verify_addrs_route", t0)
-                req, rcounts = self.comm.a2a_var(send[:n * cnt], counts, out=self._out_buf("v_req"))
-                hit = self._buf("v_hit", max(req.numel(), 1))
-                self.comm.sync()
-                t0 = self._tick("query_verify_all_to_all", t0)
-                self._try(ctx.shard_probe, req.data_ptr(), req.numel(), hit.data_ptr())
-                t0 = self._tick("query_verify_probe", t0)
-                back, _ = self.comm.a2a_var(hit[:req.numel()], rcounts, out=self._out_buf("v_back"))
-                self.comm.sync()
-                t0 = self._tick("query_verify_all_to_all", t0)
-                perm_ptr = perm.data_ptr() if W > 1 else 0  # one rank: natural order
-                if ri + 1 == len(rounds):  # the last round marks what passed
-                    m = self._try(ctx.shard_finish, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr)
-                    trace.append(m)
-                    t0 = self._tick("query_verify_finish", t0)
-                else:
-                    kept = self._buf("v_kept%d" % (ri & 1), max(n, 1) * 8).view(torch.int64)
-                    m = self._try(ctx.shard_select, sid.data_ptr(), n, cnt, back.data_ptr(), perm_ptr, kept.data_ptr())
-                    sid = kept[:m]
-                    trace.append(m)
-                    t0 = self._tick("query_verify_select", t0)
-            if not rounds:  # a single hash function: the first probe was the only one
-                self._try(ctx.shard_mark, sid.data_ptr(), sid.numel())
-                t0 = self._tick("query_verify_finish", t0)
-            self.comm.sync()
+            trace = (self._verify if self.fused else self._verify_unfused)(b, n, t0)
             survivors.append(trace)
             if len(trace) > 2 and not hasattr(self, "_fn1_pass_rate"):  # a lazy batch was measured: survivors of function 1 / first-probe survivors, all ranks
                 tot = self.comm.max_ints([trace[1], trace[0]])  # (max over ranks: a decision every rank takes alike)
@@ -879,6 +940,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         if which == "address":
             sh.t.clear()
             sh.stats["region_bytes_sent"] = 0
+            sh.stats["overflow_entries"] = 0
             moved0 = sh.comm.bytes_moved
         guarded("bench: barrier before the timed steps", dist.barrier)
         if ctx is not None:
@@ -905,7 +967,10 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
             r["region_bytes_sent"] = sh.stats.get("region_bytes_sent", 0) // args.steps
             # level-1 regions this rank SENT per second of all-to-all wall time (the exchange waits for every peer: a rate per
             # rank, what the link model of DESIGN.md section 5.2 assumed as 50 GB/s per link and direction)
-            r["all_to_all_GBs"] = r["region_bytes_sent"] * (world - 1) / max(world, 1) / max(a2a_s, 1e-9) / 1e9
+            r["all_to_all_GBs"] = r["region_bytes_sent"] / max(a2a_s, 1e-9) / 1e9  # (region_bytes_sent: what left this rank)
+            r["overflow_entries"] = sh.stats.get("overflow_entries", 0) // args.steps
+            r["exchange"] = "packed to exact sizes (tpc_shard_pack)" if sh.compact else "equal blocks of tight regions, own block in place"
+
             r["survivors"] = sh.stats.get("survivors")
         return r
 
@@ -961,7 +1026,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload_desc,
                    "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
-                   "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of packed level-1 regions per pass, per-function survivor probes; " % world) +
+                   "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of the level-1 regions per pass, per-function survivor probes; " % world) +
                                   ({"records": "text sharded too; exact-filter table sharded by key hash ((key, prev|next) records to the key's owner), all_gather of the junction keys",
                                     "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
                                     "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
@@ -974,6 +1039,8 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         "exchange_bytes_rank0_per_step": head.get("exchange_bytes"),
         "region_bytes_sent_rank0_per_step": head.get("region_bytes_sent"),
         "all_to_all_GBs_rank0": head.get("all_to_all_GBs"),
+        "region_exchange": head.get("exchange"),
+        "overflow_entries_rank0_per_step": head.get("overflow_entries"),
         "phase_ms_rank0_per_step": head.get("phase_ms"),
         "survivors_rank0": head.get("survivors"),
         "collective_timeout_s": wd.timeout,

@@ -464,35 +464,40 @@ namespace TwoPaCo
 					else if (!overflowFetched) LibCheck(r.ctx, tpc_shard_overflow_get(r.ctx, pass, mine, overflow), "shard_overflow_get");
 				}
 
-				char * gathered = static_cast<char*>(r.Ensure(OVF_ALL, size_t(W) * most * eb));
+				// the all-gathered blocks (each holds all[s] valid entries) in the first half, their valid prefixes back to back in the
+				// second (a compaction in place would copy between overlapping ranges)
+				char * gathered = static_cast<char*>(r.Ensure(OVF_ALL, 2 * size_t(W) * most * eb));
+				char * list = gathered + size_t(W) * most * eb;
 				net.AllGather(r.rank, mine, gathered, most * eb);
-				// compact the blocks (each holds all[s] valid entries) to the front of `gathered`
-				uint64_t total = all[0];
-				for (int s = 1; s < W; s++)
+				uint64_t total = 0;
+				for (int s = 0; s < W; s++)
 				{
-					if (all[s]) HipCheck(hipMemcpy(gathered + total * eb, gathered + size_t(s) * most * eb, all[s] * eb, hipMemcpyDeviceToDevice), "overflow compaction");
+					if (all[s]) HipCheck(hipMemcpy(list + total * eb, gathered + size_t(s) * most * eb, all[s] * eb, hipMemcpyDeviceToDevice), "overflow compaction");
 					total += all[s];
 				}
 
-				LibCheck(r.ctx, tpc_shard_overflow_set(r.ctx, pass, gathered, total), "shard_overflow_set");
+				LibCheck(r.ctx, tpc_shard_overflow_set(r.ctx, pass, list, total), "shard_overflow_set");
 			}
 
 			r.Phase("overflow lists");
 		}
 
-		// The survivors of the first probe (ids in r.buf[SID]) go back to the rank that hashed their position -- it rides in the id --
-		// so that they are verified where their text is.  Returns how many arrived here (ids in r.buf[SID]).
+		// The survivors of the last tpc_shard_apply go back to the rank that hashed their position -- it rides in the id -- so that they
+		// are verified where their text is (the library groups them by that rank).  Returns how many arrived here (ids in r.buf[SID]).
 		uint64_t ReturnSurvivors(ShardedRank & r, Transport & net, uint64_t n)
 		{
 			const int W = net.Ranks();
-			uint64_t * sid = static_cast<uint64_t*>(r.buf[SID]);
-			int32_t * source = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(n, 1) * 4));
-			LibCheck(r.ctx, tpc_shard_survivor_sources(r.ctx, sid, n, source), "shard_survivor_sources");
-			uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(n, 1) * 4));
-			uint64_t counts[64];
-			LibCheck(r.ctx, tpc_shard_route(r.ctx, source, n, perm, counts), "shard_route");
+			uint64_t * tmp = W > 1 ? static_cast<uint64_t*>(r.Ensure(MISC_A, std::max<uint64_t>(n, 1) * 8)) : 0;
 			uint64_t * send = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(n, 1) * 8));
-			LibCheck(r.ctx, tpc_shard_permute64(r.ctx, sid, perm, n, send), "shard_permute64");
+			uint64_t counts[64];
+			LibCheck(r.ctx, tpc_shard_survivors_home(r.ctx, tmp, send, counts), "shard_survivors_home");
+			if (W == 1)
+			{
+				std::swap(r.buf[SID], r.buf[MISC_B]);
+				std::swap(r.cap[SID], r.cap[MISC_B]);
+				return n;
+			}
+
 			std::vector<uint64_t> all;
 			net.ExchangeHost(r.rank, counts, W, all);
 			std::vector<uint64_t> recvCounts(W);
@@ -503,46 +508,59 @@ namespace TwoPaCo
 				arriving += recvCounts[s];
 			}
 
-			uint64_t * mine = static_cast<uint64_t*>(r.Ensure(SID2, std::max<uint64_t>(arriving, 1) * 8));
+			uint64_t * mine = static_cast<uint64_t*>(r.Ensure(SID, std::max<uint64_t>(arriving, 1) * 8));
 			net.AllToAllV(r.rank, send, counts, mine, recvCounts.data(), 8);
-			std::swap(r.buf[SID], r.buf[SID2]);
-			std::swap(r.cap[SID], r.cap[SID2]);
 			return arriving;
 		}
 
-		// Survivors of the first probe against functions fn .. fn+count-1; returns the number that passed (ids in r.buf[SID]).
-		uint64_t VerifyStep(ShardedRank & r, Transport & net, uint64_t n, int fn, int count)
+		// Survivors (ids in r.buf[SID]) against functions fn .. fn+count-1; returns the number that passed.  last: they are marked
+		// (tpc_shard_finish); otherwise their ids are left in r.buf[SID] for the next step.
+		uint64_t VerifyStep(ShardedRank & r, Transport & net, uint64_t n, int fn, int count, bool last)
 		{
 			const int W = net.Ranks();
 			const uint64_t items = n * uint64_t(count);
 			uint64_t * sid = static_cast<uint64_t*>(r.buf[SID]);
-			uint64_t * addr = static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(items, 1) * 8));
-			int32_t * owner = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(items, 1) * 4));
-			LibCheck(r.ctx, tpc_shard_verify_addrs(r.ctx, fn, count, sid, n, addr, owner), "shard_verify_addrs");
-			uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(items, 1) * 4));
-			uint64_t counts[64];
-			LibCheck(r.ctx, tpc_shard_route(r.ctx, owner, items, perm, counts), "shard_route");
+			// probe addresses in owner-major send order and the slot of every probe, from the library (one rank: the natural order)
+			uint64_t * tmp = W > 1 ? static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(items, 1) * 8)) : 0;
+			uint32_t * perm = W > 1 ? static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(items, 1) * 4)) : 0;
 			uint64_t * sendAddr = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(items, 1) * 8));
-			LibCheck(r.ctx, tpc_shard_permute64(r.ctx, addr, perm, items, sendAddr), "shard_permute64");
-			std::vector<uint64_t> all;
-			net.ExchangeHost(r.rank, counts, W, all);
-			std::vector<uint64_t> recvCounts(W);
-			uint64_t asked = 0;
-			for (int s = 0; s < W; s++)
+			uint64_t counts[64];
+			LibCheck(r.ctx, tpc_shard_verify_send(r.ctx, fn, count, sid, n, tmp, sendAddr, perm, counts), "shard_verify_send");
+			uint8_t * back = 0;
+			if (W == 1)
 			{
-				recvCounts[s] = all[size_t(s) * W + r.rank];
-				asked += recvCounts[s];
+				back = static_cast<uint8_t*>(r.Ensure(OWNER, std::max<uint64_t>(items, 1)));
+				LibCheck(r.ctx, tpc_shard_probe(r.ctx, sendAddr, items, back), "shard_probe");
+			}
+			else
+			{
+				std::vector<uint64_t> all;
+				net.ExchangeHost(r.rank, counts, W, all);
+				std::vector<uint64_t> recvCounts(W);
+				uint64_t asked = 0;
+				for (int s = 0; s < W; s++)
+				{
+					recvCounts[s] = all[size_t(s) * W + r.rank];
+					asked += recvCounts[s];
+				}
+
+				// requests in (ADDR: the tagged addresses are no longer needed), answers out
+				uint64_t * req = static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(std::max(asked, items), 1) * 8));
+				net.AllToAllV(r.rank, sendAddr, counts, req, recvCounts.data(), 8);
+				uint8_t * answers = static_cast<uint8_t*>(r.Ensure(OWNER, std::max<uint64_t>(std::max(asked, items * 4), 1)));
+				LibCheck(r.ctx, tpc_shard_probe(r.ctx, req, asked, answers), "shard_probe");
+				back = static_cast<uint8_t*>(r.Ensure(MISC_B, std::max<uint64_t>(items * 8, 1)));
+				net.AllToAllV(r.rank, answers, recvCounts.data(), back, counts, 1);
 			}
 
-			// requests in (reuse ADDR: the unpermuted addresses are no longer needed), answers out
-			uint64_t * req = static_cast<uint64_t*>(r.Ensure(ADDR, std::max<uint64_t>(std::max(asked, items), 1) * 8));
-			net.AllToAllV(r.rank, sendAddr, counts, req, recvCounts.data(), 8);
-			uint8_t * answers = static_cast<uint8_t*>(r.Ensure(OWNER, std::max<uint64_t>(std::max(asked, items * 4), 1)));
-			LibCheck(r.ctx, tpc_shard_probe(r.ctx, req, asked, answers), "shard_probe");
-			uint8_t * back = static_cast<uint8_t*>(r.Ensure(MISC_B, std::max<uint64_t>(items * 8, 1)));
-			net.AllToAllV(r.rank, answers, recvCounts.data(), back, counts, 1);
-			uint64_t * kept = static_cast<uint64_t*>(r.Ensure(SID2, std::max<uint64_t>(n, 1) * 8));
 			uint64_t m = 0;
+			if (last)
+			{
+				LibCheck(r.ctx, tpc_shard_finish(r.ctx, sid, n, count, back, perm, &m), "shard_finish");
+				return m;
+			}
+
+			uint64_t * kept = static_cast<uint64_t*>(r.Ensure(SID2, std::max<uint64_t>(n, 1) * 8));
 			LibCheck(r.ctx, tpc_shard_select(r.ctx, sid, n, count, back, perm, kept, &m), "shard_select");
 			std::swap(r.buf[SID], r.buf[SID2]);
 			std::swap(r.cap[SID], r.cap[SID2]);
@@ -674,8 +692,6 @@ namespace TwoPaCo
 		void VerifyBatch(ShardedRank & r, Transport & net, int hashFunctions, uint64_t n)
 		{
 			const int W = net.Ranks();
-			r.Ensure(SID, std::max<uint64_t>(n, 1) * 8);
-			LibCheck(r.ctx, tpc_shard_survivors(r.ctx, static_cast<uint64_t*>(r.buf[SID])), "shard_survivors");
 			n = ReturnSurvivors(r, net, n);
 			r.Phase("survivors home");
 			// Lazy: function 1 alone first (it rejects all but a fill-rate share of the Bloom false positives), then the rest together --
@@ -692,12 +708,12 @@ namespace TwoPaCo
 
 			if (hashFunctions == 2 || (hashFunctions > 2 && r.verifyEager == 1))
 			{
-				n = VerifyStep(r, net, n, 1, hashFunctions - 1);
+				n = VerifyStep(r, net, n, 1, hashFunctions - 1, true);
 			}
 			else if (hashFunctions > 2)
 			{
 				const uint64_t before = n;
-				n = VerifyStep(r, net, n, 1, 1);
+				n = VerifyStep(r, net, n, 1, 1, false);
 				if (r.verifyEager < 0)
 				{
 					const uint64_t mine[2] = { n, before };
@@ -708,10 +724,10 @@ namespace TwoPaCo
 					if (asked > 0) r.verifyEager = passed * 2 > asked ? 1 : 0;
 				}
 
-				n = VerifyStep(r, net, n, 2, hashFunctions - 2);
+				n = VerifyStep(r, net, n, 2, hashFunctions - 2, true);
 			}
 
-			LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");
+			if (hashFunctions < 2) LibCheck(r.ctx, tpc_shard_mark(r.ctx, static_cast<uint64_t*>(r.buf[SID]), n), "shard_mark");  // (the first probe was the only one)
 			r.Phase("verify + mark");
 		}
 
