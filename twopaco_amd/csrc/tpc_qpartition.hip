@@ -643,6 +643,11 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------ C'
+// (Round 4 also measured a persistent form of this kernel -- one workgroup per CU taking slices from a counter and issuing the next
+//  slice's insert loads before it sorts and appends the survivors of the one at hand, so that no CU waits out a launch, a region
+//  count and a first round trip per 450 KB slice: 11.16 ms for k_q_split + this kernel against 11.0 as one short workgroup per
+//  slice.  The hardware already overlaps the end of one workgroup with the start of the next; the kernel runs at what HBM gives
+//  a two-reads-to-one-write mix.)
 // Fused k_part_apply + k_q_lookup (tpc_partition.hip: deferred apply).  When the insert and the query of a round both
 // fit one tile batch, the workgroup that builds a filter slice in LDS from the insert's level-2 entries writes it out
 // AND tests the query's entries of that slice on the spot: the 2^L / 8 bytes of the filter are not read back.
