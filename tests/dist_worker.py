@@ -155,11 +155,21 @@ def comm_worker(rank, world, port, result_path, p2p=False):
     # larger equal blocks of 8-byte elements with distinct values: (rank, destination, index)
     big = torch.stack([torch.arange(40, dtype=torch.int64) + 1000 * d + 100000 * rank for d in range(world)]).reshape(-1)
     out["equal_big"] = comm.a2a_equal(big).tolist()
+    # the same with the own block left where it is (tpc_shard_apply_inplace reads it from the send buffer): block `rank` of the result is undefined
+    if world > 1:
+        skipped = comm.a2a_equal(big, skip_self=True).reshape(world, -1)
+        out["equal_skip"] = [skipped[s].tolist() for s in range(world) if s != rank]
+    else:
+        out["equal_skip"] = []
     # variable counts well beyond one chunk: rank r sends 7 r + 3 d elements to d
     bc = [7 * rank + 3 * d for d in range(world)]
     bsend = torch.cat([torch.arange(c, dtype=torch.int64) + 1000 * d + 100000 * rank for d, c in enumerate(bc)] + [torch.zeros(0, dtype=torch.int64)])
     brecv, brc = comm.a2a_var(bsend, bc)
     out["var_big"] = (brecv.tolist(), brc)
+    # ... received into a buffer the caller provides (the send/recv form only; AddressSharded._out_buf)
+    held = torch.full((4096,), -1, dtype=torch.int64)
+    brecv2, _ = comm.a2a_var(bsend, bc, out=lambda n, dt: held.view(dt)[:n])
+    out["var_out"] = (brecv2.tolist(), (brecv2.data_ptr() == held.data_ptr()) if p2p else None)
     # variable: rank r sends (r + d) % 3 elements to d, values 100 r + d
     counts = [(rank + d) % 3 for d in range(world)]
     send = torch.cat([torch.full((c,), 100 * rank + d, dtype=torch.int64) for d, c in enumerate(counts)] + [torch.zeros(0, dtype=torch.int64)])

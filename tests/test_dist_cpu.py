@@ -91,7 +91,9 @@ def test_address_sharded_collectives(world, tmp_path, p2p=False):
     for r in range(world):
         assert got[r]["equal"] == [16 * s + r for s in range(world) for _ in range(5)]
         assert got[r]["equal_big"] == [i + 1000 * r + 100000 * s for s in range(world) for i in range(40)]
+        assert got[r]["equal_skip"] == [[i + 1000 * r + 100000 * s for i in range(40)] for s in range(world) if s != r]
         assert got[r]["var_big"] == ([i + 1000 * r + 100000 * s for s in range(world) for i in range(7 * s + 3 * r)], [7 * s + 3 * r for s in range(world)])
+        assert got[r]["var_out"] == (got[r]["var_big"][0], True if p2p else None)
         want, rc = [], []
         for s in range(world):
             c = (s + r) % 3

@@ -335,7 +335,7 @@ class _Comm:
             return out, rcl
         # RCCL: grouped send/recv, at most CHUNK bytes per peer and message
         send = self._in(send)
-        r = out(sum(rcl), send.dtype) if out is not None and self.direct else torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
+        r = out(sum(rcl), send.dtype) if out is not None else torch.empty(sum(rcl), dtype=send.dtype, device=send.device)
         step = max(1, self.CHUNK // send.element_size())
         so, ro = [0], [0]
         for p in range(self.world):
