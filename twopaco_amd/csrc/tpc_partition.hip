@@ -705,16 +705,19 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // a workgroup takes ceil(pairs / nwg1) tile pairs: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t pairs = (pl.n_tiles + 1) / 2, pairs_wg = (pairs + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)(2 * pairs_wg) / (double)std::max<uint64_t>(pl.n_tiles, 1));
-    const double avg1 = a_max * share1 / (double)(1 << pl.b1);
+    // a gated round (frac < 1: only edges touching the round's vertex-hash range are inserted) fills that share of every region: sized for it,
+    // a multi-round pass over a huge filter takes half the batches -- and every batch after the first sweeps the whole filter
+    const double a_exp = a_max * std::min(1.0, std::max(frac, 1.0 / 64));
+    const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
     // tight: the densest bucket's expectation (one of the q addresses of an edge is a function-0 address: pt_bucket_peak), the gate's share
-    const double avg1t = avg1 * std::min(frac, 1.0) * (1.0 + (pt_bucket_peak(pm, F, pl.b1) - 1.0) / q);
+    const double avg1t = avg1 * (1.0 + (pt_bucket_peak(pm, F, pl.b1) - 1.0) / q);
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
-    const double avg2 = a_max * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
+    const double avg2 = a_exp * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     pl.wpb3 = 1;
-    const double avg3 = a_max * world / ((double)(1ull << F) * pl.wpb3);
+    const double avg3 = a_exp * world / ((double)(1ull << F) * pl.wpb3);
     pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
     return true;

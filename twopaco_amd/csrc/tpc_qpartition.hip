@@ -1474,10 +1474,11 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     // a workgroup takes ceil(n_tiles / nwg1) tiles: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
-    const double avg1 = a_max * share1 / (double)(1 << pl.b1);
+    const double a_exp = a_max * std::min(1.0, std::max(frac, 1.0 / 64));  // a gated round: the share of the vertices inside its range (as tpc_part_plan_sharded)
+    const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
-    const double avg1t = avg1 * std::min(frac, 1.0) * pt_bucket_peak(pm, F, pl.b1);  // tight, as in tpc_part_plan_sharded: every query address is a function-0 address
+    const double avg1t = avg1 * pt_bucket_peak(pm, F, pl.b1);  // tight, as in tpc_part_plan_sharded: every query address is a function-0 address
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
     pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
@@ -1501,7 +1502,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         return o;
     };
     const uint64_t nreg2 = (uint64_t)((1u << pl.b1) / world) * pl.wpb * (1u << pl.b2);  // local regions
-    const double avg2 = a_max * world / ((double)nreg2 * world);  // entries of all ranks over all regions
+    const double avg2 = a_exp * world / ((double)nreg2 * world);  // entries of all ranks over all regions
     pl.wpb3 = 1;
     pl.loads3 = pl.loads;
     if (pl.b3) {
@@ -1510,7 +1511,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         for (uint64_t r = 0; r <= nreg2; r++) pl.off2_host[r] = r * pl.cap2;
         pl.buf2_entries = nreg2 * pl.cap2;
         const uint64_t nreg3 = ((uint64_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / world;  // local regions
-        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_max / (double)nreg3, pl.b2);
+        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_exp / (double)nreg3, pl.b2);
         pl.loads3 = loads_for(pl.b3);
     } else {
         pl.cap2 = 0;
