@@ -153,7 +153,9 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
     def breakdown(ph):
         return {k: ph.get(v) for k, v in BREAKDOWN_KEYS if ph.get(v) is not None or k in ("exec_to_main_ms", "rounds_ms", "write_ms")}
 
-    return {"e2e_wall_s": med, "breakdown_ms": breakdown(order[len(order) // 2][1]), "e2e_wall_s_min": walls[0], "e2e_wall_s_p50": med, "e2e_wall_s_max": walls[-1],
+    detail = {k: v for k, v in order[len(order) // 2][1].items() if k.startswith("code object")}  # per translation unit, median run
+    detail["all runs"] = [ph.get("warm-up thread: code objects") for _, ph in order]
+    return {"e2e_wall_s": med, "breakdown_ms": breakdown(order[len(order) // 2][1]), "code_objects_ms": detail, "e2e_wall_s_min": walls[0], "e2e_wall_s_p50": med, "e2e_wall_s_max": walls[-1],
             "e2e_wall_s_all": walls, "slowest_run_breakdown_ms": breakdown(order[-1][1]), "settle_s_between_runs": settle_s,
             "e2e_junction_occurrences_per_sec": occ / med,
             "junction_occurrences": occ, "runs": runs, "host_threads": int(threads), "gpus": gpus,

@@ -453,13 +453,14 @@ int tpc_preload(int device)
 {   // needs no context and no stream (a second queue costs ~20 ms to create): attribute queries load the code objects
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return -10; }  // the error is this call's, not the next one's
     const bool timing = getenv("TWOPACO_TIMING") != nullptr;
-    // in the order a run needs them: partitioned insert, partitioned query, second pass, junction stream; last the direct
-    // kernels and the split pass (the largest object, and a one-round run on a large filter never launches them)
-    int (*const warm[5])() = { tpc_warm_partition, tpc_warm_qpartition, tpc_warm_pass2, tpc_warm_stream, tpc_warm_pass1 };
-    const char *const name[5] = { "partition", "qpartition", "pass2", "stream", "pass1" };
+    // in the order a run needs them: partitioned insert, partitioned query, second pass, junction stream.  Not the direct kernels
+    // and the split pass (tpc_pass1.hip: a one-round run on a large filter never launches them), nor the level-1 insert kernels of
+    // q != 5 (tpc_partition_q.o) or the long-key second pass: the runtime loads those when a run first launches one of them.
+    int (*const warm[4])() = { tpc_warm_partition, tpc_warm_qpartition, tpc_warm_pass2, tpc_warm_stream };
+    const char *const name[4] = { "partition", "qpartition", "pass2", "stream" };
     // one after the other: loading them from several host threads at once is no faster (the runtime serialises it) and was seen
     // to stall device allocations made meanwhile by ~0.5 s
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 4; i++) {
         const auto t0 = std::chrono::steady_clock::now();
         if (warm[i]() != 0) return -10;
         if (timing) fprintf(stderr, "[timing]     code object %s: %.1f ms\n", name[i], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

@@ -29,11 +29,22 @@
 #include <cstdlib>
 #include <cmath>
 
+// Two code objects from this file (as tpc_pass2.hip does): part 0 (tpc_partition.o) holds everything a run with the reference's
+// default of q = 5 hash functions launches; part 1 (-DTPC_PARTITION_PART=1 -> tpc_partition_q.o) only the level-1 hash kernels of
+// the other 15 values of q.  The runtime loads a code object when one of its kernels is first used: 240 kernel instantiations that
+// a q = 5 run never launches cost it ~15 ms of start-up (`code object partition` 23.8 -> ~5 ms of the CLI's 253 ms).
+#ifndef TPC_PARTITION_PART
+#define TPC_PARTITION_PART 0
+#endif
+
+#if TPC_PARTITION_PART == 0
 uint32_t tpc_test_sched_cap = 0;  // see tpc_bins.h:pt_schedule_dims
+#endif
+int tpc_launch_insert_part_hash_other_q(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers);  // part 1
 
 namespace {
 
-constexpr uint32_t PT_SENT = 0xFFFFFFFFu;
+[[maybe_unused]] constexpr uint32_t PT_SENT = 0xFFFFFFFFu;
 
 struct Overflow {
     uint64_t *list;
@@ -373,6 +384,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
     }
 }
 
+#if TPC_PARTITION_PART == 0
 // ------------------------------------------------------------------------------------------ level 2
 constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips better than 8
 template <bool SHARDED>
@@ -512,6 +524,8 @@ __global__ void k_part_ovf(const uint64_t *__restrict__ list, const unsigned lon
     }
 }
 
+#endif  // part 0
+
 template <int Q>
 int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_t lo, uint64_t hi, unsigned long long *n_kmers)
 {
@@ -555,6 +569,7 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     }
 }
 
+#if TPC_PARTITION_PART == 0
 // entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the < 32 leftovers per bin
 int split_loads(int bits)
 {
@@ -652,8 +667,10 @@ __global__ void __launch_bounds__(256) k_region_pack(const uint4 *__restrict__ r
     for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
 }
 
+#endif  // part 0
 }  // namespace
 
+#if TPC_PARTITION_PART == 0
 // Partition geometry for a filter of 2^L bits: slices of 2^slice_bits bits, fan-out split over two
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels)
@@ -732,30 +749,11 @@ size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.
 
 int tpc_launch_insert_part_hash(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
 {
-    switch (a.P.q) {
+    if (a.P.q == 5) return launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers);
 #ifdef TPC_DEV_Q5  // development builds: one instantiation
-    case 5: return launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers);
-    default: return -1;
-    }
-#else
-    case 1: return launch_hash_q<1>(a, pl, gated, lo, hi, n_kmers);
-    case 2: return launch_hash_q<2>(a, pl, gated, lo, hi, n_kmers);
-    case 3: return launch_hash_q<3>(a, pl, gated, lo, hi, n_kmers);
-    case 4: return launch_hash_q<4>(a, pl, gated, lo, hi, n_kmers);
-    case 5: return launch_hash_q<5>(a, pl, gated, lo, hi, n_kmers);
-    case 6: return launch_hash_q<6>(a, pl, gated, lo, hi, n_kmers);
-    case 7: return launch_hash_q<7>(a, pl, gated, lo, hi, n_kmers);
-    case 8: return launch_hash_q<8>(a, pl, gated, lo, hi, n_kmers);
-    case 9: return launch_hash_q<9>(a, pl, gated, lo, hi, n_kmers);
-    case 10: return launch_hash_q<10>(a, pl, gated, lo, hi, n_kmers);
-    case 11: return launch_hash_q<11>(a, pl, gated, lo, hi, n_kmers);
-    case 12: return launch_hash_q<12>(a, pl, gated, lo, hi, n_kmers);
-    case 13: return launch_hash_q<13>(a, pl, gated, lo, hi, n_kmers);
-    case 14: return launch_hash_q<14>(a, pl, gated, lo, hi, n_kmers);
-    case 15: return launch_hash_q<15>(a, pl, gated, lo, hi, n_kmers);
-    case 16: return launch_hash_q<16>(a, pl, gated, lo, hi, n_kmers);
-    }
     return -1;
+#else
+    return tpc_launch_insert_part_hash_other_q(a, pl, lo, hi, gated, n_kmers);  // its own code object (part 1)
 #endif
 }
 
@@ -828,3 +826,28 @@ int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n
     if (n) hipLaunchKernelGGL(k_ovf_scatter, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, off, cursor, sorted);
     return 0;
 }
+#endif  // part 0
+
+#if TPC_PARTITION_PART == 1
+int tpc_launch_insert_part_hash_other_q(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers)
+{
+    switch (a.P.q) {
+    case 1: return launch_hash_q<1>(a, pl, gated, lo, hi, n_kmers);
+    case 2: return launch_hash_q<2>(a, pl, gated, lo, hi, n_kmers);
+    case 3: return launch_hash_q<3>(a, pl, gated, lo, hi, n_kmers);
+    case 4: return launch_hash_q<4>(a, pl, gated, lo, hi, n_kmers);
+    case 6: return launch_hash_q<6>(a, pl, gated, lo, hi, n_kmers);
+    case 7: return launch_hash_q<7>(a, pl, gated, lo, hi, n_kmers);
+    case 8: return launch_hash_q<8>(a, pl, gated, lo, hi, n_kmers);
+    case 9: return launch_hash_q<9>(a, pl, gated, lo, hi, n_kmers);
+    case 10: return launch_hash_q<10>(a, pl, gated, lo, hi, n_kmers);
+    case 11: return launch_hash_q<11>(a, pl, gated, lo, hi, n_kmers);
+    case 12: return launch_hash_q<12>(a, pl, gated, lo, hi, n_kmers);
+    case 13: return launch_hash_q<13>(a, pl, gated, lo, hi, n_kmers);
+    case 14: return launch_hash_q<14>(a, pl, gated, lo, hi, n_kmers);
+    case 15: return launch_hash_q<15>(a, pl, gated, lo, hi, n_kmers);
+    case 16: return launch_hash_q<16>(a, pl, gated, lo, hi, n_kmers);
+    }
+    return -1;
+}
+#endif  // part 1
