@@ -399,7 +399,8 @@ namespace TwoPaCo
 		void Exchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, void * sendR, void * sendC, uint64_t overflow, bool overflowFetched)
 		{
 			const int W = net.Ranks();
-			void * recvR = r.Ensure(RECV_R, size_t(W) * geom[2]);
+			// (one rank, unpacked: nothing moves and tpc_shard_apply_inplace reads the send buffers -- no receive buffer for the regions)
+			void * recvR = (W > 1 || r.compactExchange) ? r.Ensure(RECV_R, size_t(W) * geom[2]) : 0;
 			void * recvC = r.Ensure(RECV_C, size_t(W) * geom[3]);
 			net.AllToAll(r.rank, sendC, recvC, geom[3]);
 			r.Phase("exchange counts");
