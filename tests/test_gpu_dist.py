@@ -43,6 +43,29 @@ def test_bench_single_rank_over_rccl(decomposition):
     assert dist_line["result"]["candidate_marks"] == single["result"]["candidate_marks"]
 
 
+def test_bench_auto_headline_is_the_faster_of_the_two_decompositions():
+    """Below eight ranks `--decomposition auto` times both decompositions; the line's value is the faster one's, the other keeps its
+    record under its own name, and both carry the same (reference) counters."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("TPC_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
+                          "--no-cpu-baseline", "--e2e-runs", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    head = line["config"]["decomposition"]
+    other = {"address": "ranges", "ranges": "address"}[head]
+    assert other in line and head not in line
+    assert line["value"] >= line[other]["value"] > 0 and line["ms_per_step"] <= line[other]["ms_per_step"]
+    assert line["result"] == line[other]["result"] and line["result"]["junctions"] > 0
+    if head == "ranges":
+        assert "phase_ms_rank0_per_step" in line["address"] and "headline" in line["config"]
+
+
 def test_bench_address_path_full_size_over_rccl():
     """The address decomposition at the bench's full size (62 x 5 Mbp, f=36) with one RCCL rank: the 8.6 GB and 19 GB exchange
     buffers cross `_Comm` in 256 MiB messages (a single multi-GiB all_to_all_single arrived truncated here), and the counters
