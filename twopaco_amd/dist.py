@@ -848,7 +848,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     """bench.py --gpus N under torch.distributed.run: strong scaling of the same workload, one process per GPU over RCCL.
 
     The north star's decomposition -- the Bloom filter sharded by bit address, all-to-all of the level-1 regions per pass -- is timed at
-    every N that is a power of two; below 8 GPUs the vertex-hash-range decomposition (no data-path exchange) is timed as well, the
+    every N that is a power of two; the vertex-hash-range decomposition (no data-path exchange) is timed as well, the
     line's value is the FASTER of the two and the other one keeps its full record under its own name ("address" / "ranges"):
     routing every hash hit to its owner pays where the links outnumber the work, which by the link model is not at two ranks
     (DESIGN.md section 6).  `--decomposition address|ranges` pins one.
@@ -870,7 +870,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     if decomposition == "auto":
         decomposition = "address" if pow2 and not injected else "ranges"
     address = decomposition == "address"
-    also_ranges = address and world < 8 and getattr(args, "decomposition", "auto") == "auto"
+    also_ranges = address and getattr(args, "decomposition", "auto") == "auto"  # both are timed at every N; the line's value is the faster one's
     ctx = ctx_r = None
     sharded2 = False
     recs = None
@@ -1056,7 +1056,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         if second["dt"] < dt:
             # Both decompositions were timed and checked at this N; the line's value is the faster one's and the other keeps its full
             # record under its own name.  (Routing every hash hit to its owner pays where the links outnumber the work: by the link
-            # model of DESIGN.md section 6 it is a slowdown at two ranks and break-even at four; at eight only it is timed.)
+            # model of DESIGN.md section 6 it is a slowdown at two ranks and break-even at four.)
             moved = ("value", "ms_per_step", "junction_occurrences_per_sec", "kernel_ms_rank0", "roofline", "exchange_bytes_rank0_per_step",
                      "region_bytes_sent_rank0_per_step", "all_to_all_GBs_rank0", "region_exchange", "overflow_entries_rank0_per_step",
                      "phase_ms_rank0_per_step", "survivors_rank0", "result")
