@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 
 struct tpc_ctx {
     int device = 0;
@@ -937,12 +938,46 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             for (int i = 0; i < 64; i++) { tot += sc[i]; most = std::max(most, sc[i]); }
             fprintf(stderr, "[ovf] query: %llu overflow entries (cap %llu, flag %llu), survivors %llu (fullest list %llu of %llu, flag %llu) b1=%d b2=%d ppr=%d loads=%d\n", f1[0],
                     (unsigned long long)pl.ovf_cap, f1[1], tot, most, (unsigned long long)pl.surv_cap, f2, pl.b1, pl.b2, pl.pos_per_round, pl.loads);
+            if (getenv("TPC_DEBUG_OVF_REGIONS") && f1[0]) {  // where the overflow entries go: (permuted) slice histogram of the list
+                const size_t n = (size_t)std::min<unsigned long long>(f1[0], 1u << 22);
+                std::vector<uint64_t> ent(2 * n);
+                (void)hipMemcpy(ent.data(), pl.ovf, 2 * n * 8, hipMemcpyDeviceToHost);
+                std::map<uint32_t, uint32_t> h;
+                std::map<uint64_t, uint32_t> ha;
+                for (size_t i = 0; i < n; i++) { h[(uint32_t)(ent[2 * i] >> pl.slice_bits)]++; ha[ent[2 * i]]++; }
+                std::vector<std::pair<uint32_t, uint32_t>> top;
+                for (auto &kv : h) top.push_back({kv.second, kv.first});
+                std::sort(top.rbegin(), top.rend());
+                fprintf(stderr, "[ovf]   %zu entries in %zu permuted slices, %zu distinct addresses; top:", n, h.size(), ha.size());
+                for (size_t i = 0; i < std::min<size_t>(top.size(), 10); i++) fprintf(stderr, " slice %u x %u;", top[i].second, top[i].first);
+                std::vector<std::pair<uint32_t, uint64_t>> topa;
+                for (auto &kv : ha) topa.push_back({kv.second, kv.first});
+                std::sort(topa.rbegin(), topa.rend());
+                for (size_t i = 0; i < std::min<size_t>(topa.size(), 6); i++) fprintf(stderr, " addr %llx x %u (edge %llu pos %llu);", (unsigned long long)topa[i].second, topa[i].first, 0ull, 0ull);
+                fprintf(stderr, "\n");
+            }
+            if (getenv("TPC_DEBUG_OVF_REGIONS") && !pl.b3) {  // which level-2 regions are full
+                const size_t nreg = pl.off2_host.size() - 1;
+                std::vector<uint32_t> cnt(nreg);
+                (void)hipMemcpy(cnt.data(), pl.cnt2, nreg * 4, hipMemcpyDeviceToHost);
+                const uint32_t smask = (1u << (pl.b1 + pl.b2)) - 1u;
+                size_t full = 0;
+                std::vector<uint32_t> hist(64, 0);
+                for (size_t r = 0; r < nreg; r++) {
+                    const uint64_t cap = pl.off2_host[r + 1] - pl.off2_host[r];
+                    const uint32_t s = (uint32_t)(((uint64_t)r * pl.perm_inv) & smask);  // PtPerm::slice_of
+                    if (cnt[r] + 16 >= cap) { full++; hist[s >> (pl.b1 + pl.b2 - 6)]++; if (full <= 12) fprintf(stderr, "[ovf]   region %zu (slice %u of %zu): %u of %llu\n", r, s, nreg, cnt[r], (unsigned long long)cap); }
+                }
+                fprintf(stderr, "[ovf]   %zu full regions; by 64ths of the address space:", full);
+                for (int i = 0; i < 64; i++) fprintf(stderr, " %u", hist[i]);
+                fprintf(stderr, "\n");
+            }
         }
         if (c->dbg_phases) {
             unsigned long long pr[32];
             (void)hipMemcpy(pr, pl.ovf_cur, sizeof pr, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu rounds %llu | hash: push %llu book %llu copy %llu rounds %llu (10 ns ticks summed over WGs)\n",
-                    pr[0], pr[8], pr[9], pr[10], pr[12], pr[16], pr[17], pr[18], pr[20]);
+            fprintf(stderr, "[phases] ovf=%llu  split: push %llu book %llu copy %llu rounds %llu | hash: push %llu book %llu copy %llu rounds %llu (10 ns ticks summed over WGs) | lost at level 1: %llu, at level 2/3: %llu\n",
+                    pr[0], pr[8], pr[9], pr[10], pr[12], pr[16], pr[17], pr[18], pr[20], pr[25], pr[27]);
         }
         if (!overflowed) {
             c->rmask_sums_valid = true;

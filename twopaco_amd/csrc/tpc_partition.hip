@@ -52,7 +52,12 @@ struct Overflow {
     uint64_t cap;
     __device__ __forceinline__ void push(uint64_t a) const
     {
-        const unsigned long long o = atomicAdd(cursor, 1ull);
+        const unsigned long long m = __ballot(1);  // one atomic per wave and call (same-address atomics serialise at ~12 ns each)
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, (int)leader, 64);
+        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
         if (o < cap) list[o] = a; else cursor[1] = 1ull;
     }
 };
@@ -724,7 +729,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     const double share1 = std::min(1.0, (double)(2 * pairs_wg) / (double)std::max<uint64_t>(pl.n_tiles, 1));
     // a gated round (frac < 1: only edges touching the round's vertex-hash range are inserted) fills that share of every region: sized for it,
     // a multi-round pass over a huge filter takes half the batches -- and every batch after the first sweeps the whole filter
-    const double a_exp = a_max * std::min(1.0, std::max(frac, 1.0 / 64));
+    const double a_exp = getenv("TPC_GATED_FULL_REGIONS") ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));
     const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;

@@ -45,7 +45,14 @@ struct QOverflow {  // entries that did not fit a region: {full address, survivo
 #ifdef TPC_PROFILE_PHASES
         atomicAdd(cursor + 24 + site, 1ull);
 #endif
-        const unsigned long long o = atomicAdd(cursor, 1ull);
+        // one atomic per wave and call, not per entry: a gated round concentrates the in-edges' addresses (vertex hash XOR a constant)
+        // in an eighth of the slices, whose regions then overflow by the million, and same-address atomics serialise at ~12 ns each
+        const unsigned long long m = __ballot(1);
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, (int)leader, 64);
+        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
         if (o < cap) { list[2 * o] = addr; list[2 * o + 1] = sid; } else cursor[1] = 1ull;
     }
 };
@@ -726,8 +733,14 @@ __global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long l
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         bool mine;
         const uint64_t a = pt_local_addr(perm, sh, log_nb2, list[2 * i], mine);  // entries of other ranks are routed by the host layer
-        if (mine && ((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u)) {
-            const unsigned long long o = atomicAdd(&surv_cur[0], 1ull);
+        const bool hit = mine && ((filter[a >> 5] >> ((uint32_t)a & 31u)) & 1u);
+        const unsigned long long m = __ballot(hit);  // one append per wave (every lane of a wave runs the same number of rounds but the last)
+        if (hit) {
+            const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&surv_cur[0], (unsigned long long)__popcll(m));
+            base = __shfl(base, (int)leader, 64);
+            const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
             if (o < surv_cap) surv[o] = list[2 * i + 1]; else surv_cur[QS_LISTS] = 1ull;
         }
     }
@@ -1470,11 +1483,20 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         return std::max(1, std::min(4, std::max(1, (1 << bits) * (c - 16) * 5 / 8) * 9 / 8 / QS_THREADS / 2));
     };
     pl.loads = loads_for(pl.b3 ? pl.b2 : pl.b1);
+    // A gated round is not uniform over the slices: the in-edge c + v of a vertex has the forward hash H(v) ^ const (cyclichash.h: hash_prepend),
+    // so the vertices of a hash range put their in-edges into the image of that range -- an eighth of the slices take ~2.5 x their
+    // share, the rings of those bins fill inside a round (waves wait for the owner's copy, then the entries are lost to the overflow
+    // list: 4.9 M of 232 M and an 11 ms k_q_split for one range of eight on the 62-genome workload).  Half a round's entries keeps the
+    // hot rings below their capacity.
+    // (a range of half the hash space -- two rounds, two ranks: frac 0.58 -- is mild: its hot half takes 1.5 x; from a third down it is not)
+    const bool gated_round = frac < 0.45;
+    if (gated_round) pl.loads = std::max(1, pl.loads / 2);
+    if (const char *e = getenv("TPC_GATED_LOADS")) { if (gated_round) pl.loads = std::max(1, std::min(4, atoi(e))); }  // measurements
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     // a workgroup takes ceil(n_tiles / nwg1) tiles: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
-    const double a_exp = a_max * std::min(1.0, std::max(frac, 1.0 / 64));  // a gated round: the share of the vertices inside its range (as tpc_part_plan_sharded)
+    const double a_exp = getenv("TPC_GATED_FULL_REGIONS") ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));  // a gated round: the share of the vertices inside its range (as tpc_part_plan_sharded)
     const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
@@ -1502,7 +1524,10 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         return o;
     };
     const uint64_t nreg2 = (uint64_t)((1u << pl.b1) / world) * pl.wpb * (1u << pl.b2);  // local regions
-    const double avg2 = a_exp * world / ((double)nreg2 * world);  // entries of all ranks over all regions
+    // ... but only at level 1, whose buckets mix the slices evenly: the slice regions of a gated round are sized for ALL the
+    // entries, because the round's hot slices (see pl.loads above) take ~2.5 x their share of what is there (sized for the share alone,
+    // the regions of one range of eight lost 25 M of 232 M entries to the overflow list)
+    const double avg2 = a_max * world / ((double)nreg2 * world);  // entries of all ranks over all regions
     pl.wpb3 = 1;
     pl.loads3 = pl.loads;
     if (pl.b3) {
@@ -1511,8 +1536,9 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         for (uint64_t r = 0; r <= nreg2; r++) pl.off2_host[r] = r * pl.cap2;
         pl.buf2_entries = nreg2 * pl.cap2;
         const uint64_t nreg3 = ((uint64_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / world;  // local regions
-        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_exp / (double)nreg3, pl.b2);
+        pl.buf3_entries = slice_table(pl.off3_host, nreg3, pl.b3, pl.wpb3, a_max / (double)nreg3, pl.b2);
         pl.loads3 = loads_for(pl.b3);
+        if (gated_round) pl.loads3 = std::max(1, pl.loads3 / 2);
     } else {
         pl.cap2 = 0;
         pl.buf2_entries = slice_table(pl.off2_host, nreg2, pl.b2, pl.wpb, avg2, 0);
