@@ -52,12 +52,7 @@ struct Overflow {
     uint64_t cap;
     __device__ __forceinline__ void push(uint64_t a) const
     {
-        const unsigned long long m = __ballot(1);  // one atomic per wave and call (same-address atomics serialise at ~12 ns each)
-        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, (int)leader, 64);
-        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long o = atomicAdd(cursor, 1ull);
         if (o < cap) list[o] = a; else cursor[1] = 1ull;
     }
 };

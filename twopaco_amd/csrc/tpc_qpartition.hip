@@ -45,14 +45,10 @@ struct QOverflow {  // entries that did not fit a region: {full address, survivo
 #ifdef TPC_PROFILE_PHASES
         atomicAdd(cursor + 24 + site, 1ull);
 #endif
-        // one atomic per wave and call, not per entry: a gated round concentrates the in-edges' addresses (vertex hash XOR a constant)
-        // in an eighth of the slices, whose regions then overflow by the million, and same-address atomics serialise at ~12 ns each
-        const unsigned long long m = __ballot(1);
-        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, (int)leader, 64);
-        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        // (one atomic per wave instead of per entry was measured here when gated rounds lost entries by the million: the appends were
+        //  not what took the time -- the full rings were, see pl.loads -- and the ballot in this rarely taken path cost the split
+        //  kernels 0.2 ms of registers and code on the ungated workload)
+        const unsigned long long o = atomicAdd(cursor, 1ull);
         if (o < cap) { list[2 * o] = addr; list[2 * o + 1] = sid; } else cursor[1] = 1ull;
     }
 };
