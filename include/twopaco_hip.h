@@ -367,7 +367,7 @@ int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);
  * "insert_batches" / "query_batches" = tile batches; "filter2_retries" = exact-filter passes repeated
- * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "pbuf_releases" = times a second-pass or output allocation did not fit beside the first pass' partition buffers, which were then freed (the next first pass allocates them again); "round_marks" = candidate marks of the round the last
+ * with the full-size table by the last tpc_pass2_filter; "text_words" = packed words of the text held (a window with option text_window); "fused_lookups" = queries that built the filter slices themselves (deferred apply); "query_overflow_entries" = entries the last batch of the last partitioned query handed to its overflow list (full rings or regions: address skew); "pbuf_releases" = times a second-pass or output allocation did not fit beside the first pass' partition buffers, which were then freed (the next first pass allocates them again); "round_marks" = candidate marks of the round the last
  * tpc_pass2_filter consumed (what tpc_pass1_query reports; the sharded first pass has no single call that does);
  * "device_free_bytes" / "device_total_bytes" = hipMemGetInfo of the context's device, now.
  * -1: unknown name. */

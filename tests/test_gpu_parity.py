@@ -1162,3 +1162,36 @@ def test_randomized_differential_vs_oracle(capi, tmp_path):
         assert e.vertices_count() == len(o.keys)
         e.close()
         o.close()
+
+
+def test_gated_rounds_keep_their_entries_in_the_regions():
+    """A gated round is skewed: the in-edge c + v of a vertex hashes to H(v) ^ const (cyclichash.h:112-121, hash_prepend), so the vertices of
+    a hash range put their in-edges into the XOR image of that range and an eighth of the slices take ~2.5 x their share.  With a full
+    round of entries per flush the rings of those bins filled inside a round of k_q_split and the entries went to the overflow list
+    by the million (one range of eight on the 62-genome workload: 4.9 M of 232 M, k_q_split 11 ms instead of 0.7).  Every range of
+    eight now keeps the list to a handful (TPC_GATED_LOADS=4 restores the old round and fails this test with 0.5 M lost entries in one range)."""
+    from twopaco_amd import capi, synth
+    from twopaco_amd.dist import vertex_hash_ranges
+    recs, p = synth.workload("m2")  # full size: a level-1 region must hold more than one round of entries for the rings to fill
+    ctx = capi.Context(0)
+    ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=20240229))
+    ctx.seq_upload(capi.PackedText.from_codes(recs))
+    n = synth.n_kmers(recs, p["k"])
+
+    def round_(lo, hi):
+        ctx.run_begin()
+        ctx.filter_reset()
+        ctx.pass1_insert(lo, hi, count=False)
+        marks = ctx.pass1_query(lo, hi)
+        assert ctx.stat("query_path") == 2  # the partitioned query, no fallback
+        return marks, ctx.stat("query_overflow_entries")
+
+    whole, _ = round_(0, (1 << p["L"]))
+    total = 0
+    for lo, hi in vertex_hash_ranges(p["L"], 8):
+        marks, lost = round_(lo, hi)
+        assert lost <= 6 * n / 8 * 1e-4, (lo, hi, lost)
+        total += marks
+    # (a range's filter holds only the edges touching the range: its Bloom false positives are a subset of the whole round's)
+    assert whole - 1000 <= total <= whole and whole > 0
+    ctx.close()

@@ -111,6 +111,7 @@ struct tpc_ctx {
     uint64_t *iovf_off = nullptr;         // [slices + 1]
     uint32_t iovf_slices = 0;
     int64_t stat_fused = 0;
+    int64_t stat_query_overflow = 0;  // entries the last partitioned query batch handed to its overflow list
     int64_t stat_pbuf_releases = 0;  // times the partition buffers were given back to let a second-pass allocation through
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
@@ -484,6 +485,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
+    if (!strcmp(name, "query_overflow_entries")) return c->stat_query_overflow;
     if (!strcmp(name, "pbuf_releases")) return c->stat_pbuf_releases;
     if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
     if (!strcmp(name, "device_free_bytes") || !strcmp(name, "device_total_bytes")) {  // hipMemGetInfo of the context's device, now
@@ -929,6 +931,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         int rc = read_counter(c, 1, &n);
         if (rc) return rc;
         overflowed = overflowed || f1[1] != 0 || f2 != 0;
+        c->stat_query_overflow = (int64_t)f1[0];
         c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (c->dbg_ovf) {
