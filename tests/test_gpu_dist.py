@@ -66,6 +66,32 @@ def test_bench_auto_headline_is_the_faster_of_the_two_decompositions():
         assert "phase_ms_rank0_per_step" in line["address"] and "headline" in line["config"]
 
 
+def test_bench_two_ranks_on_one_gpu_whole_line():
+    """`bench.py --gpus 2` as the driver starts it, with gloo standing in for RCCL and both ranks on GPU 0 (TPC_DIST_BACKEND=gloo): the launcher,
+    both decompositions at world 2 through the C-ABI (address: tight equal blocks with the own block in place, fused verification calls,
+    key-sharded second pass; ranges), the choice of the faster one, the other's record, one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPC_FORCE_DIST")}
+    env["TPC_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
+                          "--no-cpu-baseline", "--e2e-runs", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
+    head = line["config"]["decomposition"]
+    other = {"address": "ranges", "ranges": "address"}[head]
+    assert line["value"] >= line[other]["value"] > 0
+    assert line["result"] == line[other]["result"] and line["result"]["junctions"] > 0
+    addr = line if head == "address" else line["address"]
+    assert addr["region_exchange"].startswith("equal blocks") and addr["survivors_rank0"][0][0] > 0
+
+
 def test_bench_address_path_full_size_over_rccl():
     """The address decomposition at the bench's full size (62 x 5 Mbp, f=36) with one RCCL rank: the 8.6 GB and 19 GB exchange
     buffers cross `_Comm` in 256 MiB messages (a single multi-GiB all_to_all_single arrived truncated here), and the counters
