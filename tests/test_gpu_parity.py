@@ -400,6 +400,36 @@ def test_partitioned_query_adversarial_skew(capi, slice_bits):
     assert (masks[0][1] == masks[1][1]).all()
 
 
+@pytest.mark.parametrize("budget", [0, 160 << 20])
+def test_partitioned_query_long_regions(capi, budget):
+    """A small filter under a large text: 2^30 bits and 19 M positions put 110 K query entries into every slice, far beyond the 65536
+    at which a region flushes its staged survivors as it goes (k_q_lookup / k_apply_lookup: finish_with) -- without that the staging
+    area of 3072 overflows and every further survivor costs a same-address atomic (7 x 160 Mbp at f = 34: 75 ms per lookup instead of
+    8).  budget: one batch (the fused lookup) or three (k_q_lookup for the later ones).  Mask and count equal the direct kernels'."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m2", scale=0.0625)
+    text = capi.PackedText.from_codes(recs)
+    masks = []
+    for mode in (1, 2):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_option("query_mode", mode)
+        if budget and mode == 2:
+            ctx.set_option("part_budget_bytes", budget)
+            ctx.set_option("part_min_tiles", 1)
+        ctx.set_params(25, 30, 5, capi.seed_table(5, 30, seed=11))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        n = ctx.pass1_query()
+        if mode == 2:
+            assert ctx.stat("query_path") == 2 and (ctx.stat("query_batches") > 1) == bool(budget)
+        masks.append((n, ctx.mask_download(False)))
+        ctx.close()
+    assert masks[0][0] == masks[1][0] > 0
+    assert (masks[0][1] == masks[1][1]).all()
+
+
 @pytest.mark.parametrize("n", [3000, 3000000])
 def test_partitioned_insert_adversarial_skew(capi, n):
     """poly-A: every address lands in the same bins -> LDS bins and regions overflow -> overflow list

@@ -51,6 +51,9 @@ def run(text, args, mode, tab, ranges, fetch):
     ctx.set_option("query_mode", mode)
     if args.budget_gb:
         ctx.set_option("part_budget_bytes", int(args.budget_gb * (1 << 30)))
+    for kv in args.set:
+        name, value = kv.split("=")
+        ctx.set_option(name, int(value))
     ctx.set_params(args.k, args.L, args.q, tab)
     t0 = time.time()
     ctx.seq_upload(text)
@@ -282,6 +285,7 @@ def parser():
     ap.add_argument("--no-direct", action="store_true", help="skip the comparison run on the direct kernels")
     ap.add_argument("--sample", type=int, default=20000)
     ap.add_argument("--repeat", type=int, default=1, help="passes of the partitioned run on the same context; the last one is reported")
+    ap.add_argument("--set", action="append", default=[], help="name=value: tpc_set_option on both runs' contexts (e.g. survivor_fp_mode=0)")
     ap.add_argument("--json", default="")
     ap.add_argument("--force-mode", type=int, default=0, help="insert_mode / query_mode of the first run: 0 automatic, 2 the partitioned passes whatever the plan's own estimate says")
     ap.add_argument("--fasta-dir", default="", help="also write the genomes as FASTA files there and run them through CreateEnumerator (file size, counters, sha256 == the C-ABI stream)")

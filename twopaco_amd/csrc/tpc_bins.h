@@ -222,7 +222,30 @@ struct PtStream {
             if (i0 + 3 * STEP < n4) ld(b, i0 + 3 * STEP);
         }
     }
+    // the same with between() after every pair of batches (every branch is uniform: whole-workgroup work such as a flush may go there)
+    template <class F, class G>
+    __device__ __forceinline__ void finish_with(F f, G between)
+    {
+        if (n4 == 0) return;
+        for (uint32_t i0 = 0;; i0 += 2 * STEP) {
+            use(a, i0, f);
+            if (i0 + STEP >= n4) break;
+            if (i0 + 2 * STEP < n4) ld(a, i0 + 2 * STEP);
+            use(b, i0 + STEP, f);
+            if (i0 + 2 * STEP >= n4) break;
+            if (i0 + 3 * STEP < n4) ld(b, i0 + 3 * STEP);
+            between();
+        }
+    }
 };
+
+template <int THREADS, int UNR, class T, class F, class G>
+__device__ __forceinline__ void pt_stream_region_with(const T *__restrict__ src, uint32_t n, F f, G between)
+{   // pt_stream_region with between() run by the whole workgroup after every 2 x STEP x EPL entries (uniform: n is)
+    PtStream<THREADS, UNR, T> st;
+    st.begin(src, n);
+    st.finish_with(f, between);
+}
 
 template <int THREADS, int UNR, class T, class F>
 __device__ __forceinline__ void pt_stream_region(const T *__restrict__ src, uint32_t n, F f)

@@ -507,6 +507,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 // appended to sub-list (blockIdx % QS_LISTS) with one global atomic per flush.
 constexpr int QL_STAGE = 3072;
 constexpr int QL_BUCKETS = 1024;  // = PT_APPLY_THREADS: one counting-sort bucket per thread
+constexpr uint32_t QL_LONG_REGION = 65536;  // entries: regions beyond this flush the staged survivors as they go (see k_q_lookup)
 constexpr size_t QL_LDS = (size_t)QL_STAGE * 8 + (size_t)QL_BUCKETS * 4 + 128 + 64;  // staged ids (their bucket in the spare high bits) + histogram + scan scratch + control
 
 // Survivors of a slice's first probe, staged in LDS and appended to the workgroup's survivor sub-list GROUPED BY ADDRESS (round 4).
@@ -517,6 +518,10 @@ constexpr size_t QL_LDS = (size_t)QL_STAGE * 8 + (size_t)QL_BUCKETS * 4 + 128 + 
 // puts equal addresses next to each other, so the 64 lanes of a verifying wave ask for a handful of distinct filter words instead
 // of 4 x 64.  Nothing downstream depends on the order of a sub-list.  A staged entry is the 33-bit survivor id with its bucket
 // in bits 40..49 (no second array: the 32 KB beside a 128 KB slice hold 3072 entries, as before the grouping).
+// (Round 4 also built the counterpart for batches whose survivors are mostly Bloom false positives -- every survivor to the sub-list of
+//  its POSITION, the verifying workgroups walking the sub-lists one per XCD at a time so that the scattered text reads stay in that
+//  XCD's L2 -- and measured it on 7 x 160 Mbp at f = 34 (5.5 % fill, 0.33 survivors per position): k_q_verify2 7.5 -> 6.6 ms per
+//  batch, the query 70.0 -> 68.3 ms; not kept for 2 %.)
 struct SurvStage {
     static constexpr int ID_BITS = 40;
     uint64_t *sid;     // [QL_STAGE]
@@ -636,10 +641,16 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
-        pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, [&](uint64_t v) {
+        auto probe = [&](uint64_t v) {
             const uint32_t a = (uint32_t)v & slice_mask;
             if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
-        });
+        };
+        // A long region (a small filter under a large batch: 200 K entries per slice at f = 34 with 0.56 G positions) would fill the
+        // 3072-entry staging area many times over before its end, and every survivor beyond it costs a same-address global atomic
+        // (75 ms per lookup there instead of 8): such a region flushes the staging area every 8192 entries.  (Not the short ones: two
+        // barriers per 8192 entries would be ~5 % of a 28 K-entry slice of the 62-genome workload.)
+        if (n > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe, [&]() { st.maybe_flush(); });
+        else pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe);
         st.maybe_flush();
     }
     st.flush();
@@ -713,8 +724,14 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
             const uint32_t a = (uint32_t)v & slice_mask;
             if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
         };
-        if (j == 0) q0.finish(probe);
-        else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]), probe);
+        if (j == 0) {
+            if (q0.n > QL_LONG_REGION) q0.finish_with(probe, [&]() { st.maybe_flush(); });  // (uniform; see k_q_lookup)
+            else q0.finish(probe);
+        } else {
+            const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
+            if (nq > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe, [&]() { st.maybe_flush(); });
+            else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe);
+        }
         st.maybe_flush();
     }
     st.flush();
