@@ -16,6 +16,8 @@ names = ["insert", "query", "fused", "compact", "filter2", "scan2", "sort", "emi
 out = []
 for L in Ls:
     ctx = capi.Context(0)
+    for kv in [x for x in os.environ.get("TPC_SET", "").split(",") if x]:  # TPC_SET=name=value,...: tpc_set_option
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ctx.set_params(p["k"], L, p["q"], capi.seed_table(p["q"], L, seed=20240229))
     ctx.seq_upload(text)
 
