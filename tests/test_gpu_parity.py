@@ -400,6 +400,108 @@ def test_partitioned_query_adversarial_skew(capi, slice_bits):
     assert (masks[0][1] == masks[1][1]).all()
 
 
+@pytest.mark.parametrize("budget", [0, 3 << 20])
+def test_six_byte_query_entries_many_groups(capi, budget):
+    """The 48-bit level-2 query entries (tpc_qpart6.h) carry the low bits of a position; its GROUP is implicit in where the entry
+    lies in its region (zone boundaries + a parity bit).  Option test_q6_pb2 = 14 makes a group one tile of 16384 positions, so a
+    25-tile text crosses 24 boundaries -- with 8 level-2 workgroups per bucket (several regions per slice: the staged survivors are
+    resolved against the right region's boundaries) and, with the small budget, in several batches.  Mask and count equal the
+    oracle's; the 6-byte path did run."""
+    from twopaco_amd import synth
+    recs, _ = synth.workload("m1", scale=0.01)   # 8 x 50 kbp = 25 tiles of 16384 positions
+    text = capi.PackedText.from_codes(recs)
+    o = O.Oracle(25, 30, 5, O.seed_table(11, 5, 30))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    o.fill_only()
+    marks = o.check_only()
+    ctx = capi.Context(0)
+    try:
+        for opt, val in (("insert_mode", 2), ("query_mode", 2), ("test_q6_pb2", 14)):
+            ctx.set_option(opt, val)
+        if budget:
+            ctx.set_option("part_min_tiles", 1)
+            ctx.set_option("part_budget_bytes", budget)
+        ctx.set_params(25, 30, 5, capi.seed_table(5, 30, seed=11))
+        ctx.seq_upload(text)
+        ctx.filter_reset()
+        ctx.pass1_insert()
+        assert ctx.pass1_query() == marks
+        assert ctx.stat("query_path") == 2 and ctx.stat("query_entry_fmt") == 6
+        assert (ctx.stat("query_batches") > 1) == bool(budget)
+        assert (ctx.mask_download(False) == o.round_mask).all()
+        assert (ctx.filter_download() == o.filter).all()
+    finally:
+        ctx.set_option("test_q6_pb2", 0)
+        ctx.close()
+
+
+def test_six_byte_query_entries_skew_with_many_groups(capi):
+    """Repeats + poly-A under tile-sized groups: rings and regions of the 6-byte level 2 overflow while zones open and close, so
+    entries reach the overflow list through both of its doors (a full ring at the push, a full region at a flush) and their positions
+    are rebuilt from the zone at hand and the parity bit.  Result equals the direct kernel's."""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 700).astype(np.uint8)
+    recs = [np.tile(unit, 400), np.zeros(200000, dtype=np.uint8), np.concatenate([unit[:300], unit[350:]]), rng.integers(0, 4, 300000).astype(np.uint8)]
+    text = capi.PackedText.from_codes(recs)
+    masks = []
+    try:
+        for mode in (1, 2):
+            ctx = capi.Context(0)
+            ctx.set_option("insert_mode", mode)
+            ctx.set_option("query_mode", mode)
+            ctx.set_option("slice_bits", 16)
+            ctx.set_option("test_q6_pb2", 14)
+            ctx.set_params(25, 24, 5, capi.seed_table(5, 24, seed=3))
+            ctx.seq_upload(text)
+            ctx.filter_reset()
+            ctx.pass1_insert()
+            n = ctx.pass1_query()
+            if mode == 2:
+                assert ctx.stat("query_entry_fmt") == 6 and ctx.stat("query_path") in (2, 12)
+            masks.append((n, ctx.mask_download(False)))
+            ctx.close()
+    finally:
+        c2 = capi.Context(0)
+        c2.set_option("test_q6_pb2", 0)
+        c2.close()
+    assert masks[0][0] == masks[1][0] > 0
+    assert (masks[0][1] == masks[1][1]).all()
+
+
+@pytest.mark.parametrize("name,slice_bits", [("rand6_k9_q8", 9), ("rand6_k9_L33", 20), ("c2_k51_r2", 14), ("rand6_k25_q3", 12)])
+def test_insert_entries_of_24_bits(capi, tmp_path, name, slice_bits):
+    """Option insert_entry_fmt = 3: the level-2 insert entries as blocked lines of 40 x 24 bits (tpc_binsp.h:PFmt3; off by default,
+    the split kernel pays for the narrow LDS stores what the apply saves in bytes).  Same filter as the oracle's, with the apply on
+    its own and deferred into the query's lookup (k_apply_lookup6<true>), whole range and gated rounds."""
+    case = [c for c in CASES if c["name"] == name][0]
+    o = _oracle_for(case, tmp_path)
+    text = capi.PackedText.from_fasta(case_files(case, tmp_path))
+    ctx = capi.Context(0)
+    try:
+        for opt, val in (("insert_mode", 2), ("query_mode", 2), ("slice_bits", slice_bits), ("insert_entry_fmt", 3)):
+            ctx.set_option(opt, val)
+        ctx.set_params(case["k"], case["L"], case["q"], capi.seed_table(case["q"], case["L"], seed=case["seed"]))
+        ctx.seq_upload(text)
+        ranges = [(0, 1 << case["L"])] + [(r["low"], r["high"]) for r in case["rounds"] if case["n_rounds"] > 1]
+        for lo, hi in ranges:
+            o.fill_only(lo, hi)
+            marks = o.check_only(lo, hi)
+            ctx.filter_reset()
+            ctx.pass1_insert(lo, hi)
+            assert ctx.stat("insert_entry_fmt") == 3
+            assert (ctx.filter_download() == o.filter).all(), (name, lo, hi)   # the apply on its own
+            ctx.filter_reset()
+            ctx.pass1_insert(lo, hi)
+            assert ctx.pass1_query(lo, hi) == marks                            # the apply inside the query's lookup
+            assert (ctx.mask_download(False) == o.round_mask).all(), (name, lo, hi)
+            assert (ctx.filter_download() == o.filter).all(), (name, lo, hi)
+    finally:
+        ctx.set_option("insert_entry_fmt", 0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("budget", [0, 160 << 20])
 def test_partitioned_query_long_regions(capi, budget):
     """A small filter under a large text: 2^30 bits and 19 M positions put 110 K query entries into every slice, far beyond the 65536

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -Itwopaco_amd/csrc -Iinclude tools/bins_bench.hip -o tools/bins_bench
 #include "tpc_rbins.h"
 #include "tpc_bins3.h"
+#include "tpc_binsp.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -292,8 +293,129 @@ int run3(const char *name, int log_nb, int steps, int ppr, int filler)
     return 0;
 }
 
+// BinsP (tpc_binsp.h): planar lines of 21 x 48-bit / 42 x 24-bit entries
+template <class F> __device__ __forceinline__ typename F::T make_pval(uint32_t r, uint32_t id);
+template <> __device__ __forceinline__ uint64_t make_pval<PFmt6>(uint32_t r, uint32_t id) { return ((uint64_t)(id & 0xFFFFFu) << 28) | (r & 0x0FFFFFFFu); }
+template <> __device__ __forceinline__ uint32_t make_pval<PFmt3>(uint32_t r, uint32_t) { return r & 0xFFFFFFu; }
+
+template <class F, int N, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_binsp(int LOG_NB, int steps, int ppr, int filler, unsigned char *buf, uint32_t *cnt, uint64_t cap_lines, unsigned long long *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using T = typename F::T;
+    const int NB = 1 << LOG_NB;
+    const uint32_t wg = blockIdx.x;
+    unsigned lost_n = 0;
+    auto lost = [&lost_n](uint32_t, T) { lost_n++; };
+    uint32_t rng = (blockIdx.x * THREADS + threadIdx.x) * 2654435761u + 12345u;
+    unsigned long long sum = 0;
+    BinsP<F, THREADS> bins;
+    bins.carve(smem, LOG_NB);
+    bins.init(buf, [=](uint32_t b) { return make_uint2((uint32_t)(((uint64_t)wg * NB + b) * cap_lines), (uint32_t)cap_lines); });
+    __syncthreads();
+    for (int s0 = 0; s0 < steps; s0 += ppr) {
+        for (int s = s0; s < min(steps, s0 + ppr); s++) {
+            uint32_t b[N];
+            T val[N];
+            bool ok[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                uint32_t r = lcg(rng);
+                for (int f = 0; f < (filler >= 1000 ? 0 : filler); f++) r = r * 1664525u + (r >> 13);
+                b[i] = ((r ^ (r >> 15)) * 0x2c1b3c6du >> 12) & (uint32_t)(NB - 1);
+                if (filler >= 1000 && ((s >> 4) & 1)) b[i] = (uint32_t)((i * 5 + (s >> 5)) % 3) & (uint32_t)(NB - 1);
+                val[i] = make_pval<F>(r, (uint32_t)s);
+                ok[i] = true;
+                sum += (unsigned long long)val[i] ^ ((unsigned long long)b[i] << 50);
+            }
+            bins.template push_batch<N>(b, val, ok, lost);
+        }
+        bins.template flush<false>(lost);
+    }
+    bins.template flush<true>(lost);
+    bins.store_counts(cnt + (uint64_t)wg * NB, [](uint32_t b) { return b; });
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[0], sum);
+    if (lost_n) atomicAdd(&sums[2], (unsigned long long)lost_n);
+}
+
+template <class F>
+__global__ void k_check_p(const unsigned char *buf, const uint32_t *cnt, uint64_t cap_lines, int NB, unsigned long long *sums)
+{   // one workgroup per region
+    const uint64_t r = blockIdx.x;
+    const uint32_t b = (uint32_t)(r % NB);
+    const uint32_t n = cnt[r];
+    unsigned long long sum = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t line = i / F::GROUP, e = i % F::GROUP;
+        const typename F::T v = F::load(buf + (r * cap_lines + line) * 128, e);
+        sum += (unsigned long long)v ^ ((unsigned long long)b << 50); c++;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); c += __shfl_down(c, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[1], sum); atomicAdd(&sums[4], c); }
+}
+
+template <class F, int N>
+int runp(const char *name, int log_nb, int steps, int ppr, int filler)
+{
+    constexpr int THREADS = 1024;
+    const int nwg = 256, NB = 1 << log_nb;
+    const uint64_t per_bin = (uint64_t)steps * THREADS * N / NB;
+    const uint64_t cap_lines = ((uint64_t)(per_bin * 1.2) + 256) / F::GROUP + 1;
+    unsigned char *buf; uint32_t *cnt; unsigned long long *sums;
+    CK(hipMalloc(&buf, (size_t)nwg * NB * cap_lines * 128));
+    CK(hipMalloc(&cnt, (size_t)nwg * NB * 4));
+    CK(hipMalloc(&sums, 256));
+    const size_t lds = BinsP<F, THREADS>::lds_bytes(log_nb);
+    CK(hipFuncSetAttribute((const void *)k_binsp<F, N, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemset(sums, 0, 256));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_binsp<F, N, THREADS>), dim3(nwg), dim3(THREADS), lds, 0, log_nb, steps, ppr, filler, buf, cnt, cap_lines, sums);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    hipLaunchKernelGGL((k_check_p<F>), dim3(nwg * NB), dim3(256), 0, 0, buf, cnt, cap_lines, NB, sums);
+    unsigned long long h[32];
+    CK(hipMemcpy(h, sums, 256, hipMemcpyDeviceToHost));
+    const double n = (double)nwg * THREADS * steps * N;
+    printf("%-28s NB %3d N %d ppr %d filler %2d: %8.3f ms %8.1f G entries/s %6.2f TB/s written   %s (entries %.0f, found %llu, lost %llu)\n", name, NB, N, ppr, filler, ms,
+           n / ms / 1e6, n * 128.0 / F::GROUP / ms / 1e9, (h[0] == h[1] + 0 && h[4] + h[2] == (unsigned long long)n) ? (h[2] ? "count OK (some lost)" : "OK") : "MISMATCH", n, h[4], h[2]);
+    CK(hipFree(buf)); CK(hipFree(cnt)); CK(hipFree(sums));
+    return 0;
+}
+
 int main()
 {
+    if (getenv("BINSP_ONLY")) {
+        for (int filler : {0, 40}) {
+            run3<uint64_t, 6>("Bins3 u64", 8, 1184, 1, filler);
+            runp<PFmt6, 6>("BinsP 48-bit", 8, 1184, 1, filler);
+            run3<uint32_t, 5>("Bins3 u32", 8, 1184, 3, filler);
+            runp<PFmt3, 5>("BinsP 24-bit ppr 3", 8, 1184, 3, filler);
+            runp<PFmt3, 5>("BinsP 24-bit ppr 4", 8, 1184, 4, filler);
+        }
+        run3<uint64_t, 4>("Bins3 u64 split-like", 8, 1776, 1, 0);
+        runp<PFmt6, 4>("BinsP 48-bit split-like", 8, 1776, 1, 0);
+        runp<PFmt6, 5>("BinsP 48-bit split-like N5", 8, 1420, 1, 0);
+        run3<uint32_t, 8>("Bins3 u32 split-like N8x2", 8, 1184, 2, 0);
+        runp<PFmt3, 8>("BinsP 24-bit split-like N8x2", 8, 1184, 2, 0);
+        runp<PFmt3, 8>("BinsP 24-bit split-like N8x3", 8, 1184, 3, 0);
+        run3<uint64_t, 6>("Bins3 u64 512 bins", 9, 1184, 1, 0);
+        runp<PFmt6, 6>("BinsP 48-bit 512 bins", 9, 1184, 1, 0);
+        runp<PFmt6, 3>("BinsP 48-bit 512 bins N3", 9, 2368, 1, 0);
+        runp<PFmt6, 4>("BinsP 48-bit 512 bins N4", 9, 1776, 1, 0);
+        runp<PFmt6, 6>("BinsP 48-bit 64 bins", 6, 1184, 1, 0);
+        runp<PFmt6, 6>("BinsP 48-bit 16 bins ppr4", 4, 1184, 4, 0);
+        runp<PFmt3, 5>("BinsP 24-bit 16 bins ppr8", 4, 1184, 8, 0);
+        runp<PFmt6, 6>("BinsP 48-bit 64 bins skew", 6, 1184, 1, 1000);
+        runp<PFmt3, 5>("BinsP 24-bit 512 bins", 9, 1184, 1, 0);
+        return 0;
+    }
     if (getenv("BINS3_ONLY")) {
         for (int filler : {0, 40}) {
             run<uint64_t, 6, false>("Bins  u64 (flush/round)", 8, 1184, 1, filler);

@@ -83,7 +83,7 @@ struct tpc_ctx {
     int opt_slice_bits = 20;
     // partitioned insert
     bool filter_zero_pending = false;  // filter_reset requested, not yet materialised
-    static constexpr int NPBUF = 18;  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3; sharded contexts: 12 / 13 the insert's APPLY-side overflow list + cursor, 14 / 15 the query's hash-side list, 16 / 17 its apply-side list (sh_ovf)
+    static constexpr int NPBUF = 19;  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3; sharded contexts: 12 / 13 the insert's APPLY-side overflow list + cursor, 14 / 15 the query's hash-side list, 16 / 17 its apply-side list (sh_ovf); 18 the group boundaries of the 6-byte query (tpc_qpart6.h)
     void *pbuf[NPBUF] = {};   // shared by insert and query
     size_t pbytes[NPBUF] = {};
     std::vector<uint64_t> off2_uploaded, off3_uploaded;   // region offset tables currently in pbuf[8] / pbuf[11]
@@ -92,6 +92,7 @@ struct tpc_ctx {
     // what the last insert / query actually ran (tpc_get_stat)
     int stat_path[2] = {0, 0};       // 1 direct kernel, 2 / 3 partitioned with that many levels (+10: partitioned, then completed by the direct kernel)
     int64_t stat_batches[2] = {0, 0};
+    int stat_fmt[2] = {0, 0};        // entry format of the last partitioned insert (level 2: 0 = 32-bit, 3 = planar 24-bit) / query (0 = 8-byte, 6 = planar 48-bit)
     int64_t stat_filter2_retries = 0;  // exact-filter passes repeated with the full-size table (last tpc_pass2_filter)
     int64_t opt_part_min_tiles = 256;  // never cut batches smaller than this many 512-word tiles
     int64_t opt_part_budget = 0;  // bytes of partition buffers per batch; 0 = automatic (part_budget())
@@ -444,6 +445,8 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "shard_tight_regions")) { c->opt_shard_tight = value ? 1 : 0; c->sh_have[0] = c->sh_have[1] = false; return 0; }
     if (!strcmp(name, "part_min_tiles")) { c->opt_part_min_tiles = value < 1 ? 1 : value; return 0; }
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
+    if (!strcmp(name, "test_q6_pb2")) { tpc_test_q6_pb2 = (int)value; return 0; }  // process-wide, tests only
+    if (!strcmp(name, "insert_entry_fmt")) { tpc_test_insert_p3 = value == 3; return 0; }  // process-wide; 3 = blocked 24-bit level-2 insert entries (off by default: tpc_partition.hip)
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
     if (!strcmp(name, "test_force_anyq")) { tpc_test_force_anyq = value != 0; return 0; }  // process-wide, tests only
@@ -481,6 +484,8 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!c || !name) return -1;
     if (!strcmp(name, "insert_path")) return c->stat_path[0];
     if (!strcmp(name, "query_path")) return c->stat_path[1];
+    if (!strcmp(name, "insert_entry_fmt")) return c->stat_fmt[0];
+    if (!strcmp(name, "query_entry_fmt")) return c->stat_fmt[1];
     if (!strcmp(name, "insert_batches")) return c->stat_batches[0];
     if (!strcmp(name, "query_batches")) return c->stat_batches[1];
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
@@ -657,7 +662,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         // deferred apply: the insert in one batch, the query partitioned with the same slice geometry (its FIRST batch then
         // builds the slices), and room for the insert's level-2 regions beside the query's buffers
         defer = part && c->opt_fuse && batches == 1 && qpart && pl.b3 == 0 && qpl.b3 == 0 && qpl.slice_bits == pl.slice_bits &&
-                qpl.b1 == pl.b1 && qpl.b2 == pl.b2;
+                qpl.b1 == pl.b1 && qpl.b2 == pl.b2 && (qpl.fmt == 6 || pl.fmt2 == 0);  // (the 8-byte lookup reads 32-bit insert entries only)
         if (defer) {
             const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
             for (int i = 0; i < 2 && defer; i++) {
@@ -736,6 +741,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                     pl.b2, pl.pos_per_round, (unsigned long long)pl.cap1, (unsigned long long)pl.cap2, pl.nwg1);
         overflowed = overflowed || ov[1] != 0;
         c->stat_path[0] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
+        c->stat_fmt[0] = pl.fmt2;
         c->stat_batches[0] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (!overflowed) {
             if (n_kmers) return read_counter(c, 0, n_kmers);
@@ -861,7 +867,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (qpart_need(pl, i)) part = ensure_pbuf(c, i, qpart_need(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
     const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
-                       pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2;
+                       pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2 && (pl.fmt == 6 || c->pending_pl.fmt2 == 0);
     if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     if (part) {
         pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
@@ -873,6 +879,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             c->off2_uploaded = pl.off2_host;
         }
         pl.buf3 = (uint64_t *)c->pbuf[0]; pl.cnt3 = (uint32_t *)c->pbuf[10]; pl.off3 = (const uint64_t *)c->pbuf[11];  // qpart_need
+        pl.bnd = (uint32_t *)c->pbuf[18];
         if (pl.b3 && c->off3_uploaded != pl.off3_host) {
             HIPCHK(c, hipMemcpy(c->pbuf[11], pl.off3_host.data(), pl.off3_host.size() * 8, hipMemcpyHostToDevice));
             c->off3_uploaded = pl.off3_host;
@@ -933,6 +940,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         overflowed = overflowed || f1[1] != 0 || f2 != 0;
         c->stat_query_overflow = (int64_t)f1[0];
         c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
+        c->stat_fmt[1] = pl.fmt;
         c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (c->dbg_ovf) {
             unsigned long long sc[65];
@@ -941,6 +949,17 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             for (int i = 0; i < 64; i++) { tot += sc[i]; most = std::max(most, sc[i]); }
             fprintf(stderr, "[ovf] query: %llu overflow entries (cap %llu, flag %llu), survivors %llu (fullest list %llu of %llu, flag %llu) b1=%d b2=%d ppr=%d loads=%d\n", f1[0],
                     (unsigned long long)pl.ovf_cap, f1[1], tot, most, (unsigned long long)pl.surv_cap, f2, pl.b1, pl.b2, pl.pos_per_round, pl.loads);
+            if (const char *path = getenv("TPC_DUMP_SURV")) {  // development: the first-probe survivors of the last batch, one id per line
+                if (FILE *fp = fopen(path, "w")) {
+                    for (int i = 0; i < 64; i++) {
+                        const size_t n = (size_t)std::min<unsigned long long>(sc[i], pl.surv_cap);
+                        std::vector<uint64_t> ids(n);
+                        if (n) (void)hipMemcpy(ids.data(), pl.surv + (size_t)i * pl.surv_cap, n * 8, hipMemcpyDeviceToHost);
+                        for (uint64_t v : ids) fprintf(fp, "%llu\n", (unsigned long long)v);
+                    }
+                    fclose(fp);
+                }
+            }
             if (getenv("TPC_DEBUG_OVF_REGIONS") && f1[0]) {  // where the overflow entries go: (permuted) slice histogram of the list
                 const size_t n = (size_t)std::min<unsigned long long>(f1[0], 1u << 22);
                 std::vector<uint64_t> ent(2 * n);

@@ -38,8 +38,9 @@ struct TpcPartPlan {
     uint64_t tile0, n_tiles;  // 512-word tiles of the text handled by this batch
     uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
     uint32_t wpb3 = 1;    // level-3 workgroups per (b1, b2) bucket
-    uint64_t cap1, cap2;  // entries per private region (multiples of 32)
+    uint64_t cap1, cap2;  // entries per private region (multiples of 32; cap2 a multiple of 42 when fmt2 == 3)
     uint64_t cap3 = 0;
+    int fmt2 = 0;         // level-2 regions: 0 = 32-bit entries, 3 = planar lines of 42 x 24-bit entries (tpc_binsp.h:PFmt3)
     uint64_t ovf_cap;
     uint32_t *buf1, *cnt1, *buf2, *cnt2;
     uint32_t *buf3 = nullptr, *cnt3 = nullptr;
@@ -60,7 +61,8 @@ size_t tpc_part_buf2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl);
 size_t tpc_part_buf3_bytes(const TpcPartPlan &pl);
 size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl);
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels = 0, bool tight = false);
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels = 0, bool tight = false,
+                           bool packed = false);  // packed: the one-GPU passes may use the planar entry formats of tpc_binsp.h
 int tpc_launch_insert_partitioned(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, bool fresh,
                                   unsigned long long *n_kmers);
 // the two halves of the above, for the sharded path (an all_to_all of the level-1 regions sits between them)
@@ -101,11 +103,18 @@ struct TpcQPlan {
     const uint64_t *rown1 = nullptr;  // own block in place, as in TpcPartPlan
     const uint32_t *rowncnt1 = nullptr;
     bool group_survivors = true;      // the lookup appends its survivors grouped by address (tpc_qpartition.hip:SurvStage)
+    // fmt == 6 (round 5; one rank, two levels, 16..512 bins at level 2): the level-2 entries are 48 bits in blocked lines of 20
+    // (tpc_binsp.h:PFmt6, tpc_qpart6.h).  buf2 is addressed in 128-byte lines, off2_host counts lines, cnt2 is exact, `bnd` receives
+    // n_groups entry counts per level-2 region, and level 1 hashes contiguous blocks of tiles_per_wg tiles per workgroup.
+    int fmt = 0;
+    uint32_t tiles_per_wg = 0, n_groups = 0, pb2 = 0;  // pb2: position bits a level-2 entry carries (groups of 2^pb2 positions)
+    uint32_t *bnd = nullptr;
 };
 #define TPC_SURV_CUR_WORDS 72  // surv_cur: [0..63] sub-list cursors, [64] overflow flag
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels = 0);  // n_tiles: 512-word tiles per batch
-size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0, bool tight = false);
+size_t tpc_qpart_bytes(const TpcQPlan &pl, int which);  // 0 buf1, 1 cnt1, 2 buf2, 3 cnt2, 4 ovf, 5 ovf_cur, 6 surv, 7 surv_cur, 8 off2, 9 buf3, 10 cnt3, 11 off3, 18 bnd (fmt 6)
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels = 0, bool tight = false,
+                            bool packed = false);
 int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 // deferred apply: the insert stops after its level-2 binning (tpc_launch_insert_part_split), the query's lookup builds the slices itself
 int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl);   // level 2 (and 3) only
@@ -116,6 +125,8 @@ int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n
                             uint64_t *off, uint64_t *sorted);
 #define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
+extern int tpc_test_q6_pb2;          // tpc_qpartition.hip: option "test_q6_pb2" (tests: position bits of a 6-byte level-2 entry, to get many groups on small inputs; process-wide)
+extern int tpc_test_insert_p3;       // tpc_partition.hip: option "insert_entry_fmt" (3: the level-2 insert entries as blocked 24-bit lines; process-wide)
 extern uint32_t tpc_test_sched_cap;  // tpc_partition.hip: option "test_sched_cap" (tests: rounds per schedule segment of the split kernels)
 // compacted exchange of the sharded path: off[i] = entries before region i (off[n] = all of them), in 16-byte units of
 // `entry_bytes`-byte entries -- counts written by Bins are whole flush groups, so every region stays 128-byte aligned;

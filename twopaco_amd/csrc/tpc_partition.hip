@@ -22,10 +22,12 @@
 // HBM traffic per address: 4 B written + 4 B read per level, plus one sequential pass over the
 // filter -- versus one 64-byte read-for-ownership and write-back per address for the atomics.
 #include "tpc_bins3.h"
+#include "tpc_binsp.h"
 #include "tpc_lean.h"
 #include "tpc_insert_step.h"
 #include "tpc_internal.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <cmath>
 
@@ -39,6 +41,7 @@
 
 #if TPC_PARTITION_PART == 0
 uint32_t tpc_test_sched_cap = 0;  // see tpc_bins.h:pt_schedule_dims
+int tpc_test_insert_p3 = 0;       // option "insert_entry_fmt" = 3: 24-bit level-2 insert entries (tpc_part_plan_sharded)
 #endif
 int tpc_launch_insert_part_hash_other_q(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers);  // part 1
 
@@ -387,7 +390,10 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
 #if TPC_PARTITION_PART == 0
 // ------------------------------------------------------------------------------------------ level 2
 constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips better than 8
-template <bool SHARDED>
+// P3: the output regions are planar lines of 42 x 24-bit entries (tpc_binsp.h:PFmt3, round 5) instead of 32-bit entries -- the
+// last level's entries are slice offsets of at most 20 bits; 3.05 bytes each instead of 4 on this kernel's writes and the apply's reads.
+// cap2 is then a multiple of 42 and the buffer is addressed in 128-byte lines.
+template <bool SHARDED, bool P3>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
              uint64_t cap1, uint32_t *buf2, uint32_t *cnt2, uint64_t cap2, Overflow ovf, PtShard sh, uint32_t prev_wpb, int log_prev_nb2, int loads,
@@ -397,7 +403,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
     constexpr int LOADS = 16;  // upper bound; `loads` of them are used
-    Bins3<uint32_t, PS_THREADS> bins;
+    typename std::conditional<P3, BinsP<PFmt3, PS_THREADS>, Bins3<uint32_t, PS_THREADS>>::type bins;
     unsigned char *s_free = bins.carve(smem, LOG_NB2);
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
     // global bucket: a sharded rank numbers its buckets compactly (bl = b1 / world); at the third level bl = (local b1, b2)
@@ -414,8 +420,13 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
     auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
     {
-        const uint64_t first = (uint64_t)blockIdx.x * NB2 * cap2;  // this workgroup's regions in buf2, entries
-        bins.init(buf2, [first, cap2](uint32_t b) { return make_uint2((uint32_t)((first + (uint64_t)b * cap2) >> 5), (uint32_t)cap2); });
+        if constexpr (P3) {
+            const uint32_t cl = (uint32_t)(cap2 / PFmt3::GROUP);  // lines per region
+            bins.init(buf2, [cl, NB2](uint32_t b) { return make_uint2((uint32_t)(((uint64_t)blockIdx.x * NB2 + b) * cl), cl); });
+        } else {
+            const uint64_t first = (uint64_t)blockIdx.x * NB2 * cap2;  // this workgroup's regions in buf2, entries
+            bins.init(buf2, [first, cap2](uint32_t b) { return make_uint2((uint32_t)((first + (uint64_t)b * cap2) >> 5), (uint32_t)cap2); });
+        }
     }
     __syncthreads();
     // rounds of `loads` x PS_THREADS entries over the regions (w, b1), w = j, j + wpb, ..., taken from the round schedule;
@@ -481,6 +492,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
 
 // ------------------------------------------------------------------------------------------ level 3
 // One workgroup per 2^slice_bits-bit slice of the filter.
+template <bool P3>  // the regions are planar lines of 42 x 24-bit entries (see k_part_split)
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
              uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm, PtShard sh)
@@ -504,6 +516,11 @@ k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restri
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+        if constexpr (P3) {
+            PlStream<PFmt3, PT_APPLY_THREADS, 1> is;
+            is.begin(reinterpret_cast<const unsigned char *>(buf2) + r * (cap2 / PFmt3::GROUP) * PT_LINE, n);
+            is.finish([slice](uint32_t v, uint32_t) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+        } else
         pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + r * cap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
     }
     __syncthreads();
@@ -570,38 +587,44 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
 }
 
 #if TPC_PARTITION_PART == 0
-// entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the < 32 leftovers per bin
-int split_loads(int bits)
+// entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the leftovers (< one line) per bin
+int split_loads(int bits, bool p3 = false)
 {
-    const int cap = (PT_BIN_BYTES / 4) >> bits;
-    return std::max(1, std::min(14, (1 << bits) * std::max(cap - 32, 4) * 5 / 8 / PS_THREADS));
+    const int group = p3 ? PFmt3::GROUP : 32;
+    const int cap = p3 ? (int)BinsP<PFmt3, PS_THREADS>::cap_for(bits) : (PT_BIN_BYTES / 4) >> bits;
+    return std::max(1, std::min(p3 ? 16 : 14, (1 << bits) * std::max(cap - group, 4) * 5 / 8 / PS_THREADS));
 }
 
 int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
 {
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtShard sh{pl.rank, pl.world};
-    const size_t lds_base = Bins3<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3)) + 128;
+    const bool p3 = pl.fmt2 == 3;  // (two levels, one rank: tpc_part_plan_sharded)
+    const size_t lds_base = (p3 ? BinsP<PFmt3, PS_THREADS>::lds_bytes(pl.b2) : Bins3<uint32_t, PS_THREADS>::lds_bytes(std::max(pl.b2, pl.b3))) + 128;
     const dim3 grid((unsigned)(((1u << pl.b1) / pl.world) * pl.wpb));  // local buckets only
     const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
     uint32_t nreg_cap, sched_cap;
     size_t lds;
-    const int loads2 = split_loads(pl.b2);
+    const int loads2 = split_loads(pl.b2, p3);
     pt_schedule_dims(pl.nwg1 * pl.world, pl.wpb, pl.cap1, (uint32_t)loads2 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
     if (pl.world > 1) {
-        (void)hipFuncSetAttribute((const void *)k_part_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_part_split<true>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+        (void)hipFuncSetAttribute((const void *)k_part_split<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_part_split<true, false>), grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
                            pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1, pl.rown1, pl.rowncnt1);
+    } else if (p3) {
+        (void)hipFuncSetAttribute((const void *)k_part_split<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_part_split<false, true>), grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+                           pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     } else {
-        (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_part_split<false>, grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
+        (void)hipFuncSetAttribute((const void *)k_part_split<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_part_split<false, false>), grid, dim3(PS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, low_bits, pl.nwg1, pl.wpb, pl.rbuf1, pl.rcnt1,
                            pl.cap1, pl.buf2, pl.cnt2, pl.cap2, ovf, sh, 0u, 0, loads2, nreg_cap, sched_cap, pl.roff1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     }
     if (pl.b3) {  // third level: bucket (b1, b2), input = the regions written above
         const int loads3 = split_loads(pl.b3);
         pt_schedule_dims(pl.wpb, pl.wpb3, pl.cap2, (uint32_t)loads3 * PS_THREADS, lds_base, nreg_cap, sched_cap, lds);
-        (void)hipFuncSetAttribute((const void *)k_part_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_part_split<false>, dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
+        (void)hipFuncSetAttribute((const void *)k_part_split<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_part_split<false, false>), dim3((unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3)), dim3(PS_THREADS), lds, a.stream, pl.b1 + pl.b2, pl.b3, a.P.L,
                            pl.slice_bits, 0u, pl.wpb3, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.cap3, ovf, sh, pl.wpb, pl.b2, loads3, nreg_cap, sched_cap, (const uint64_t *)nullptr,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     }
@@ -675,13 +698,13 @@ __global__ void __launch_bounds__(256) k_region_pack(const uint4 *__restrict__ r
 // levels.  Returns false when the partitioned path does not apply (tiny filters: direct kernel).
 bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, TpcPartPlan &pl, int levels)
 {
-    return tpc_part_plan_sharded(L, q, slice_bits, n_tiles, frac, 0, 1, pl, levels);
+    return tpc_part_plan_sharded(L, q, slice_bits, n_tiles, frac, 0, 1, pl, levels, false, true);
 }
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions are sized for the entries of all ranks
 // tight: level-1 regions sized at the expected fill + 6 sigma instead of 1.3 x + 8 sigma -- the regions of a sharded pass travel
 // whole (equal-block all_to_all: no packing pass), so slack is wire bytes; what does not fit goes the overflow list's way
-bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight)
+bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight, bool packed)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
@@ -733,6 +756,15 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
     const double avg2 = a_exp * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
+    // the last level's entries as planar 24-bit lines (tpc_binsp.h): one rank, two levels, slice offsets of at most 20 bits, bins that
+    // do not span waves.  TPC_ENTRY_FMT=legacy (read once per process) keeps the 32-bit entries for A/B measurements.
+    // Measured on the 62-genome workload (profiles/r05d_*): the split kernel pays for the two narrow LDS stores per entry what the
+    // apply saves in bytes (k_part_split 2.40 -> 2.88 ms, the fused lookup 5.9 -> 5.7), so the format is OFF unless asked for
+    // (TPC_ENTRY_FMT=all, read once per process; the tests force it through option "insert_entry_fmt").
+    static const bool want_p3 = [] { const char *e = getenv("TPC_ENTRY_FMT"); return e && e[0] == 'a'; }();
+    const bool legacy_fmt = !(want_p3 || tpc_test_insert_p3);
+    pl.fmt2 = (packed && !legacy_fmt && world == 1 && !three && slice_bits <= 20 && pl.b2 >= 4 && pl.b2 <= 9) ? 3 : 0;
+    if (pl.fmt2 == 3) pl.cap2 = (pl.cap2 + PFmt3::GROUP - 1) / PFmt3::GROUP * PFmt3::GROUP;
     pl.wpb3 = 1;
     const double avg3 = a_exp * world / ((double)(1ull << F) * pl.wpb3);
     pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
@@ -742,7 +774,11 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
 
 size_t tpc_part_buf1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 4; }
 size_t tpc_part_cnt1_bytes(const TpcPartPlan &pl) { return (size_t)pl.nwg1 * (1u << pl.b1) * 4; }
-size_t tpc_part_buf2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * pl.cap2 * 4; }
+size_t tpc_part_buf2_bytes(const TpcPartPlan &pl)
+{
+    const size_t regions = (size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2);
+    return pl.fmt2 == 3 ? regions * (pl.cap2 / PFmt3::GROUP) * PT_LINE : regions * pl.cap2 * 4;
+}
 size_t tpc_part_cnt2_bytes(const TpcPartPlan &pl) { return ((size_t)((1u << pl.b1) / pl.world) * pl.wpb * (1u << pl.b2)) * 4; }
 size_t tpc_part_buf3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * pl.cap3 * 4 : 0; }
 size_t tpc_part_cnt3_bytes(const TpcPartPlan &pl) { return pl.b3 ? (((size_t)pl.wpb3 << (pl.b1 + pl.b2 + pl.b3)) / pl.world) * 4 : 0; }
@@ -763,14 +799,20 @@ int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl,
 {
     const size_t lds = (size_t)4 << (pl.slice_bits - 5);
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
-    (void)hipFuncSetAttribute((const void *)k_part_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const PtShard sh{pl.rank, pl.world};
-    if (pl.b3)  // regions of the third level: [(b1, b2)][j][b3]
-        hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
-                           pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh);
-    else
-        hipLaunchKernelGGL(k_part_apply, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+    if (pl.fmt2 == 3) {  // planar 24-bit regions (two levels, one rank)
+        (void)hipFuncSetAttribute((const void *)k_part_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_part_apply<true>, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
                            pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+    } else {
+        (void)hipFuncSetAttribute((const void *)k_part_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (pl.b3)  // regions of the third level: [(b1, b2)][j][b3]
+            hipLaunchKernelGGL(k_part_apply<false>, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+                               pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh);
+        else
+            hipLaunchKernelGGL(k_part_apply<false>, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                               pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+    }
     hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2 + pl.b3);
     return 0;
 }

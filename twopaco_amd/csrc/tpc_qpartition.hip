@@ -23,12 +23,16 @@
 // all q probes.  The mask is bit-identical to k_query's (tests/test_gpu_parity.py).
 #include "tpc_rbins.h"
 #include "tpc_bins3.h"
+#include "tpc_binsp.h"
 #include "tpc_lean.h"
 #include "tpc_internal.h"
 #include <algorithm>
 #include <type_traits>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
+
+int tpc_test_q6_pb2 = 0;  // option "test_q6_pb2" (tests)
 
 namespace {
 
@@ -248,8 +252,10 @@ __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
           const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round,
           uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
-          uint64_t gbase, uint32_t *__restrict__ rmask)
+          uint64_t gbase, uint32_t *__restrict__ rmask, uint32_t tiles_per_wg)
 {   // LHI: L > 32; L-bit values on two separate 32-bit registers (LeanV, tpc_lean.h: round 4)
+    // tiles_per_wg > 0: workgroup w takes the tiles [w T, (w + 1) T) of the batch instead of w, w + nwg, ...: its regions then hold
+    // ascending positions, which the 6-byte level-2 entries rely on (k_q_split<.., P6>)
     using V = LeanV<LHI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NB = 1 << LOG_NB;
@@ -293,7 +299,10 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
     const uint32_t ppr_mask = (uint32_t)pos_per_round - 1u;  // a power of two <= 16
     constexpr bool half_rounds = HALF;                       // 512 bins: see the push below
     const uint32_t p0 = 32u + tid * (uint32_t)QH_RUN;        // my first position, relative to the first staged word (the one before the tile)
-    for (uint64_t tile = tile0 + blockIdx.x; tile < tile0 + n_tiles; tile += gridDim.x) {
+    const uint64_t t_first = tile0 + (tiles_per_wg ? (uint64_t)blockIdx.x * tiles_per_wg : (uint64_t)blockIdx.x);
+    const uint64_t t_end = tiles_per_wg ? min(tile0 + n_tiles, t_first + tiles_per_wg) : tile0 + n_tiles;
+    const uint64_t t_step = tiles_per_wg ? 1u : gridDim.x;
+    for (uint64_t tile = t_first; tile < t_end; tile += t_step) {
         __syncthreads();
         const uint64_t wfirst = tile * PT_THREADS;
         for (int i = (int)tid; i < PT_THREADS + 1 + xw; i += QH_THREADS) {
@@ -404,24 +413,37 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
 
 // ------------------------------------------------------------------------------------------ B
 constexpr int QS_THREADS = 1024;  // split: 16 waves hide the LDS atomic round trips better than 8
-template <bool SHARDED, bool RB>
+// P6 (round 5, one rank, last level, flush-per-round bins): the OUTPUT regions are blocked lines of 20 x 48-bit entries (tpc_binsp.h:
+// PFmt6; off2 counts 128-byte lines, cnt2 is exact) instead of 8-byte entries:
+//     { slice offset S = slice_bits | edge 3 | low PB2 = 44 - S bits of the position | parity of the position's group }
+// The group -- the position's bits above PB2 -- is implicit in where the entry lies.  Level 1 hashed the text in contiguous blocks of
+// tiles_per_wg tiles per workgroup (k_q_hash2), this kernel streams the regions (w, b1) in ascending w and each region in the order
+// it was written, so the positions of the stream ascend region by region and a region spans at most two groups (the plan makes
+// sure of tiles_per_wg tiles <= 2^PB2 positions).  Before the first round of every region that may reach a group g not seen so far
+// the flush records how many entries each output region holds: bnd[g].  An entry at index i of its region then lies in zone
+// z = #{g >= 1 : bnd[g] <= i}, which holds entries of groups z - 1 and z only -- the parity bit says which (q6_sid).
+template <bool SHARDED, bool RB, bool P6 = false>
 __global__ void __launch_bounds__(QS_THREADS)
 k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t nwg1, uint32_t wpb, const uint64_t *__restrict__ buf1,
           const uint32_t *__restrict__ cnt1, uint64_t cap1, uint64_t *buf2, uint32_t *cnt2, const uint64_t *__restrict__ off2, QOverflow ovf,
           PtShard sh, uint32_t prev_wpb, int log_prev_nb2, uint32_t nreg_cap, uint32_t sched_cap, const uint64_t *__restrict__ off1,
-          const uint64_t *__restrict__ own1, const uint32_t *__restrict__ owncnt1)
+          const uint64_t *__restrict__ own1, const uint32_t *__restrict__ owncnt1, uint32_t *__restrict__ bnd = nullptr, uint32_t n_groups = 0,
+          uint32_t tiles_per_wg = 0, uint32_t batch_tiles = 0, uint32_t pb2 = 0)
 {   // own1 / owncnt1 (sharded, optional): the block of source rank == this rank is read from the send buffers it was hashed into
     // prev_wpb > 0 (three-level geometry): this bucket is (b1, b2) of an earlier k_q_split whose regions [b1][j][b2] are the input
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t NB1 = 1u << LOG_NB1, NB2 = 1u << LOG_NB2;
-    constexpr int LOADS = 4;
+    constexpr int LOADS = P6 ? 5 : 4;  // (6-byte entries: a ring holds 80 instead of 64)
     constexpr uint64_t SENT = ~0ull;
-    typename std::conditional<RB, RBins<uint64_t, QS_THREADS>, Bins3<uint64_t, QS_THREADS>>::type bins;  // RB: see k_q_hash
+    static_assert(!P6 || (!SHARDED && !RB), "the 6-byte output is the one-rank, flush-per-round form");
+    typename std::conditional<P6, BinsP<PFmt6, QS_THREADS>,
+                              typename std::conditional<RB, RBins<uint64_t, QS_THREADS>, Bins3<uint64_t, QS_THREADS>>::type>::type bins;  // RB: see k_q_hash
     uint64_t *s_off = reinterpret_cast<uint64_t *>(bins.carve(smem, LOG_NB2));  // [NB2 + 1] region offsets of this workgroup
     if constexpr (RB) bins.init();
     else {
         const uint64_t *o2 = off2 + (uint64_t)blockIdx.x * NB2;
-        bins.init(buf2, [o2](uint32_t b) { const uint64_t o = o2[b]; return make_uint2((uint32_t)(o >> 4), (uint32_t)(o2[b + 1] - o)); });
+        if constexpr (P6) bins.init(buf2, [o2](uint32_t b) { const uint64_t o = o2[b]; return make_uint2((uint32_t)o, (uint32_t)(o2[b + 1] - o)); });  // lines
+        else bins.init(buf2, [o2](uint32_t b) { const uint64_t o = o2[b]; return make_uint2((uint32_t)(o >> 4), (uint32_t)(o2[b + 1] - o)); });
     }
     for (uint32_t i = threadIdx.x; i <= NB2; i += QS_THREADS) s_off[i] = off2[(uint64_t)blockIdx.x * NB2 + i];
     const uint32_t bl = blockIdx.x / wpb, j = blockIdx.x % wpb;  // local bucket, share of its source regions
@@ -438,7 +460,39 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     const uint64_t rem_mask = ((uint64_t)1 << shift1) - 1;
     // level-2 regions are sized per filter slice (function-0 addresses are denser in low slices): off2
     auto reg = [buf2, s_off](uint32_t b) { const uint64_t o = s_off[b]; return PtRegion<uint64_t>{buf2 + o, s_off[b + 1] - o}; };
+    // P6: entry layout and the group bookkeeping (all uniform)
+    const uint32_t S6 = (uint32_t)slice_bits, PB2 = pb2;  // <= min(44 - S6, 30): a level-1 entry holds a 30-bit position
+    uint32_t next_g = 1;             // groups below this one have their boundary
+    uint32_t *my_bnd = P6 ? bnd + (uint64_t)blockIdx.x * NB2 * n_groups * 2u : nullptr;  // per region: n_groups zone starts, then n_groups zone ends
+    // highest group a region of level-1 workgroup w can hold (its tiles: [w T, (w + 1) T) of the batch)
+    auto gmax = [=](uint32_t w) { return (uint32_t)((min((uint64_t)(w + 1u) * tiles_per_wg, (uint64_t)batch_tiles) * (uint64_t)(PT_THREADS * TPC_RUN) - 1ull) >> PB2); };
+    // (P6) An entry that found no room -- its ring full at the push, or its region full at a flush -> the overflow list's {full
+    // permuted address, survivor id = edge | position << 3}.  Every snapshot empties the rings (below), so whatever sits in a ring
+    // belongs to the zone at hand, next_g - 1, whose entries are of that group or the one below: the parity bit says which.
+    auto lost_p6 = [&](uint32_t b2, uint64_t val) {
+        const uint32_t z = next_g - 1u;
+        const uint64_t plow = (val >> (S6 + 3u)) & ((1ull << PB2) - 1ull);
+        const uint64_t g = (z & 1u) == ((uint32_t)(val >> 47) & 1u) ? z : z - 1u;
+        ovf.push(((uint64_t)b1 << shift1) | ((uint64_t)b2 << S6) | (val & ((1ull << S6) - 1ull)), ((val >> S6) & 7ull) | (((g << PB2) | plow) << 3), 3);
+    };
     auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
+    // (P6) the snapshot: a FINAL-type flush -- every bin's last line goes out partly filled, the next entry starts a new line -- that
+    // records, for the groups [lo, hi) it opens, where their zone starts (bnd, a whole number of lines) and, for the zone it closes,
+    // where its entries end (vend: what follows up to the next line is garbage).  No entry ever waits in a ring across a boundary.
+    auto snapshot = [&](uint32_t lo, uint32_t hi) {
+      if constexpr (P6) {
+        const uint32_t ng = n_groups;
+        uint32_t *mb0 = my_bnd;  // per region: n_groups zone starts, then n_groups zone ends
+        bins.template flush_with<true, false>([&](uint32_t b2, uint64_t val, uint32_t) { lost_p6(b2, val); },
+            [lo, hi, ng, mb0](uint32_t b, uint32_t n) {
+                const uint32_t padded = (n + (uint32_t)PFmt6::GROUP - 1u) / (uint32_t)PFmt6::GROUP * (uint32_t)PFmt6::GROUP;
+                uint32_t *mb = mb0 + (uint64_t)b * 2u * ng, *mv = mb + ng;
+                mv[lo - 1u] = n;
+                for (uint32_t g = lo; g < hi; g++) { mb[g] = padded; mv[g] = padded; }  // (the last of them is the zone now open: its end follows)
+            });
+        next_g = hi;
+      }
+    };
     __syncthreads();
     // rounds of `loads` x QS_THREADS entries over the source regions (j, j + wpb, ...), taken from the round schedule; the
     // loads of the next TWO rounds are in flight while a round is binned and flushed (one round ahead left ~32 KB per CU
@@ -475,6 +529,12 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
             load(va, x0);
             load(vb, x1);
             uint32_t r = 0;
+            if constexpr (P6) {  // a segment that opens with the first round of a region which may hold groups without a boundary yet
+                if (x0.base == 0u) {  // (the very first region among them: boundary 0)
+                    const uint32_t gm = min(gmax(j + x0.t * wpb), n_groups - 1u);
+                    if (gm >= next_g) snapshot(next_g, gm + 1u);
+                }
+            }
             auto round = [&](uint64_t (&cur)[LOADS], uint64_t (&pre)[LOADS]) {
                 const Round x2 = round_at(r + 2);
                 load(pre, x2);
@@ -482,7 +542,22 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
                 bool ok[LOADS];
 #pragma unroll
                 for (int i = 0; i < LOADS; i++) { ok[i] = valid(x0, i) && cur[i] != SENT; bb[i] = (uint32_t)((cur[i] & rem_mask) >> slice_bits); }
-                if constexpr (RB) bins.template push_batch<LOADS>(bb, cur, ok, reg, lost);
+                if constexpr (P6) {
+                    uint64_t v6[LOADS];
+#pragma unroll
+                    for (int i = 0; i < LOADS; i++) {
+                        const uint32_t pos = (uint32_t)(cur[i] >> 34);  // 30 bits, batch relative
+                        const uint64_t id = (uint64_t)((uint32_t)(cur[i] >> QE_E_SHIFT) & 7u) | ((uint64_t)(pos & (uint32_t)((1ull << PB2) - 1ull)) << 3);  // edge | low position bits
+                        v6[i] = (id << S6) | ((uint32_t)cur[i] & ((1u << S6) - 1u)) | ((uint64_t)((uint32_t)((uint64_t)pos >> PB2) & 1u) << 47);
+                    }
+                    bins.template push_batch<LOADS>(bb, v6, ok, lost_p6);
+                    bins.template flush<false>(lost_p6);
+                    // is the NEXT round the first of a region that may hold groups without a boundary yet?  Then they start here.
+                    if (r + 1 < n_seg && x1.base == 0u) {
+                        const uint32_t gm = min(gmax(j + x1.t * wpb), n_groups - 1u);
+                        if (gm >= next_g) snapshot(next_g, gm + 1u);
+                    }
+                } else if constexpr (RB) bins.template push_batch<LOADS>(bb, cur, ok, reg, lost);
                 else { bins.template push_batch<LOADS>(bb, cur, ok, lost); bins.template flush<false>(lost); }
                 x0 = x1; x1 = x2; r++;
             };
@@ -498,7 +573,10 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
         if (total <= skip + sched_cap) break;
         pt_barrier_lds();  // every wave is done with this segment of the schedule
     }
-    if constexpr (RB) { bins.flush(true, reg, lost); bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; }); }
+    if constexpr (P6) {  // the end of the last zone; groups the stream never reached get empty zones behind it
+        snapshot(next_g, n_groups);
+        bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, [](uint32_t b) { return b; });
+    } else if constexpr (RB) { bins.flush(true, reg, lost); bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, reg, [](uint32_t b) { return b; }); }
     else { bins.template flush<true>(lost); bins.store_counts(cnt2 + (uint64_t)blockIdx.x * NB2, [](uint32_t b) { return b; }); }
 }
 
@@ -522,8 +600,13 @@ constexpr size_t QL_LDS = (size_t)QL_STAGE * 8 + (size_t)QL_BUCKETS * 4 + 128 + 
 //  its POSITION, the verifying workgroups walking the sub-lists one per XCD at a time so that the scattered text reads stay in that
 //  XCD's L2 -- and measured it on 7 x 160 Mbp at f = 34 (5.5 % fill, 0.33 survivors per position): k_q_verify2 7.5 -> 6.6 ms per
 //  batch, the query 70.0 -> 68.3 ms; not kept for 2 %.)
+// (Round 5: a staged value may be RAW -- the 6-byte path stages {entry bits, index in the region} and turns them into a survivor id
+//  only when the staging area is flushed, with every lane busy: done where the bit is tested, the search over the region's group
+//  boundaries ran in a branch that 86 % of the wave-instructions entered for 3 % of the lanes.  `res` below: raw -> id, or ~0 for a
+//  padding entry, which the verification kernels skip.)
+struct SurvIdentity { __device__ __forceinline__ uint64_t operator()(uint64_t raw) const { return raw; } };
 struct SurvStage {
-    static constexpr int ID_BITS = 40;
+    static constexpr int ID_BITS = 54;
     uint64_t *sid;     // [QL_STAGE]
     uint32_t *hist;    // [QL_BUCKETS]
     uint32_t *scan;    // [32]
@@ -542,16 +625,18 @@ struct SurvStage {
         shift = slice_bits > 10 ? slice_bits - 10 : 0;
         return reinterpret_cast<unsigned char *>(ctl + 16);
     }
-    __device__ __forceinline__ void push(uint64_t id, uint32_t a)
+    template <class Res = SurvIdentity>
+    __device__ __forceinline__ void push(uint64_t id, uint32_t a, Res res = Res())
     {
         const uint32_t slot = atomicAdd(&ctl[0], 1u);
         if (slot < (uint32_t)QL_STAGE) sid[slot] = id | ((uint64_t)min(a >> shift, (uint32_t)QL_BUCKETS - 1u) << ID_BITS);
         else {  // staging full (dense hits): straight to the sub-list
             const unsigned long long o = atomicAdd(&surv_cur[list], 1ull);
-            if (o < surv_cap) my_list[o] = id; else surv_cur[QS_LISTS] = 1ull;
+            if (o < surv_cap) my_list[o] = res(id); else surv_cur[QS_LISTS] = 1ull;
         }
     }
-    __device__ __forceinline__ void flush()  // all PT_APPLY_THREADS threads
+    template <class Res = SurvIdentity>
+    __device__ __forceinline__ void flush(Res res = Res())  // all PT_APPLY_THREADS threads
     {
         constexpr int PER = QL_STAGE / PT_APPLY_THREADS;
         static_assert(QL_BUCKETS == PT_APPLY_THREADS && QL_STAGE % PT_APPLY_THREADS == 0, "one bucket per thread, whole entries per thread");
@@ -565,7 +650,7 @@ struct SurvStage {
             __syncthreads();
             const uint64_t base = (uint64_t)ctl[2] | ((uint64_t)ctl[3] << 32);
             for (uint32_t i = threadIdx.x; i < m; i += PT_APPLY_THREADS) {
-                if (base + i < surv_cap) my_list[base + i] = sid[i] & ((1ull << ID_BITS) - 1ull);
+                if (base + i < surv_cap) my_list[base + i] = res(sid[i] & ((1ull << ID_BITS) - 1ull));
                 else surv_cur[QS_LISTS] = 1ull;
             }
             __syncthreads();
@@ -597,7 +682,7 @@ struct SurvStage {
                 const uint32_t i = threadIdx.x + u * PT_APPLY_THREADS;
                 if (i < m) {
                     const uint64_t at = base + hist[(uint32_t)(e[u] >> ID_BITS)] + rank[u];
-                    if (at < surv_cap) my_list[at] = e[u] & ((1ull << ID_BITS) - 1ull);
+                    if (at < surv_cap) my_list[at] = res(e[u] & ((1ull << ID_BITS) - 1ull));
                     else surv_cur[QS_LISTS] = 1ull;  // sub-list overflow -> host falls back
                 }
             }
@@ -607,12 +692,13 @@ struct SurvStage {
         __syncthreads();
     }
     // after a region: flush once the staging area is more than half full
-    __device__ __forceinline__ void maybe_flush()
+    template <class Res = SurvIdentity>
+    __device__ __forceinline__ void maybe_flush(Res res = Res())
     {
         __syncthreads();
         const uint32_t staged = min(ctl[0], (uint32_t)QL_STAGE);
         __syncthreads();  // everyone has read the count before anyone stages more
-        if (staged > QL_STAGE / 2) flush();
+        if (staged > QL_STAGE / 2) flush(res);
     }
 };
 
@@ -774,6 +860,7 @@ k_q_verify(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
         const uint64_t sid = my[idx];
+        if (sid == ~0ull) continue;  // a padding entry of the 6-byte path (tpc_qpart6.h)
         const int e = (int)(sid & 7);
         const uint64_t g = gbase + (sid >> 3);
         // (no "is the position marked already?" test: that scattered read cost more than the work it saved, 3.73 -> 3.40 ms.
@@ -896,15 +983,17 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
     // software pipeline: the survivor id and the text word of the NEXT survivor are loaded before this one is hashed (the
     // kernel waits for scattered accesses, not for arithmetic: twice the loads in flight per lane)
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (~0 = a padding entry of the 6-byte path, tpc_qpart6.h: skipped; its text load reads position 0)
     uint64_t sid_n = idx < n ? my[idx] : 0;
-    uint64_t w_n = idx < n ? tpc_text_word_x2(bases, gbase + (sid_n >> 3)) : 0;
+    uint64_t w_n = idx < n ? tpc_text_word_x2(bases, gbase + (sid_n == ~0ull ? 0ull : sid_n >> 3)) : 0;
     for (; idx < n; idx += stride) {
         const uint64_t sid = sid_n;
         const uint64_t w = w_n & wmask;
         if (idx + stride < n) {
             sid_n = my[idx + stride];
-            w_n = tpc_text_word_x2(bases, gbase + (sid_n >> 3));
+            w_n = tpc_text_word_x2(bases, gbase + (sid_n == ~0ull ? 0ull : sid_n >> 3));
         }
+        if (sid == ~0ull) continue;
         const int e = (int)(sid & 7), c = e & 3;
         const uint64_t g = gbase + (sid >> 3);
         // the edge's k + 1 letters, first letter in the low bits: in-edge c + v, out-edge v + c
@@ -1010,6 +1099,8 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
         if (present) atomicOr(&rmask[g >> 5], 1u << ((uint32_t)g & 31u));
     }
 }
+
+#include "tpc_qpart6.h"
 
 // ------------------------------------------------------------------------------------------ sharded verification
 constexpr int RT_CHUNK = 4096, RT_MAXW = 64;  // owner routing: items per workgroup round, most ranks
@@ -1371,7 +1462,7 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
         (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S, H, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         hipLaunchKernelGGL((k_q_hash2<G, S, H, X>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
-                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask);                                                      \
+                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask, pl.fmt == 6 ? pl.tiles_per_wg : 0u);                 \
     } while (0)
 #define TPC_QHASH2_GS(H, X)                                                                                                                 \
     do {                                                                                                                                    \
@@ -1425,6 +1516,20 @@ void launch_qsplit(const TpcLaunch &a, bool sharded, int log_nb1, int log_nb2, i
 #undef TPC_QSPLIT_GO
 }
 
+// the level-2 binning of a fmt-6 plan: 8-byte entries in, blocked 48-bit lines + group boundaries out (k_q_split<false, false, true>)
+void launch_qsplit6(const TpcLaunch &a, const TpcQPlan &pl, QOverflow ovf)
+{
+    const PtShard sh{0, 1};
+    const size_t lds_base = BinsP<PFmt6, QS_THREADS>::lds_bytes(pl.b2) + ((size_t)8 << pl.b2) + 64 + 128;
+    uint32_t nreg_cap, sched_cap;
+    size_t lds;
+    pt_schedule_dims(pl.nwg1, pl.wpb, pl.cap1, (uint32_t)pl.loads * QS_THREADS, lds_base, nreg_cap, sched_cap, lds);
+    (void)hipFuncSetAttribute((const void *)k_q_split<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_q_split<false, false, true>), dim3((1u << pl.b1) * pl.wpb), dim3(QS_THREADS), lds, a.stream, pl.b1, pl.b2, a.P.L, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb,
+                       pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0, nreg_cap, sched_cap, pl.roff1, (const uint64_t *)nullptr, (const uint32_t *)nullptr,
+                       pl.bnd, pl.n_groups, pl.tiles_per_wg, (uint32_t)pl.n_tiles, pl.pb2);
+}
+
 template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
@@ -1451,12 +1556,12 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels)
 {
-    return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl, levels);
+    return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl, levels, false, true);
 }
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions cover the slices this rank owns and are sized
 // for the entries of all ranks
-bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight)
+bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight, bool packed)
 {
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
@@ -1558,11 +1663,50 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
         pl.off3_host.clear();
         pl.buf3_entries = 0;
     }
+    // ---- 48-bit level-2 entries in blocked lines (tpc_qpart6.h): one rank, two levels, flush-per-round bins at level 2 that do not
+    // span waves.  TPC_ENTRY_FMT=legacy (read once per process) keeps the 8-byte entries for A/B measurements.
+    pl.fmt = 0;
+    static const bool legacy_fmt = [] { const char *e = getenv("TPC_ENTRY_FMT"); return e && (e[0] == 'l' || e[0] == 'i'); }();  // "legacy", or "insert": only the insert's new format
+    int PB2 = std::min(44 - slice_bits, 30);  // position bits below the group (a level-1 entry holds a 30-bit position)
+    if (tpc_test_q6_pb2 >= 14 && tpc_test_q6_pb2 < PB2) PB2 = tpc_test_q6_pb2;  // tests: many groups on a small input
+    const uint64_t tpw = (n_tiles + pl.nwg1 - 1) / pl.nwg1;  // level 1: contiguous tiles per workgroup
+    const uint64_t groups = ((n_tiles * (uint64_t)(PT_THREADS * TPC_RUN)) + (1ull << PB2) - 1) >> PB2;
+    static const bool no_lean = getenv("TPC_NO_LEAN") != nullptr;  // (measurements: the generic hash kernel takes its tiles interleaved)
+    // (512 bins at level 2 -- f = 37, 38 -- stay on the 8-byte barrier-free rings: 40-entry rings allow rounds of 3072 entries only, and
+    //  the 62-genome text at f = 38 measured 40.6 ms per step against 39.6; TPC_P6_MAXB2=9 lifts the gate for measurements)
+    static const int max_b2 = [] { const char *e = getenv("TPC_P6_MAXB2"); return e ? atoi(e) : 8; }();
+    if (packed && !legacy_fmt && !no_lean && world == 1 && !three && pl.b2 >= 4 && pl.b2 <= max_b2 && pl.b1 <= 9 && pl.sub_rounds <= 2 && F <= 24 && PB2 >= 14 &&
+        tpw * (uint64_t)(PT_THREADS * TPC_RUN) <= (1ull << PB2) && groups >= 1 && groups <= 64) {
+        pl.fmt = 6;
+        pl.tiles_per_wg = (uint32_t)tpw;
+        pl.n_groups = (uint32_t)groups;
+        pl.pb2 = (uint32_t)PB2;
+        // ring rounds of the level-2 bins: CAP = 20 entries x groups per bin; a round = loads x 1024 entries; the last level's bins see a 2x skew
+        const int cap_s = (int)BinsP<PFmt6, QS_THREADS>::cap_for(pl.b2);
+        static const int loads_cap = [] { const char *e = getenv("TPC_P6_LOADS"); return e ? std::max(1, std::min(5, atoi(e))) : 5; }();  // (measurements)
+        pl.loads = std::max(1, std::min(loads_cap, std::max(1, (1 << pl.b2) * (cap_s - PFmt6::GROUP) * 5 / 8) * 9 / 8 / QS_THREADS / 2));
+        if (gated_round) pl.loads = std::max(1, pl.loads / 2);
+        // level-2 regions in lines
+        uint64_t o = 0;
+        for (uint64_t r = 0; r < nreg2; r++) {
+            const uint64_t e = pl.off2_host[r + 1] - pl.off2_host[r];  // entries the 8-byte path gives this slice
+            pl.off2_host[r] = o;
+            o += (e + PFmt6::GROUP - 1) / PFmt6::GROUP;
+        }
+        pl.off2_host[nreg2] = o;
+        pl.buf2_entries = o;  // lines
+    }
     return true;
 }
 
 size_t tpc_qpart_bytes(const TpcQPlan &pl, int which)
 {
+    if (pl.fmt == 6) {
+        switch (which) {
+        case 2: return (size_t)pl.buf2_entries * PT_LINE;
+        case 18: return ((size_t)(1u << pl.b1) * pl.wpb * (1u << pl.b2)) * pl.n_groups * 8;  // zone starts and zone ends
+        }
+    }
     switch (which) {
     case 0: return (size_t)pl.nwg1 * (1u << pl.b1) * pl.cap1 * 8;
     case 1: return (size_t)pl.nwg1 * (1u << pl.b1) * 4;
@@ -1591,6 +1735,16 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 {
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
+    if (pl.fmt == 6) {
+        launch_qsplit6(a, pl, QOverflow{pl.ovf, pl.ovf_cur, pl.ovf_cap});
+        const size_t words = (size_t)1 << (pl.slice_bits - 5);
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
+        (void)hipFuncSetAttribute((const void *)k_q_lookup6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_q_lookup6, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, (const unsigned char *)pl.buf2,
+                           pl.cnt2, pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);
+        hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
+        return 0;
+    }
     {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
@@ -1624,6 +1778,23 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
     const PtShard sh{0, 1};
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
+    if (pl.fmt == 6) {
+        launch_qsplit6(a, pl, ovf);
+        const size_t words = (size_t)1 << (pl.slice_bits - 5);
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
+#define TPC_AL6_GO(I3)                                                                                                                                  \
+    do {                                                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)k_apply_lookup6<I3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipLaunchKernelGGL(k_apply_lookup6<I3>, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, (const unsigned char *)ipl.buf2, \
+                           ipl.cnt2, (uint64_t)(I3 ? ipl.cap2 / PFmt3::GROUP : ipl.cap2 / 32), fresh ? 1 : 0, iovf, iovf_off, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2, \
+                           pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);       \
+    } while (0)
+        if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
+#undef TPC_AL6_GO
+        hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
+        return 0;
+    }
+    if (ipl.fmt2 == 3) return -1;  // the 8-byte lookup reads 32-bit insert entries (the caller plans both passes with the same format switch)
     {
         launch_qsplit(a, false, pl.b1, pl.b2, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0,
                       pl.roff1, (1u << pl.b1) * pl.wpb);
