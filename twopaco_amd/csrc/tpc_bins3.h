@@ -36,7 +36,10 @@ struct Bins3 {
     // The control words sit BELOW the rings: with the workgroup's dynamic LDS starting at address 0 their offsets (and the rings'
     // base, 4224) fit the 16-bit immediate of the DS instructions, so a push forms no address beyond `bin << 2` (round 3 had
     // the rings first: every tail / limit access paid a v_add of a 131072+ base that no immediate can hold).
-    static constexpr uint32_t OFF_TAIL = 0, OFF_LIMIT = OFF_TAIL + NB_MAX * 4, OFF_DONE = OFF_LIMIT + NB_MAX * 4, OFF_CNTDOWN = OFF_DONE + 64, OFF_RINGS = OFF_CNTDOWN + 64,
+    // (Round 5: {tail, limit} of a bin are ONE 64-bit word, tail in the low half, claimed with a single returning ds_add_u64 -- a push
+    //  no longer reads the limit separately; profiles/r02_lds_bench.txt priced the pair at 8.17 + 10.5 lane-clocks against 5.35.  Whoever
+    //  changes a half while pushes may be in flight must do it with a 64-bit atomic too: the claim writes both halves back.)
+    static constexpr uint32_t OFF_CTL = 0, OFF_DONE = OFF_CTL + NB_MAX * 8, OFF_CNTDOWN = OFF_DONE + 64, OFF_RINGS = OFF_CNTDOWN + 64,
                               OFF_END = OFF_RINGS + PT_BIN_BYTES;
     static_assert(PT_BIN_BYTES == 131072 && PT_LINE == 128 && OFF_RINGS % PT_LINE == 0, "layout constants");
 
@@ -52,8 +55,7 @@ struct Bins3 {
 
     static size_t lds_bytes(int) { return OFF_END; }
 
-    __device__ __forceinline__ uint32_t *tail() const { return reinterpret_cast<uint32_t *>(base + OFF_TAIL); }
-    __device__ __forceinline__ uint32_t *limit() const { return reinterpret_cast<uint32_t *>(base + OFF_LIMIT); }
+    __device__ __forceinline__ unsigned long long *ctl() const { return reinterpret_cast<unsigned long long *>(base + OFF_CTL); }
     __device__ __forceinline__ uint32_t *done() const { return reinterpret_cast<uint32_t *>(base + OFF_DONE); }
     __device__ __forceinline__ uint32_t *cntdown() const { return reinterpret_cast<uint32_t *>(base + OFF_CNTDOWN); }  // bins that span several waves: owners still copying
     __device__ __forceinline__ bool multi() const { return LOG_GPB > 6u; }  // a bin's ring groups span more than one wave
@@ -79,7 +81,7 @@ struct Bins3 {
         gbase = reinterpret_cast<unsigned char *>(global) + (threadIdx.x & 7u) * 16u;
         const uint2 r = region(my_bin);
         my_unit0 = r.x; my_cap = r.y;
-        for (uint32_t b = threadIdx.x; b < (uint32_t)NB_MAX; b += THREADS) { tail()[b] = 0; limit()[b] = CAP; }
+        for (uint32_t b = threadIdx.x; b < (uint32_t)NB_MAX; b += THREADS) ctl()[b] = (unsigned long long)CAP << 32;  // tail 0, limit CAP
         if (threadIdx.x < 16) done()[threadIdx.x] = 0;
     }
 
@@ -93,8 +95,8 @@ struct Bins3 {
         for (int i = 0; i < N; i++) {
             slot[i] = 0; lim[i] = 0;
             if (ok[i]) {
-                slot[i] = atomicAdd(&tail()[b[i]], 1u);
-                lim[i] = limit()[b[i]];
+                const unsigned long long c = atomicAdd(&ctl()[b[i]], 1ull);
+                slot[i] = (uint32_t)c; lim[i] = (uint32_t)(c >> 32);
             }
         }
         uint32_t pend = 0;
@@ -121,7 +123,7 @@ struct Bins3 {
                     const uint32_t w0 = (bi << LOG_GPB) >> 6, nw = multi() ? 1u << (LOG_GPB - 6u) : 1u;
                     bool owners_done = true;
                     for (uint32_t w = w0; w < w0 + nw; w++) owners_done = owners_done && __hip_atomic_load(&done()[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == flushes;
-                    const uint32_t l2 = __hip_atomic_load(&limit()[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t l2 = __hip_atomic_load(reinterpret_cast<uint32_t *>(&ctl()[bi]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (si < l2) {
                         *reinterpret_cast<T *>(base + OFF_RINGS + (((bi << LOG_CAP) | (si & (CAP - 1u))) << LOG_T)) = vi;
                         pend &= ~(1u << i);
@@ -148,17 +150,19 @@ struct Bins3 {
     __device__ __forceinline__ void flush(Lost lost)
     {
         pt_barrier_lds();  // B1: every push of the round is in its ring
-        uint32_t t = tail()[my_bin];
-        const uint32_t lim = limit()[my_bin];
+        const unsigned long long c0 = ctl()[my_bin];
+        uint32_t t = (uint32_t)c0;
+        const uint32_t lim = (uint32_t)(c0 >> 32);
         const uint32_t h = lim - CAP;
         if (t - h > CAP) {  // the ring overflowed: the slot numbers beyond CAP were handed to lost() by push_batch
             t = h + CAP;
-            if (my_slot == 0) tail()[my_bin] = t;
+            if (my_slot == 0) *reinterpret_cast<uint32_t *>(&ctl()[my_bin]) = t;  // (no push is in flight between the two barriers)
         }
         if (multi() && my_slot == 0) cntdown()[my_bin] = 1u << (LOG_GPB - 6u);  // owner waves that have to finish their copy before the ring space is released
         pt_barrier_lds();  // B2: no push of the next round before every snapshot is taken
         const uint32_t n = t - h;
         const uint32_t nfull = FINAL ? (n + GROUP - 1u) >> LOG_GROUP : n >> LOG_GROUP;
+        if (FINAL && my_slot == 0) *reinterpret_cast<uint32_t *>(&ctl()[my_bin]) = h + (nfull << LOG_GROUP);  // the padded tail (nothing is pushed any more)
         const uint32_t gmask = (1u << LOG_GPB) - 1u;
         const uint32_t rel = (my_slot - (h >> LOG_GROUP)) & gmask;  // my ring group is the rel-th group after the head
         const bool ready = rel < nfull;
@@ -216,15 +220,9 @@ struct Bins3 {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         flushes++;
         if (!multi()) {
-            if (my_slot == 0) {
-                limit()[my_bin] = lim + (nfull << LOG_GROUP);
-                if (FINAL) tail()[my_bin] = h + (nfull << LOG_GROUP);
-            }
+            if (my_slot == 0 && nfull) atomicAdd(&ctl()[my_bin], (unsigned long long)(nfull << LOG_GROUP) << 32);
         } else if (lane == 0) {  // the wave's 64 ring groups belong to one bin: the last owner wave to finish releases the space
-            if (atomicSub(&cntdown()[my_bin], 1u) == 1u) {
-                limit()[my_bin] = lim + (nfull << LOG_GROUP);
-                if (FINAL) tail()[my_bin] = h + (nfull << LOG_GROUP);
-            }
+            if (atomicSub(&cntdown()[my_bin], 1u) == 1u && nfull) atomicAdd(&ctl()[my_bin], (unsigned long long)(nfull << LOG_GROUP) << 32);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&done()[wave], flushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -236,7 +234,7 @@ struct Bins3 {
     {
         pt_barrier_lds();
         if (my_slot == 0) {
-            const uint32_t head = limit()[my_bin] - CAP;
+            const uint32_t head = (uint32_t)(ctl()[my_bin] >> 32) - CAP;
             out[idx(my_bin)] = min(head, my_cap);
         }
     }

@@ -110,12 +110,14 @@ struct PlStream {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const uint32_t blk = i0 + u * STEP + threadIdx.x;
-            if (blk < nb) {
+            const uint32_t idx0 = blk * (uint32_t)F::PER_BLOCK;
+            if (idx0 + (uint32_t)F::PER_BLOCK <= n) {  // a whole block (all but the region's last one): no test per entry
 #pragma unroll
-                for (int i = 0; i < F::PER_BLOCK; i++) {
-                    const uint32_t idx = blk * (uint32_t)F::PER_BLOCK + (uint32_t)i;
-                    if (idx < n) f(F::get(d0[u], d1[u], i), idx);
-                }
+                for (int i = 0; i < F::PER_BLOCK; i++) f(F::get(d0[u], d1[u], i), idx0 + (uint32_t)i);
+            } else if (blk < nb) {
+#pragma unroll
+                for (int i = 0; i < F::PER_BLOCK; i++)
+                    if (idx0 + (uint32_t)i < n) f(F::get(d0[u], d1[u], i), idx0 + (uint32_t)i);
             }
         }
     }
