@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 G_BYTES = 64           # HBM access granule of a scattered 4-byte access (SURVEY 8d planning value)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
 GOLDEN_SEED = 20240229  # tests/golden/make_golden.py: the seed the reference goldens were made with
-PMC_PROFILE = "r04_pmc_traffic.json"
+PMC_PROFILE = "r05_pmc_traffic.json"
 
 
 def launch_ranks(args, script=None):
@@ -184,7 +184,7 @@ def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
             return time.time() - t0, res
 
         fixed = None
-        if mode == "full":
+        if mode in ("full", "sample"):  # the reference's fixed cost at this filter size: allocation + serial zeroing (~11 s at f = 36)
             tiny = os.path.join(tmp, "tiny.fa")
             synth.write_fasta(tiny, [recs[0][:2000]])
             try:
@@ -207,7 +207,7 @@ def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
                              % ("all" if mode == "full" else "first 6 genomes", len(sample), kmers, p["k"], p["q"], L, cores, wall,
                                 m.group(1) if m else "?", m.group(2) if m else "?", occ),
                    "junction_occurrences_per_sec": occ / wall, "wall_s": wall}
-            if fixed is not None:
+            if fixed is not None and L == p["L"]:
                 out["fixed_cost_s"] = fixed
                 out["value_without_fixed_cost"] = kmers / max(wall - fixed, 1e-9)
                 out["sample"] += "; a 2 kbp input takes %.1f s (filter allocation + serial zeroing, concurrentbitvector.cpp:11-24)" % fixed
@@ -311,6 +311,9 @@ def main():
     dt = time.perf_counter() - t0
     kms = {n: v / args.steps for n, v in kms.items()}
     fused = ctx.stat("fused_lookups") - fused0 == args.steps  # deferred apply: the query's lookup built the filter slices
+    # bytes per level-2 entry as the passes ran them (tpc_binsp.h: 48-bit query entries in lines of 20, 24-bit insert entries in lines of 40)
+    q_l2_bytes = 128 / 20 if ctx.stat("query_entry_fmt") == 6 else 8.0
+    i_l2_bytes = 128 / 40 if ctx.stat("insert_entry_fmt") == 3 else 4.0
     result = {"candidate_marks": marks, "junctions": J, "junction_occurrences": n_valid, **st}
     result_ok = None
     if golden:  # the reference's own counters for this workload (VE.h:384-388), tests/golden/cases.json
@@ -330,13 +333,13 @@ def main():
     q = p["q"]
     filter_bytes = (1 << p["L"]) // 8
     ins_addr, qry_addr = q * n_kmers, 6 * n_kmers
-    design_ins = 0.375 * n_kmers + ins_addr * 4 * 4 + filter_bytes          # W l1, R+W l2, R apply; filter written once
-    design_qry = 0.375 * n_kmers + qry_addr * 8 * 4 + (0 if fused else filter_bytes)  # uint64 entries; filter read once unless fused
+    design_ins = 0.375 * n_kmers + ins_addr * (4 + 4 + 2 * i_l2_bytes) + filter_bytes          # W l1, R+W l2, R apply; filter written once
+    design_qry = 0.375 * n_kmers + qry_addr * (8 + 8 + 2 * q_l2_bytes) + (0 if fused else filter_bytes)  # 8-byte level-1 entries; filter read once unless fused
     # With the apply deferred into the query's lookup kernel ("fused" = k_q_split + k_apply_lookup, timed inside "query"),
     # the insert's share of that group is what its apply has to move: its level-2 entries in, the filter out.
     ins_ms, qry_ms = kms["insert"], kms["query"]
     if fused:
-        share = (ins_addr * 4 + filter_bytes) / (ins_addr * 4 + filter_bytes + qry_addr * 8 * 3)
+        share = (ins_addr * i_l2_bytes + filter_bytes) / (ins_addr * i_l2_bytes + filter_bytes + qry_addr * (8 + 2 * q_l2_bytes))
         ins_ms, qry_ms = kms["insert"] + share * kms["fused"], kms["query"] - share * kms["fused"]
     traffic_ins = traffic_qry = None
     pmc_tag = None
@@ -351,20 +354,26 @@ def main():
             pmc_tag = "stale: %s was collected on other kernel sources" % PMC_PROFILE
 
     def roof(kernel, ms, design, traffic, survey_bytes, floor_per_kmer):
-        ach = design / (ms * 1e-3) / 1e9
+        # `achieved` / `frac`: the HBM bytes the rocprofv3 counters saw per launch of this kernel group (profiles/<PMC_PROFILE>, same
+        # command, same kernel sources) over the group's time measured live with HIP events in this run -- the north star's
+        # "rocprof achieved-HBM-GB/s".  No counters for these sources (stale profile): no fraction, rather than a number priced with
+        # something else.  What the design has to move by construction is reported beside it (design_*), never as `frac`.
+        meas = (traffic / (ms * 1e-3) / 1e9) if traffic else None
+        des = design / (ms * 1e-3) / 1e9
         floor = floor_per_kmer * n_kmers
-        d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        d = {"bound": "hbm", "kernel": kernel, "achieved": meas, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (meas / HBM_PEAK_GBS) if meas else None,
              "traffic": traffic, "traffic_source": pmc_tag, "launch_ms": ms, "algorithmic_bytes_per_launch": design,
              "algorithmic_bytes_per_kmer": design / n_kmers,
-             "measured_hbm_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
-             "measured_hbm_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+             "measured_hbm_GBs": meas,
+             "measured_hbm_frac": (meas / HBM_PEAK_GBS) if meas else None,
+             "design_GBs": des, "design_frac": des / HBM_PEAK_GBS,
              "survey_model_GBs": n_kmers * survey_bytes / (ms * 1e-3) / 1e9,
              # the implementation-independent floor ("the word-level lower bound ... what a perfectly write-combined /
              # bucketed implementation approaches"): every address crosses HBM once as an 8-byte word, plus the packed text.  `frac`
              # above is priced with what THIS design moves, so a design change that moves fewer bytes lowers numerator and time
              # together; frac_of_floor only moves when the pass gets faster.
              "floor_bytes": floor, "floor_bytes_per_kmer": floor_per_kmer, "frac_of_floor": floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "bytes_over_floor": design / floor}
+             "bytes_over_floor": design / floor, "measured_bytes_over_floor": (traffic / floor) if traffic else None}
         return d
 
     out = {
@@ -374,7 +383,7 @@ def main():
         "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d, 1 round"
                                % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
                    "kmers": n_kmers, "filter_bytes": filter_bytes, "insert_test_first": args.test_first, "decomposition": "single GPU",
-                   "apply_fused_into_lookup": fused},
+                   "apply_fused_into_lookup": fused, "query_level2_entry_bytes": q_l2_bytes, "insert_level2_entry_bytes": i_l2_bytes},
         "junction_occurrences_per_sec": n_valid * args.steps / dt,
         "insert_kmers_per_sec": n_kmers / (ins_ms * 1e-3),
         "query_kmers_per_sec": n_kmers / (qry_ms * 1e-3),

@@ -1327,3 +1327,38 @@ def test_gated_rounds_keep_their_entries_in_the_regions():
     # (a range's filter holds only the edges touching the range: its Bloom false positives are a subset of the whole round's)
     assert whole - 1000 <= total <= whole and whole > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("q", [1, 2])
+def test_gated_insert_rounds_with_few_functions_keep_their_entries_in_the_regions(q):
+    """ADVICE (round 4): the slice regions of a GATED insert are sized for the round's share of the entries, but one of the q addresses
+    of an edge is a function-0 address and those of a vertex-hash range pile into the XOR image of the range (~2.5 x the share in the
+    hot slices).  With q = 1 or 2 that exceeded the 1.5 x slack of the regions; now such rounds are sized for all the entries.  Eight
+    rounds at f = 30: the partitioned insert completes on its own (path 2, no direct-kernel completion) and its overflow list stays
+    (almost) empty; the filter of every round equals the direct kernel's."""
+    from twopaco_amd import capi, synth
+    from twopaco_amd.dist import vertex_hash_ranges
+    recs, p = synth.workload("m2", scale=0.1)
+    text = capi.PackedText.from_codes(recs)
+    n = synth.n_kmers(recs, p["k"])
+    L = 30
+    filters = {}
+    for mode in (2, 1):
+        ctx = capi.Context(0)
+        ctx.set_option("insert_mode", mode)
+        ctx.set_params(p["k"], L, q, capi.seed_table(q, L, seed=20240229))
+        ctx.seq_upload(text)
+        for i, (lo, hi) in enumerate(vertex_hash_ranges(L, 8)):
+            if i not in (0, 3, 7):
+                continue
+            ctx.filter_reset()
+            ctx.pass1_insert(lo, hi, count=False)
+            if mode == 2:
+                assert ctx.stat("insert_path") == 2, (q, i, ctx.stat("insert_path"))
+                assert ctx.stat("insert_overflow_entries") <= max(64, q * n * 1e-5), (q, i, ctx.stat("insert_overflow_entries"))
+            f = ctx.filter_download()
+            if mode == 2:
+                filters[i] = f
+            else:
+                assert (filters[i] == f).all(), (q, i)
+        ctx.close()

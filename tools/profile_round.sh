@@ -17,5 +17,10 @@ kdb=$(find $out/prof_${tag}_k -name "*.db" | head -1); fdb=$(find $out/prof_${ta
 test -n "$kdb" && test -n "$fdb" && test -n "$wdb"
 python3 tools/prof_summary.py $kdb > $out/${tag}_kernel_stats.csv
 python3 tools/pmc_traffic.py $fdb $wdb > $out/${tag}_pmc_traffic.json
+# the bench line reads profiles/<PMC_PROFILE of bench.py>: put the counters just collected there BEFORE the line is taken, so that it
+# carries `traffic` / `frac` of THIS build (round 4's kept line said "stale" because this copy came after)
+pmc_name=$(python3 -c "import re;print(re.search(r'PMC_PROFILE = \"(.*?)\"', open('bench.py').read()).group(1))")
+cp $out/${tag}_pmc_traffic.json profiles/$pmc_name
 python3 bench.py "${@:2}" > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cp profiles/$pmc_name $out/$pmc_name
 head -14 $out/${tag}_kernel_stats.csv

@@ -113,6 +113,7 @@ struct tpc_ctx {
     uint32_t iovf_slices = 0;
     int64_t stat_fused = 0;
     int64_t stat_query_overflow = 0;  // entries the last partitioned query batch handed to its overflow list
+    int64_t stat_insert_overflow = 0; // ... and the last partitioned insert batch
     int64_t stat_pbuf_releases = 0;  // times the partition buffers were given back to let a second-pass allocation through
     // address-sharded filter (tpc_shard_*)
     uint32_t sh_rank = 0, sh_world = 1;
@@ -491,6 +492,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "filter2_retries")) return c->stat_filter2_retries;
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
     if (!strcmp(name, "query_overflow_entries")) return c->stat_query_overflow;
+    if (!strcmp(name, "insert_overflow_entries")) return c->stat_insert_overflow;
     if (!strcmp(name, "pbuf_releases")) return c->stat_pbuf_releases;
     if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
     if (!strcmp(name, "device_free_bytes") || !strcmp(name, "device_total_bytes")) {  // hipMemGetInfo of the context's device, now
@@ -742,6 +744,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         overflowed = overflowed || ov[1] != 0;
         c->stat_path[0] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_fmt[0] = pl.fmt2;
+        c->stat_insert_overflow = (int64_t)ov[0];
         c->stat_batches[0] = (int64_t)((tiles + per_batch - 1) / per_batch);
         if (!overflowed) {
             if (n_kmers) return read_counter(c, 0, n_kmers);

@@ -754,7 +754,14 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // tight: the densest bucket's expectation (one of the q addresses of an edge is a function-0 address: pt_bucket_peak), the gate's share
     const double avg1t = avg1 * (1.0 + (pt_bucket_peak(pm, F, pl.b1) - 1.0) / q);
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 31) & ~31ull;
-    const double avg2 = a_exp * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
+    // A gated round is not uniform over the slices: the vertices of a hash range put the function-0 addresses of their edges into the XOR
+    // image of that range (tpc_qpart_plan_sharded: the query's hot slices take ~2.5 x their share).  One of the q addresses of an edge is a
+    // function-0 address, so an insert slice of such a round can hold 1 + 1.5 / q times its share; with one or two functions the regions
+    // are sized for all the entries, as the query's are.  (sized for the share alone, hot slices of a q <= 2 round overflow
+    // the 1.5 x slack; a sharded filter has no direct-kernel fallback behind its overflow list.)
+    const bool gated_plan = frac < 1.0;
+    const double a_l2 = !gated_plan ? a_exp : q <= 2 ? a_max : std::min(a_max, a_exp * (1.0 + 1.5 / q));
+    const double avg2 = a_l2 * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     // the last level's entries as planar 24-bit lines (tpc_binsp.h): one rank, two levels, slice offsets of at most 20 bits, bins that
     // do not span waves.  TPC_ENTRY_FMT=legacy (read once per process) keeps the 32-bit entries for A/B measurements.
@@ -766,7 +773,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     pl.fmt2 = (packed && !legacy_fmt && world == 1 && !three && slice_bits <= 20 && pl.b2 >= 4 && pl.b2 <= 9) ? 3 : 0;
     if (pl.fmt2 == 3) pl.cap2 = (pl.cap2 + PFmt3::GROUP - 1) / PFmt3::GROUP * PFmt3::GROUP;
     pl.wpb3 = 1;
-    const double avg3 = a_exp * world / ((double)(1ull << F) * pl.wpb3);
+    const double avg3 = a_l2 * world / ((double)(1ull << F) * pl.wpb3);
     pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
     return true;

@@ -196,7 +196,7 @@ int tpc_launch_split_anyq(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, u
 {
     const dim3 grid((unsigned)((a.n_text + 255) / 256));
     const bool crowded = (double)a.P.q * (double)a.n_text > (double)(a.P.lmask >> 3);
-    const int phases = crowded ? a.P.q : 3;  // as tpc_pass1.hip:launch_split_q
+    const int phases = (a.P.q < 3 || crowded) ? a.P.q : 3;  // as tpc_pass1.hip:launch_split_q (a phase beyond q would hash with an all-zero table row)
     for (int phase = 0; phase < phases; phase++)
         hipLaunchKernelGGL(k_split_anyq, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, emask, phase, a.n_text, a.filter, bins, bin_size);
     return 0;
