@@ -130,6 +130,8 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
         cmd = [exe, "-k", str(p["k"]), "-f", str(p["L"]), "-q", str(p["q"]), "-t", threads, "--seed", str(GOLDEN_SEED), "--tmpdir", tmp, "-o", out]
         if gpus > 1:
             cmd += ["--gpus", str(gpus)]
+            if os.environ.get("TPC_E2E_EMULATE_RANKS"):  # tests: the N ranks of the C++ host on ONE device (loopback transport)
+                cmd += ["--emulate-ranks"]
         cmd += files
         t0 = time.perf_counter()
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -137,7 +139,16 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
         if res.returncode != 0:
             return {"error": res.stderr.decode()[-400:]}
         walls.append(wall)
-        phases.append((wall, {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[timing\]\s+(.*): ([0-9.eE+-]+) ms", res.stderr.decode())}))
+        err = res.stderr.decode()
+        ph = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[timing\]\s+(.*): ([0-9.eE+-]+) ms", err)}
+        # the C++ multi-GPU host's own phases of the sharded first pass (rank 0, summed over the rounds): "name ms;" pairs on one line
+        sharded = {}
+        for m in re.finditer(r"\[timing\]\s+sharded first pass[^:]*\(rank 0, ms\):(.*)", err):
+            for name, val in re.findall(r"\s*([^;]*?) ([0-9.eE+-]+);", m.group(1)):
+                sharded[name.strip()] = sharded.get(name.strip(), 0.0) + float(val)
+        if sharded:
+            ph["__sharded__"] = sharded
+        phases.append((wall, ph))
         occ = int(re.search(r"True marks count: (\d+)", res.stdout.decode()).group(1))
         if rep == 0 and golden:
             sha_ok = sha256_file(out) == golden["bin_sha256"] and occ == golden["true_marks"]
@@ -153,13 +164,17 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
     def breakdown(ph):
         return {k: ph.get(v) for k, v in BREAKDOWN_KEYS if ph.get(v) is not None or k in ("exec_to_main_ms", "rounds_ms", "write_ms")}
 
-    detail = {k: v for k, v in order[len(order) // 2][1].items() if k.startswith("code object")}  # per translation unit, median run
+    median_ph = order[len(order) // 2][1]
+    sharded = median_ph.get("__sharded__")
+    detail = {k: v for k, v in median_ph.items() if k.startswith("code object")}  # per translation unit, median run
     detail["all runs"] = [ph.get("warm-up thread: code objects") for _, ph in order]
     return {"e2e_wall_s": med, "breakdown_ms": breakdown(order[len(order) // 2][1]), "code_objects_ms": detail, "e2e_wall_s_min": walls[0], "e2e_wall_s_p50": med, "e2e_wall_s_max": walls[-1],
             "e2e_wall_s_all": walls, "slowest_run_breakdown_ms": breakdown(order[-1][1]), "settle_s_between_runs": settle_s,
             "e2e_junction_occurrences_per_sec": occ / med,
             "junction_occurrences": occ, "runs": runs, "host_threads": int(threads), "gpus": gpus,
             "output_sha256_equals_reference": sha_ok,
+            "sharded_first_pass_ms_rank0": {k: v for k, v in sharded.items() if k != "region bytes sent"} if sharded else None,
+            "region_bytes_sent_rank0": int(sharded["region bytes sent"]) if sharded and "region bytes sent" in sharded else None,
             "what": "twopaco CLI child process%s, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (
                 " --gpus %d (C++ host, RCCL transport)" % gpus if gpus > 1 else "", len(files), runs)}
 

@@ -213,6 +213,11 @@ int tpc_emit_stream_part(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t
 int tpc_host_alloc(void **ptr, uint64_t bytes);
 void tpc_host_free(void *ptr);
 
+/* One rank (world == 1, e.g. the sharded protocol exercised on a single device): the survivors of the last tpc_shard_apply(QUERY)
+ * are verified against hash functions 1..q-1 and marked in place -- every survivor is home and every probe address is owned here,
+ * so none of the routing calls below is needed (reference: CandidateCheckingWorker's remaining probes, vertexenumerator.h:640-660). */
+int tpc_shard_verify_local(tpc_ctx *ctx);
+
 /* ---- address-sharded filter (multi-GPU) -------------------------------------------------
  * The Bloom filter (ConcurrentBitVector bitVector, VE.h:257) is cut over `world` ranks (a power of
  * two) by bit address: the partitioned passes route every address to the workgroup that owns its

@@ -102,6 +102,7 @@ struct tpc_ctx {
     int opt_fuse = 1;
     bool pending_apply = false;   // the filter in HBM does not hold the last insert yet
     bool pending_fresh = false;
+    bool pending_shard = false;   // ... and that insert was a sharded one (tpc_shard_apply*): its overflow entries wait in the pass' apply-side list
     TpcPartPlan pending_pl;
     void *ikeep[2] = {nullptr, nullptr};  // the insert's level-2 regions and counts while an apply is pending
     size_t ikeep_bytes[2] = {0, 0};
@@ -122,6 +123,7 @@ struct tpc_ctx {
     bool sh_have[2] = {false, false};
     uint64_t sh_per[2] = {0, 0}, sh_batches[2] = {0, 0};
     uint64_t sh_nsurv = 0;
+    bool sh_defer = false;   // the insert plan at hand may leave its apply to the query's lookup (one batch, room for its level-2 regions)
     // Overflow lists of a sharded pass, two per pass (round 4): the hash kernels append to the PRODUCED list (tpc_shard_overflow_get
     // reads it), tpc_shard_overflow_set writes the gathered entries into the APPLIED list, which the apply side extends (level-2
     // losses) and consumes (k_part_ovf / k_q_ovf).  With one list per pass a hash running under the previous batch's exchange
@@ -236,6 +238,13 @@ int flush_pending_apply(tpc_ctx *c)
 {   // the deferred apply of the last insert, for anything that reads or extends the filter other than the fused lookup
     if (!c->pending_apply) return 0;
     c->pending_apply = false;
+    if (c->pending_shard) {  // the sharded insert: level-2 regions kept aside, the overflow entries still in the apply-side list the plan points at
+        c->pending_shard = false;
+        Timed t(c, TPC_K_SHARD_APPLY);
+        if (tpc_launch_insert_part_apply_only(make_launch(c), c->pending_pl, c->pending_fresh)) return fail(c, -1, "apply launch failed");
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     Timed t(c, TPC_K_FUSED);
     // the insert's overflow entries were set aside (the list buffer is shared with the query): put them back for k_part_ovf.
     // The shared buffers may have been reallocated since the insert (ensure_pbuf for a query plan of another size): take the
@@ -617,6 +626,7 @@ int tpc_filter_reset(tpc_ctx *c)
     // only materialised (hipMemsetAsync, timed as TPC_K_FILTER_RESET) when something else needs it.
     c->filter_zero_pending = true;
     c->pending_apply = false;  // an insert nobody looked at is forgotten with the filter
+    c->pending_shard = false;
     c->ev_used[TPC_K_FILTER_RESET] = false;
     return 0;
 }
@@ -724,7 +734,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                                                         c->ikeep_ovf + c->ikeep_ovf_cap)) return fail(c, -1, "overflow grouping launch failed");
                         }
                     }
-                    if (keep) { c->pending_apply = true; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = ov[0]; }
+                    if (keep) { c->pending_apply = true; c->pending_shard = false; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = ov[0]; }
                     else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
                     break;
                 }
@@ -869,7 +879,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (part)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (qpart_need(pl, i)) part = ensure_pbuf(c, i, qpart_need(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
-    const bool fused = c->pending_apply && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
+    const bool fused = c->pending_apply && !c->pending_shard && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
                        pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2 && (pl.fmt == 6 || c->pending_pl.fmt2 == 0);
     if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     if (part) {
@@ -1585,6 +1595,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         return fail(c, -1, "a sharded filter needs the partitioned hash kernels: q=%d, L=%d, slice_bits=%d are outside what they cover (1..8 functions, or 9..16 with L - slice_bits <= 24)",
                     c->P.q, c->P.L, c->opt_slice_bits);
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    if (pass == TPC_SHARD_INSERT) { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }  // (its regions are about to be re-planned)
     const uint64_t W = c->sh_world, tiles = text_tiles512(c);
     const uint64_t per_total = (tiles + W - 1) / W;
     const double m = gated ? range_mass(c, lo, hi) : 1.0;
@@ -1604,6 +1615,22 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
         if (pl.b3 && (!ensure_pbuf(c, 9, tpc_part_buf3_bytes(pl)) || !ensure_pbuf(c, 10, tpc_part_cnt3_bytes(pl)))) return fail(c, -10, "out of device memory for the partition buffers");
         pl.buf2 = (uint32_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3]; pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
         pl.buf3 = (uint32_t *)c->pbuf[9]; pl.cnt3 = (uint32_t *)c->pbuf[10];
+        // Deferred apply (as on one GPU, section 3.2): a round whose insert is ONE batch stops after its level-2 binning, the regions kept
+        // aside (the query's plan reuses the shared ones), and the first lookup of the round's query builds every owned slice itself
+        // (k_apply_lookup on the shard): the shard is written once and not read back.  Room for the regions permitting.
+        c->sh_defer = false;
+        if (c->opt_fuse && per == per_total && pl.b3 == 0) {
+            const size_t want[2] = { tpc_part_buf2_bytes(pl), tpc_part_cnt2_bytes(pl) };
+            bool ok = true;
+            for (int i = 0; i < 2 && ok; i++) {
+                if (want[i] <= c->ikeep_bytes[i]) continue;
+                if (c->ikeep[i]) (void)hipFree(c->ikeep[i]);
+                c->ikeep[i] = nullptr; c->ikeep_bytes[i] = 0;
+                if (hipMalloc(&c->ikeep[i], want[i]) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+                c->ikeep_bytes[i] = want[i];
+            }
+            c->sh_defer = ok;
+        }
         geom[2] = tpc_part_buf1_bytes(pl) / W; geom[3] = tpc_part_cnt1_bytes(pl) / W;
         geom[4] = 0; geom[5] = pl.ovf_cap; geom[6] = 8;
         geom[7] = pl.slice_bits; geom[8] = pl.b1; geom[9] = pl.b2; geom[10] = pl.perm_mult; geom[11] = pl.perm_inv; geom[12] = pl.b3;
@@ -1710,7 +1737,7 @@ int shard_hash_impl(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t 
         pl.tile0 = t0; pl.n_tiles = n; pl.tile0_global = t0;  // positions in the entries are relative to this rank's batch
         pl.buf1 = (uint64_t *)send_regions; pl.cnt1 = (uint32_t *)send_counts;
         // (the hash does not read the filter; the lookup of tpc_shard_apply materialises a pending reset before it probes)
-        if (!async) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+        if (!async && !c->pending_apply) { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a deferred apply waits for the lookup)
         HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), st));
         if (!async) HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), st));  // (async: tpc_shard_apply zeroes the survivor cursors itself)
         // marks of this batch's survivors land anywhere in the batch, the hash kernel only rewrites this rank's tiles
@@ -1868,15 +1895,49 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
         pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
         pl.rbuf1 = (const uint32_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
         pl.rown1 = (const uint32_t *)own_regions; pl.rowncnt1 = (const uint32_t *)own_counts;
+        { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }  // (an earlier insert nobody looked up: OR on top of it)
+        const bool fresh = c->filter_zero_pending;
+        const bool defer = c->sh_defer && c->sh_batches[pass] == 1 && pl.b3 == 0;
+        if (defer) { pl.buf2 = (uint32_t *)c->ikeep[0]; pl.cnt2 = (uint32_t *)c->ikeep[1]; }
         {
             Timed t(c, TPC_K_SHARD_APPLY);
-            if (tpc_launch_insert_part_apply(make_launch(c), pl, c->filter_zero_pending)) return fail(c, -1, "apply launch failed");
+            if (defer ? tpc_launch_insert_part_split(make_launch(c), pl) : tpc_launch_insert_part_apply(make_launch(c), pl, fresh)) return fail(c, -1, "apply launch failed");
         }
-        c->filter_zero_pending = false;  // every owned slice has been written
         HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (ov[1]) return fail(c, -20, "overflow list overflowed (address skew beyond what the sharded path handles)");
+        if (defer) {
+            // the overflow entries (this rank's and the gathered ones of the others) grouped by local slice for the fused kernel; they also
+            // stay where they are, for an apply that has to be completed without a lookup (flush_pending_apply)
+            bool keep = ov[0] <= TPC_FUSE_MAX_OVF;
+            const uint32_t n_slices = (1u << (pl.b1 + pl.b2)) / pl.world;
+            if (keep && ov[0]) {
+                if (c->ikeep_ovf_cap < ov[0]) {
+                    if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
+                    c->ikeep_ovf = nullptr; c->ikeep_ovf_cap = 0;
+                    const uint64_t cap = std::max<uint64_t>(4096, ov[0] + ov[0] / 4);
+                    if (hipMalloc((void **)&c->ikeep_ovf, 2 * cap * sizeof(uint64_t)) == hipSuccess) c->ikeep_ovf_cap = cap; else { (void)hipGetLastError(); keep = false; }
+                }
+                if (keep && c->iovf_slices < n_slices) {
+                    if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
+                    if (c->iovf_off) (void)hipFree(c->iovf_off);
+                    c->iovf_cnt = nullptr; c->iovf_off = nullptr; c->iovf_slices = 0;
+                    if (hipMalloc((void **)&c->iovf_cnt, 2 * (size_t)n_slices * sizeof(uint32_t)) == hipSuccess &&
+                        hipMalloc((void **)&c->iovf_off, ((size_t)n_slices + 1) * sizeof(uint64_t)) == hipSuccess) c->iovf_slices = n_slices;
+                    else { (void)hipGetLastError(); keep = false; }
+                }
+                if (keep && tpc_launch_ovf_by_slice(make_launch(c), pl.ovf, ov[0], pl.slice_bits, n_slices, c->iovf_cnt, c->iovf_cnt + n_slices, c->iovf_off,
+                                                    c->ikeep_ovf + c->ikeep_ovf_cap, pl.rank, pl.world, pl.b2)) return fail(c, -1, "overflow grouping launch failed");
+            }
+            if (keep) { c->pending_apply = true; c->pending_shard = true; c->pending_fresh = fresh; c->pending_pl = pl; c->pending_novf = ov[0]; }
+            else {
+                Timed t(c, TPC_K_SHARD_APPLY);
+                if (tpc_launch_insert_part_apply_only(make_launch(c), pl, fresh)) return fail(c, -1, "apply launch failed");
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        c->filter_zero_pending = false;  // every owned slice has been (or is about to be) written
         if (n_survivors) *n_survivors = 0;
         return 0;
     }
@@ -1884,7 +1945,10 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
     pl.ovf = (uint64_t *)c->pbuf[alist]; pl.ovf_cur = (unsigned long long *)c->pbuf[alist + 1];
     pl.rbuf1 = (const uint64_t *)recv_regions; pl.rcnt1 = (const uint32_t *)recv_counts; pl.roff1 = roff1;
     pl.rown1 = (const uint64_t *)own_regions; pl.rowncnt1 = (const uint32_t *)own_counts;
-    { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a query whose hash ran ahead of the round's insert: tpc_shard_hash_begin)
+    // the deferred apply of this round's insert: the lookup builds the owned slices itself when the geometry still matches
+    const bool fused = c->pending_apply && c->pending_shard && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits && pl.b1 == c->pending_pl.b1 &&
+                       pl.b2 == c->pending_pl.b2 && pl.world == c->pending_pl.world && pl.fmt == 0 && c->pending_pl.fmt2 == 0;
+    if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }  // (a query whose hash ran ahead of the round's insert: tpc_shard_hash_begin)
     HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
     const uint64_t W = c->sh_world, per = c->sh_per[pass], tiles = text_tiles512(c);
     const uint64_t chunk = (tiles + W - 1) / W;
@@ -1893,7 +1957,12 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
     unsigned long long cur[65];
     {
         Timed t(c, TPC_K_SHARD_APPLY);
-        if (tpc_launch_query_part_lookup(make_launch(c), pl)) return fail(c, -1, "lookup launch failed");
+        if (fused) {
+            c->pending_apply = false; c->pending_shard = false;
+            c->stat_fused++;
+            if (tpc_launch_query_part_fused_lookup(make_launch(c), pl, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
+                                                   c->pending_novf ? c->iovf_off : nullptr)) return fail(c, -1, "fused lookup launch failed");
+        } else if (tpc_launch_query_part_lookup(make_launch(c), pl)) return fail(c, -1, "lookup launch failed");
     }
     HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cur, pl.surv_cur, sizeof cur, hipMemcpyDeviceToHost, c->stream));
@@ -1913,6 +1982,22 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
 }
 
 }  // namespace
+
+int tpc_shard_verify_local(tpc_ctx *c)
+{   // One rank: every survivor of the last tpc_shard_apply was hashed here and every probe address of functions 1..q-1 is owned
+    // here, so the single-GPU verification kernel runs on the survivor sub-lists as they are -- no gather, no routing, no answers.
+    if (!c || !c->sh_have[TPC_SHARD_QUERY]) return fail(c, -1, "tpc_shard_plan / tpc_shard_apply for the query first");
+    if (c->sh_world != 1) return fail(c, -1, "tpc_shard_verify_local needs a filter of one shard (world == 1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    if (c->sh_nsurv) {
+        Timed t(c, TPC_K_SHARD_APPLY);
+        if (tpc_launch_query_verify(make_launch(c), c->sh_qpl, c->rmask)) return fail(c, -1, "verify launch failed");
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 int tpc_shard_survivors(tpc_ctx *c, uint64_t *sid_dev)
 {

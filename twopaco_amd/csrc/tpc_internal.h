@@ -122,7 +122,7 @@ int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl,
 // iovf_sorted / iovf_off: the insert's overflow entries grouped by slice (tpc_launch_ovf_by_slice), or nullptr when there are none
 int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf_sorted, const uint64_t *iovf_off);  // k_q_split + k_apply_lookup + k_q_ovf
 int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n, int slice_bits, uint32_t n_slices, uint32_t *cnt, uint32_t *cursor,
-                            uint64_t *off, uint64_t *sorted);
+                            uint64_t *off, uint64_t *sorted, uint32_t rank = 0, uint32_t world = 1, int log_nb2 = 0);  // world > 1: local slices of this rank's shard
 #define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
 extern int tpc_test_q6_pb2;          // tpc_qpartition.hip: option "test_q6_pb2" (tests: position bits of a 6-byte level-2 entry, to get many groups on small inputs; process-wide)

@@ -662,20 +662,34 @@ __global__ void __launch_bounds__(1024) k_region_offsets(const uint32_t *__restr
 
 // The insert's overflow entries (permuted full addresses) in slice order for the fused apply + lookup kernel: count per slice,
 // offsets (k_region_offsets), scatter.  The order inside a slice does not matter (the bits are OR-ed).
-__global__ void __launch_bounds__(256) k_ovf_count(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, uint32_t *cnt)
+// (a sharded filter: the slice number is the LOCAL one, [local bucket][b2], and the entries of other ranks -- the list is the all-gathered
+//  one -- are left out: pt_local_addr)
+__device__ __forceinline__ bool ovf_slice(uint64_t a, int slice_bits, PtShard sh, int log_nb2, uint32_t &s)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&cnt[list[i] >> slice_bits], 1u);
+    const uint32_t sp = (uint32_t)(a >> slice_bits);
+    if (sh.world == 1) { s = sp; return true; }
+    const uint32_t b1 = sp >> log_nb2;
+    s = ((b1 >> sh.log_world()) << log_nb2) | (sp & ((1u << log_nb2) - 1u));
+    return (b1 & (sh.world - 1)) == sh.rank;
 }
 
-__global__ void __launch_bounds__(256) k_ovf_scatter(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, const uint64_t *__restrict__ off,
+__global__ void __launch_bounds__(256) k_ovf_count(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, PtShard sh, int log_nb2, uint32_t *cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t s;
+        if (ovf_slice(list[i], slice_bits, sh, log_nb2, s)) atomicAdd(&cnt[s], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ovf_scatter(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, PtShard sh, int log_nb2, const uint64_t *__restrict__ off,
                                                      uint32_t *cursor, uint64_t *__restrict__ sorted)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t a = list[i];
-        const uint64_t s = a >> slice_bits;
-        sorted[off[s] + atomicAdd(&cursor[s], 1u)] = a;
+        uint32_t s;
+        if (ovf_slice(a, slice_bits, sh, log_nb2, s)) sorted[off[s] + atomicAdd(&cursor[s], 1u)] = a;
     }
 }
 
@@ -865,14 +879,15 @@ int tpc_launch_region_pack(const TpcLaunch &a, const void *regions, uint64_t cap
 // list[0..n) -> sorted[0..n) grouped by slice (address >> slice_bits); off[s] .. off[s + 1] = the entries of slice s.
 // cnt and cursor: n_slices words each; off: n_slices + 1.
 int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n, int slice_bits, uint32_t n_slices, uint32_t *cnt, uint32_t *cursor,
-                            uint64_t *off, uint64_t *sorted)
-{
+                            uint64_t *off, uint64_t *sorted, uint32_t rank, uint32_t world, int log_nb2)
+{   // world > 1: n_slices local slices, entries of other ranks skipped (off[n_slices] = this rank's entries)
+    const PtShard sh{rank, world};
     if (hipMemsetAsync(cnt, 0, (size_t)n_slices * sizeof(uint32_t), a.stream) != hipSuccess ||
         hipMemsetAsync(cursor, 0, (size_t)n_slices * sizeof(uint32_t), a.stream) != hipSuccess) return -1;
     const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
-    if (n) hipLaunchKernelGGL(k_ovf_count, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, cnt);
+    if (n) hipLaunchKernelGGL(k_ovf_count, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, sh, log_nb2, cnt);
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, a.stream, cnt, n_slices, off);
-    if (n) hipLaunchKernelGGL(k_ovf_scatter, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, off, cursor, sorted);
+    if (n) hipLaunchKernelGGL(k_ovf_scatter, dim3(grid), dim3(256), 0, a.stream, list, n, slice_bits, sh, log_nb2, off, cursor, sorted);
     return 0;
 }
 #endif  // part 0

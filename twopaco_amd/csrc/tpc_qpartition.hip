@@ -754,8 +754,8 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
                const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
-               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group)
-{
+               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, PtShard sh)
+{   // sh.world > 1 (round 5): the owned slices of a sharded filter, compact layout [local bucket][b2] as k_part_apply / k_q_lookup write and read it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
@@ -765,7 +765,7 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     uint32_t *s_ctl = st.ctl;
     const uint32_t nb2 = 1u << log_nb2;
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
+    uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
     const bool wide = (words & 3u) == 0;
     // ---- apply (k_part_apply)
     if (fresh) {
@@ -1774,9 +1774,10 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 // the query, then k_apply_lookup over the insert's and the query's level-2 regions, then the overflow probes.
 int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, const uint64_t *iovf_off)
 {
-    if (pl.b3 || ipl.b3 || pl.world != 1 || ipl.world != 1 || pl.slice_bits != ipl.slice_bits || pl.b1 != ipl.b1 || pl.b2 != ipl.b2) return -1;
+    if (pl.b3 || ipl.b3 || pl.world != ipl.world || pl.rank != ipl.rank || pl.slice_bits != ipl.slice_bits || pl.b1 != ipl.b1 || pl.b2 != ipl.b2) return -1;
+    if (pl.world > 1 && (pl.fmt == 6 || ipl.fmt2 == 3)) return -1;  // (the sharded passes keep the power-of-two entries)
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
-    const PtShard sh{0, 1};
+    const PtShard sh{pl.rank, pl.world};
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     if (pl.fmt == 6) {
         launch_qsplit6(a, pl, ovf);
@@ -1796,15 +1797,15 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     }
     if (ipl.fmt2 == 3) return -1;  // the 8-byte lookup reads 32-bit insert entries (the caller plans both passes with the same format switch)
     {
-        launch_qsplit(a, false, pl.b1, pl.b2, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0,
-                      pl.roff1, (1u << pl.b1) * pl.wpb);
+        launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0,
+                      pl.roff1, ((1u << pl.b1) / pl.world) * pl.wpb, pl.rown1, pl.rowncnt1);
     }
     {
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_apply_lookup, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
-                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);
+        hipLaunchKernelGGL(k_apply_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
+                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
     return 0;

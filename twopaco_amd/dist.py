@@ -568,6 +568,11 @@ class AddressSharded:
         (tpc_shard_survivors_home / _verify_send / _finish).  Returns the survivor counts after every step."""
         torch, ctx, W = self.torch, self.ctx, self.world
         zeros = [0] * W
+        if W == 1 and not os.environ.get("TPC_VERIFY_ROUTED"):  # one rank: every survivor is home and every probe is owned here
+            self.comm.phase = "query batch %d: local verification" % b
+            self._try(ctx.shard_verify_local)
+            self._tick("query_verify_finish", t0)
+            return [n]
         self.comm.phase = "query batch %d: survivors home" % b
         # survivors go back to the rank that hashed their position (it rides in the id) and are verified there, where
         # their text is: a rank then needs only its own chunk of the packed text.  The library groups them by that rank.
@@ -870,7 +875,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     if decomposition == "auto":
         decomposition = "address" if pow2 and not injected else "ranges"
     address = decomposition == "address"
-    also_ranges = address and getattr(args, "decomposition", "auto") == "auto"  # both are timed at every N; the line's value is the faster one's
+    also_ranges = address and getattr(args, "decomposition", "auto") == "auto"  # both are timed at every N; the line's value is the address-sharded filter's, the ranges keep their record under "ranges"
     ctx = ctx_r = None
     sharded2 = False
     recs = None
@@ -1048,32 +1053,17 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         "collective_timeout_s": wd.timeout,
         "result": head["result"],
         "result_equals_reference_golden": True if golden else None,
+        # `value` is ONE decomposition at every N, so that the per-N values form a scaling curve of one design: the filter sharded by bit
+        # address (the north star's) unless --decomposition ranges was asked for.  The other one, when it was timed too, keeps its full
+        # record under the key "ranges" -- by the link model (README) it is the faster one below eight ranks.
+        "headline_decomposition": "address" if address else "ranges",
     }
     if second is not None:
         out["ranges"] = {"value": n_kmers * args.steps / second["dt"], "unit": "k-mers/s", "ms_per_step": second["dt"] / args.steps * 1e3,
                          "decomposition": "%d vertex-hash ranges, one per GPU, no data-path exchange (DESIGN.md section 5.1)" % world,
                          "kernel_ms_rank0": second["kms"], "result": second["result"]}
-        if second["dt"] < dt:
-            # Both decompositions were timed and checked at this N; the line's value is the faster one's and the other keeps its full
-            # record under its own name.  (Routing every hash hit to its owner pays where the links outnumber the work: by the link
-            # model of DESIGN.md section 6 it is a slowdown at two ranks and break-even at four.)
-            moved = ("value", "ms_per_step", "junction_occurrences_per_sec", "kernel_ms_rank0", "roofline", "exchange_bytes_rank0_per_step",
-                     "region_bytes_sent_rank0_per_step", "all_to_all_GBs_rank0", "region_exchange", "overflow_entries_rank0_per_step",
-                     "phase_ms_rank0_per_step", "survivors_rank0", "result")
-            out["address"] = dict({k: out.pop(k) for k in moved}, unit="k-mers/s", decomposition=out["config"]["parallelism"])
-            r = out.pop("ranges")
-            qms_r = max(r["kernel_ms_rank0"].get("query", 0.0), 1e-9)
-            design_r = 0.375 * n_kmers + 6 * n_kmers / world * 32 + fb
-            out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms_rank0": r["kernel_ms_rank0"], "result": r["result"],
-                        "junction_occurrences_per_sec": r["result"]["junction_occurrences"] * args.steps / second["dt"],
-                        "roofline": {"bound": "hbm", "kernel": "first-pass query on rank 0", "achieved": design_r / (qms_r * 1e-3) / 1e9, "peak": 8000.0,
-                                     "unit": "GB/s", "frac": design_r / (qms_r * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                                     "algorithmic_bytes_per_launch": design_r, "launch_ms": qms_r} if ctx is not None else None})
-            out["config"]["decomposition"] = "ranges"
-            out["config"]["parallelism"] = r["decomposition"]
-            out["config"]["headline"] = "the faster of the two decompositions timed at this N (the address-sharded filter's record: key 'address')"
     # the metric's second half at N GPUs: the C++ host end to end (`twopaco --gpus N`, host/multigpu.cpp: RCCL transport), fresh child
-    # processes on the FASTA files, output sha256 == the reference golden.  A failure here fails the run (no line).
+    # processes on the FASTA files, output sha256 == the reference golden.  A failure here is reported IN the line (e2e.error, e2e_failed = true, no end-to-end figure).
     if e2e is not None and recs is not None:
         time.sleep(2.0)  # the other ranks' processes are on their way out: let the driver have their device memory back
         try:
@@ -1090,6 +1080,19 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         else:
             out["e2e_junction_occurrences_per_sec"] = out["e2e"]["e2e_junction_occurrences_per_sec"]
             out["e2e_wall_s"] = out["e2e"]["e2e_wall_s"]
+            # the PRODUCT's host at this N (host/multigpu.cpp: C++, RCCL directly): its own timers, median of the CLI runs above, beside
+            # the torch.distributed driver's figures -- the first hardware curve must be readable for the host that ships
+            bd = out["e2e"].get("breakdown_ms") or {}
+            rounds_ms = bd.get("rounds_ms")
+            ph = out["e2e"].get("sharded_first_pass_ms_rank0") or {}
+            a2a_ms = sum(v for k, v in ph.items() if k.endswith("all-to-all"))
+            sent = out["e2e"].get("region_bytes_sent_rank0")
+            out["cxx_host"] = {"what": "twopaco --gpus %d (C++ host, one thread per GPU, RCCL send/recv groups), its own TWOPACO_TIMING figures, median run" % world,
+                               "rounds_ms": rounds_ms, "kmers_per_sec": (n_kmers / (rounds_ms * 1e-3)) if rounds_ms else None,
+                               "sharded_first_pass_ms_rank0": ph or None, "region_bytes_sent_rank0": sent,
+                               "all_to_all_GBs_rank0": (sent / (a2a_ms * 1e-3) / 1e9) if sent and a2a_ms > 0 else None,
+                               "runs": out["e2e"].get("runs")}
+        out["e2e_failed"] = "error" in out["e2e"]
     if cpu_baseline is not None and recs is not None:
         try:
             out["cpu_baseline"] = cpu_baseline(recs, p)

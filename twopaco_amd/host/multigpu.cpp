@@ -341,10 +341,11 @@ namespace TwoPaCo
 	{
 		if (!phaseOn) return;
 		std::fprintf(stderr, "[timing]     %s (rank 0, ms):", title);
-		for (auto & p : phaseMs) std::fprintf(stderr, " %s %.1f;", p.first.c_str(), p.second);
+		for (auto & p : phaseMs) std::fprintf(stderr, " %s %.3f;", p.first.c_str(), p.second);
 		size_t held = 0;
 		for (int i = 0; i < ShardedRank::BUFFERS; i++) held += cap[i];
-		std::fprintf(stderr, " exchange buffers held %.2f GB\n", double(held) / 1e9);
+		std::fprintf(stderr, " region bytes sent %llu; exchange buffers held %.2f GB\n", (unsigned long long)regionBytesSent, double(held) / 1e9);
+		regionBytesSent = 0;  // (per printed pass: the bench divides them by the pass' all-to-all time)
 		phaseMs.clear();
 	}
 
