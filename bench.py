@@ -62,7 +62,7 @@ def csrc_signature():
 
 
 def golden_case(workload, scale):
-    name = {("m2", 1.0): "m2_full", ("m1", 1.0): "m1_full"}.get((workload, scale))
+    name = {("m2", 1.0): "m2_full", ("m1", 1.0): "m1_full", ("m2r", 1.0): "m2r_full"}.get((workload, scale))
     path = os.path.join(ROOT, "tests", "golden", "cases.json")
     if not name or not os.path.exists(path):
         return None
@@ -84,14 +84,13 @@ def one_step(ctx, abundance=(1 << 64) - 1):
     return marks, st, J, n_valid
 
 
-def write_fasta_files(recs, tmp, n=None):
+def write_fasta_files(recs, tmp, n=None, p=None):
+    """One FASTA file per genome: a record each, or the genome's contigs (p["files"], workload m2r); n: the first n genomes only."""
     from twopaco_amd import synth
-    files = []
-    for i, r in enumerate(recs[:n]):
-        path = os.path.join(tmp, "g%d.fa" % i)
-        synth.write_fasta(path, [r], first_id=i)
-        files.append(path)
-    return files
+    pp = dict(p or {})
+    if n is not None:
+        pp["files"] = (pp.get("files") or [(i, i + 1) for i in range(len(recs))])[:n]
+    return synth.fasta_files(recs, pp, tmp)
 
 
 def sha256_file(path):
@@ -187,10 +186,12 @@ def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
     from twopaco_amd import synth
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "twopaco_ref")
-    sample = recs if mode == "full" else recs[:6]
+    groups = p.get("files") or [(i, i + 1) for i in range(len(recs))]
+    n_genomes = len(groups) if mode == "full" else min(6, len(groups))
+    sample = recs[:groups[n_genomes - 1][1]]
     kmers = synth.n_kmers(sample, p["k"])
     if os.path.exists(ref):
-        files = write_fasta_files(sample, tmp)
+        files = write_fasta_files(recs, tmp, n=n_genomes, p=p)
 
         def run(fs, L, to):
             cmd = [ref, "-k", str(p["k"]), "-f", str(L), "-q", str(p["q"]), "-t", str(cores), "--tmpdir", tmp, "-o", os.path.join(tmp, "ref.bin")] + fs
@@ -219,7 +220,7 @@ def cpu_baseline(recs, p, tmp, mode="sample", timeout=240):
             out = {"value": kmers / wall, "unit": "k-mers/s", "cores": cores, "kind": "reference",
                    "sample": "%s of the workload (%d genomes, %d k-mers), k=%d q=%d f=%d, reference binary -t %d, wall %.1f s "
                              "(its log: fill %s s incl. serial filter zeroing, query %s s); %d junction occurrences"
-                             % ("all" if mode == "full" else "first 6 genomes", len(sample), kmers, p["k"], p["q"], L, cores, wall,
+                             % ("all" if mode == "full" else "first 6 genomes", n_genomes, kmers, p["k"], p["q"], L, cores, wall,
                                 m.group(1) if m else "?", m.group(2) if m else "?", occ),
                    "junction_occurrences_per_sec": occ / wall, "wall_s": wall}
             if fixed is not None and L == p["L"]:
@@ -246,7 +247,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="m2")
+    ap.add_argument("--workload", default="m2", help="m2 (the headline: BASELINE configs[2]), m1, m3, or m2r = m2 with repeat families, low-complexity tracts, "
+                                                      "two reverse-complemented genomes and 50-300 contigs per genome (synth.py)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--test-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -289,7 +291,7 @@ def main():
             def e2e(recs, p, gpus):
                 tmp = tempfile.mkdtemp(prefix="tpc_bench_")
                 try:
-                    return e2e_cli(write_fasta_files(recs, tmp), p, golden_case(args.workload, args.scale), min(args.e2e_runs, 3), tmp, gpus=gpus,
+                    return e2e_cli(write_fasta_files(recs, tmp, p=p), p, golden_case(args.workload, args.scale), min(args.e2e_runs, 3), tmp, gpus=gpus,
                                    settle_s=args.e2e_settle)
                 finally:
                     shutil.rmtree(tmp, ignore_errors=True)
@@ -326,6 +328,8 @@ def main():
     dt = time.perf_counter() - t0
     kms = {n: v / args.steps for n, v in kms.items()}
     fused = ctx.stat("fused_lookups") - fused0 == args.steps  # deferred apply: the query's lookup built the filter slices
+    paths = {"insert_path": ctx.stat("insert_path"), "query_path": ctx.stat("query_path"), "insert_overflow_entries": ctx.stat("insert_overflow_entries"),
+             "query_overflow_entries": ctx.stat("query_overflow_entries"), "insert_batches": ctx.stat("insert_batches"), "query_batches": ctx.stat("query_batches")}
     # bytes per level-2 entry as the passes ran them (tpc_binsp.h: 48-bit query entries in lines of 20, 24-bit insert entries in lines of 40)
     q_l2_bytes = 128 / 20 if ctx.stat("query_entry_fmt") == 6 else 8.0
     i_l2_bytes = 128 / 40 if ctx.stat("insert_entry_fmt") == 3 else 4.0
@@ -395,14 +399,18 @@ def main():
         "metric": "kmers_hashed_per_sec", "value": n_kmers * args.steps / dt, "unit": "k-mers/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py), k=%d q=%d f=%d, 1 round"
-                               % (args.workload, len(recs), recs[0].size, p["k"], p["q"], p["L"]),
+        "config": {"workload": "%s: %d genomes x %d bp E. coli-like synthetic (twopaco_amd/synth.py)%s, k=%d q=%d f=%d, 1 round"
+                               % (args.workload, len(p.get("files") or recs), sum(r.size for r in recs) // len(p.get("files") or recs),
+                                  " in %d records (repeat families, low-complexity tracts, two genomes reverse-complemented)" % len(recs) if p.get("files") else "",
+                                  p["k"], p["q"], p["L"]),
                    "kmers": n_kmers, "filter_bytes": filter_bytes, "insert_test_first": args.test_first, "decomposition": "single GPU",
                    "apply_fused_into_lookup": fused, "query_level2_entry_bytes": q_l2_bytes, "insert_level2_entry_bytes": i_l2_bytes},
         "junction_occurrences_per_sec": n_valid * args.steps / dt,
         "insert_kmers_per_sec": n_kmers / (ins_ms * 1e-3),
         "query_kmers_per_sec": n_kmers / (qry_ms * 1e-3),
         "kernel_ms": kms,
+        "paths": paths,  # 2 = partitioned with two levels, +10 = completed by the direct kernel; entries that went the overflow lists' way (last step)
+        "ps_per_kmer": dt / args.steps / n_kmers * 1e12,
         "insert_ms_with_its_share_of_fused": ins_ms, "query_ms_without_it": qry_ms,
         "result": result,
         "result_equals_reference_golden": result_ok,
@@ -415,7 +423,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tpc_bench_")
     try:
         if args.e2e_runs > 0:
-            files = write_fasta_files(recs, tmp)
+            files = write_fasta_files(recs, tmp, p=p)
             time.sleep(args.e2e_settle)  # this process's own context (60 GB) has just been closed
             out["e2e"] = e2e_cli(files, p, golden, args.e2e_runs, tmp, settle_s=args.e2e_settle)
             if "error" in out["e2e"]:

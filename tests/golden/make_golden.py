@@ -205,18 +205,18 @@ def main():
     for name, wl, scale, L, thr in [("m1_small", "m1", 0.02, 26, 1), ("m1_full", "m1", 1.0, None, 1), ("m2_small", "m2", 0.004, 26, 1),
                                     ("m2_full", "m2", 1.0, None, 3), ("m2_s05_f38", "m2", 0.05, 38, 3), ("m3_f38", "m3", 1.0, None, 4),
                                     # m2_x15 = the bench workload with 15 x longer genomes: 4.65 G text positions, beyond 2^32 (hours of reference time)
-                                    ("m2_x15", "m2", 15.0, None, 6)]:
+                                    ("m2_x15", "m2", 15.0, None, 6),
+                                    # m2r = m2 with repeat families, low-complexity tracts, two genomes on the other strand and 50-300 contigs per
+                                    # genome (round 5: address skew, hot exact-filter keys, the stub / separator path at full size)
+                                    # -t 1: the stub ids of sequence ends come from a shared counter in the order the worker threads reach them
+                                    # (VE.h:945-947) -- with 10 149 records the bytes of a multi-threaded run depend on the scheduling
+                                    ("m2r_small", "m2r", 0.02, 26, 1), ("m2r_full", "m2r", 1.0, None, 1)]:
         if only is not None and name not in only:
             continue
 
         def files(name=name, wl=wl, scale=scale):
-            recs, _ = synth.workload(wl, seed=12345, scale=scale)
-            out = []
-            for i, r in enumerate(recs):
-                path = os.path.join(tmp, "%s_%d.fa" % (name, i))
-                synth.write_fasta(path, [r], first_id=i)
-                out.append(path)
-            return out
+            recs, pp = synth.workload(wl, seed=12345, scale=scale)
+            return synth.fasta_files(recs, pp, tmp, prefix=name + "_")
         p = synth.workload(wl, seed=12345, scale=0.0001)[1]
         case(name, None, p["k"], L or p["L"], q=p["q"], keep_bin=False, synth_spec={"workload": wl, "seed": 12345, "scale": scale}, files=files, threads=thr)
 

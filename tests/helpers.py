@@ -10,7 +10,7 @@ GOLDEN = os.path.join(HERE, "golden")
 
 
 # full-size synthetic workloads: minutes of work and GiBs of filter each -- dedicated tests, not the parametrised sweeps
-BIG = ("m1_full", "m2_full", "m2_s05_f38", "m3_f38", "m2_x15")
+BIG = ("m1_full", "m2_full", "m2_s05_f38", "m3_f38", "m2_x15", "m2r_full")
 
 
 def golden_cases():
@@ -24,13 +24,8 @@ def case_files(case, tmpdir):
         return [os.path.join(GOLDEN, case["fasta"])]
     from twopaco_amd import synth
     s = case["synth"]
-    recs, _ = synth.workload(s["workload"], seed=s["seed"], scale=s["scale"])
-    files = []
-    for i, r in enumerate(recs):
-        path = os.path.join(str(tmpdir), "%s_%d.fa" % (case["name"], i))
-        synth.write_fasta(path, [r], first_id=i)
-        files.append(path)
-    return files
+    recs, p = synth.workload(s["workload"], seed=s["seed"], scale=s["scale"])
+    return synth.fasta_files(recs, p, tmpdir, prefix=case["name"] + "_")  # one record per file, or a genome's contigs per file (m2r)
 
 
 def sha256_file(path):

@@ -111,8 +111,8 @@ def test_m1_full_four_emulated_ranks(capi, tmp_path):
 
 @pytest.mark.parametrize("name,ranks", [("rand6_k25_q3", 4), ("m2_small", 2)])
 def test_emulated_ranks_equal_block_exchange(capi, tmp_path, name, ranks, monkeypatch):
-    """The equal-block exchange of the level-1 regions (testing knob TWOPACO_EQUAL_EXCHANGE) gives the same bytes as the
-    default exact-size exchange covered by test_emulated_ranks_write_reference_bytes."""
+    """The equal-block exchange of the level-1 regions forced on (TWOPACO_EQUAL_EXCHANGE; it is the default below eight ranks, the
+    exact-size packed exchange from eight on) gives the same bytes as the runs of test_emulated_ranks_write_reference_bytes."""
     monkeypatch.setenv("TWOPACO_EQUAL_EXCHANGE", "1")
     case = CASES[name]
     out = str(tmp_path / "mg.bin")

@@ -773,6 +773,29 @@ def test_beyond_2_32_positions_m2_x15_bytes_equal_reference(capi, tmp_path):
     e.close()
 
 
+def test_m2r_full_size_bytes_equal_reference(capi, tmp_path):
+    """The bench workload made less kind (synth.workload("m2r"): 20 repeat families of 1-5 kbp at 5-50 copies per genome, poly-A /
+    dinucleotide tracts, two genomes reverse-complemented, 10 149 contigs in 62 files) against the real reference binary: sha256 of
+    de_bruijn.bin and every log counter.  High-multiplicity k-mers (a family k-mer occurs ~1700 times), hot exact-filter keys, the
+    stub / separator path at full size, and the partitioned passes must complete on their own (no direct-kernel completion)."""
+    case = [c for c in CASES if c["name"] == "m2r_full"]
+    if not case:
+        pytest.skip("golden m2r_full not generated yet (tests/golden/make_golden.py --only m2r_full)")
+    case = case[0]
+    out = str(tmp_path / "m2r.bin")
+    files = case_files(case, tmp_path)
+    e = capi.Enumerator(files, case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out, seed=case["seed"], threads=64)
+    for f in files:
+        os.unlink(f)
+    assert os.path.getsize(out) == case["bin_bytes"]
+    log = parse_log(e.log)
+    assert log["rounds"] == case["rounds"] and log["true_marks"] == case["true_marks"]
+    assert e.vertices_count() == case["distinct"]
+    assert sha256_file(out) == case["bin_sha256"]
+    os.unlink(out)
+    e.close()
+
+
 def test_naive_positions_seed_free(capi, tmp_path):
     """Random seeds (like the reference's own --test, test.cpp:163-254): positions == naive oracle."""
     fa = os.path.join(GOLDEN, "rand6.fa")

@@ -22,6 +22,15 @@
 // flush pads every bin's last group with the all-ones sentinel, full regions hand their entries to lost().
 #pragma once
 #include "tpc_bins.h"
+#include <type_traits>
+#include <utility>
+
+// A `lost` handler may offer reserve(n) -> first of n consecutive places and put(bin, value, place): the flush then hands a whole ring
+// group that found its region full to the overflow list with ONE global atomic instead of one per entry (round 5: a slice that holds
+// the k-mers of a repeat family fills its region; 1.9 M + 3.2 M entries per step of the 62-genome text with repeat families went
+// through a single cursor, ~12 ns each).  Plain callables (bin, value) keep working.
+template <class L, class = void> struct pt_bulk : std::false_type {};
+template <class L> struct pt_bulk<L, std::void_t<decltype(std::declval<L &>().reserve(0u))>> : std::true_type {};
 
 template <class T, int THREADS = 1024, int DEBUG = 0>
 struct Bins3 {
@@ -203,11 +212,19 @@ struct Bins3 {
                 const uint32_t valid = (x >> 8) & 63u, owner_lane = x & 63u;
                 const bool over = (x >> 31) != 0;
                 const uint32_t b = ((wave << 6) + owner_lane) >> LOG_GPB;
+                unsigned long long place = 0;
+                if constexpr (pt_bulk<Lost>::value) {
+                    if (over) {  // (the 8 lanes of a group take this branch together)
+                        if (l == 0) place = lost.reserve(valid);
+                        place = __shfl(place, (int)(lane & ~7u), 64);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < EPL; e++) {
                     if (l * EPL + e >= valid) u.e[e] = SENT;
                     else if (over) {
-                        lost(b, u.e[e]);
+                        if constexpr (pt_bulk<Lost>::value) lost.put(b, u.e[e], place + l * EPL + e);
+                        else lost(b, u.e[e]);
 #ifdef TPC_BINS3_DEBUG
                         if (dbg) atomicAdd(dbg + 1, 1ull);
 #endif
@@ -239,3 +256,4 @@ struct Bins3 {
         }
     }
 };
+

@@ -305,6 +305,12 @@ struct BinsP {
                 asm volatile("" : "+v"(x));
                 const uint32_t nv = (x >> 8) & 63u, owner_lane = x & 63u;
                 const uint32_t b = ((wave << 6) + owner_lane) >> LOG_GPB;
+                if constexpr (pt_bulk<LostAt>::value) {  // one reservation per group (tpc_bins3.h:pt_bulk; the 8 lanes of a group are here together)
+                    unsigned long long place = 0;
+                    if (l == 0) place = lost_at.reserve(nv);
+                    place = __shfl(place, (int)(lane & ~7u), 64);
+                    for (uint32_t e = l; e < nv; e += 8u) lost_at.put(b, F::load(grp, e), place + e);
+                } else
                 for (uint32_t e = l; e < nv; e += 8u) lost_at(b, F::load(grp, e), rline * (uint32_t)GROUP + e);
             }
         }
@@ -317,7 +323,11 @@ struct BinsP {
         if (lane == 0) __hip_atomic_store(&done()[wave], flushes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     template <bool FINAL, class Lost>
-    __device__ __forceinline__ void flush(Lost lost) { flush_with<FINAL, false>([&](uint32_t b, T v, uint32_t) { lost(b, v); }, [](uint32_t, uint32_t) {}); }
+    __device__ __forceinline__ void flush(Lost lost)
+    {
+        if constexpr (pt_bulk<Lost>::value) flush_with<FINAL, false>(lost, [](uint32_t, uint32_t) {});
+        else flush_with<FINAL, false>([&](uint32_t b, T v, uint32_t) { lost(b, v); }, [](uint32_t, uint32_t) {});
+    }
 
     // idx(b): position of bin b's EXACT entry count in `out`; call after the final flush, by all threads
     template <class Idx>

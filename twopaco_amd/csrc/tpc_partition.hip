@@ -418,7 +418,16 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     const int shift1 = L - LOG_NB1;
     auto addr_of = [=](uint32_t b2, uint32_t val) { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; };
-    auto lost = [=](uint32_t b2, uint32_t val) { ovf.push(addr_of(b2, val)); };
+    // entries that found no room: one at a time from a push, a whole ring group with one reservation from a flush (tpc_bins3.h:pt_bulk)
+    struct Lost2 {
+        Overflow ovf; uint32_t b1; int shift1, slice_bits;
+        __device__ __forceinline__ uint64_t addr(uint32_t b2, uint32_t val) const { return ((uint64_t)b1 << shift1) | ((uint64_t)b2 << slice_bits) | val; }
+        __device__ __forceinline__ void operator()(uint32_t b2, uint32_t val) const { ovf.push(addr(b2, val)); }
+        __device__ __forceinline__ unsigned long long reserve(uint32_t n) const { return atomicAdd(ovf.cursor, (unsigned long long)n); }
+        __device__ __forceinline__ void put(uint32_t b2, uint32_t val, unsigned long long at) const { if (at < ovf.cap) ovf.list[at] = addr(b2, val); else ovf.cursor[1] = 1ull; }
+    };
+    const Lost2 lost{ovf, b1, shift1, slice_bits};
+    (void)addr_of;
     {
         if constexpr (P3) {
             const uint32_t cl = (uint32_t)(cap2 / PFmt3::GROUP);  // lines per region
@@ -470,7 +479,16 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
                     uint32_t bb[LOADS / 2], val[LOADS / 2];
                     bool ok[LOADS / 2];
 #pragma unroll
-                    for (int i = 0; i < LOADS / 2; i++) { ok[i] = valid(x0, h + i) && cur[h + i] != PT_SENT; bb[i] = cur[h + i] >> slice_bits; val[i] = cur[h + i] & slice_mask; }
+                    for (int i = 0; i < LOADS / 2; i++) {
+                        // An entry equal to its left neighbour's (the lane before holds the entry before in the region) is dropped: OR is
+                        // idempotent, and a low-complexity tract -- poly-A: the same five addresses for hundreds of positions in a row --
+                        // otherwise arrives as a burst of identical entries that fills its bin's ring inside the round (the 62-genome text
+                        // with such tracts: 1.9 M entries per step took the overflow list's way, k_part_split 2.4 -> 4.3 ms).  One DPP
+                        // move and a compare; lane 0 of a row of 16 has no neighbour and keeps its entry.
+                        const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)~cur[h + i], (int)cur[h + i], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+                        ok[i] = valid(x0, h + i) && cur[h + i] != PT_SENT && left != cur[h + i];
+                        bb[i] = cur[h + i] >> slice_bits; val[i] = cur[h + i] & slice_mask;
+                    }
                     bins.template push_batch<LOADS / 2>(bb, val, ok, lost);
                 }
                 bins.template flush<false>(lost);
@@ -676,9 +694,22 @@ __device__ __forceinline__ bool ovf_slice(uint64_t a, int slice_bits, PtShard sh
 __global__ void __launch_bounds__(256) k_ovf_count(const uint64_t *__restrict__ list, uint64_t n, int slice_bits, PtShard sh, int log_nb2, uint32_t *cnt)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t s;
-        if (ovf_slice(list[i], slice_bits, sh, log_nb2, s)) atomicAdd(&cnt[s], 1u);
+    // neighbours in the list mostly share their slice (a ring group that found its region full is appended as one run): a run inside
+    // the wave costs ONE atomic -- the entries of a hot slice otherwise queue up on its counter (2.5 ms for 1.9 M entries)
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint64_t i = i0 + (threadIdx.x & 63u);
+        uint32_t s = 0xFFFFFFFFu;
+        const bool mine = i < n && ovf_slice(list[i], slice_bits, sh, log_nb2, s);
+        if (!mine) s = 0xFFFFFFFFu;
+        const uint32_t prev = __shfl_up(s, 1, 64);
+        const bool head = (threadIdx.x & 63u) == 0u || prev != s;
+        const unsigned long long hm = __ballot(head);
+        if (mine && head) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
+            const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+            atomicAdd(&cnt[s], len);
+        }
     }
 }
 
@@ -686,10 +717,26 @@ __global__ void __launch_bounds__(256) k_ovf_scatter(const uint64_t *__restrict_
                                                      uint32_t *cursor, uint64_t *__restrict__ sorted)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t a = list[i];
-        uint32_t s;
-        if (ovf_slice(a, slice_bits, sh, log_nb2, s)) sorted[off[s] + atomicAdd(&cursor[s], 1u)] = a;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {  // runs of one slice: one atomic (k_ovf_count)
+        const uint64_t i = i0 + (threadIdx.x & 63u);
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint64_t a = i < n ? list[i] : 0ull;
+        uint32_t s = 0xFFFFFFFFu;
+        const bool mine = i < n && ovf_slice(a, slice_bits, sh, log_nb2, s);
+        if (!mine) s = 0xFFFFFFFFu;
+        const uint32_t prev = __shfl_up(s, 1, 64);
+        const bool head = lane == 0u || prev != s;
+        const unsigned long long hm = __ballot(head);
+        const unsigned long long below = hm & ((2ull << lane) - 1ull);       // heads at or below me: the highest is my run's
+        const uint32_t hl = 63u - (uint32_t)__clzll((long long)below);
+        uint32_t base = 0;
+        if (mine && head) {
+            const unsigned long long above = lane == 63u ? 0ull : (hm >> (lane + 1u));
+            const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+            base = atomicAdd(&cursor[s], len);
+        }
+        base = __shfl(base, (int)hl, 64);
+        if (mine) sorted[off[s] + base + (lane - hl)] = a;
     }
 }
 

@@ -62,7 +62,7 @@ k_q_lookup6(int slice_bits, int log_nb2, uint32_t wpb, const unsigned char *__re
     if (threadIdx.x == 0) st.ctl[0] = 0;
     const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
     st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
     st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     const Q6Res res{s_bnd, n_groups, pb2};
     for (uint32_t j = 0; j < wpb; j++) {
@@ -145,7 +145,7 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
     // ---- lookup against the slice still in LDS
     const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
     st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
     st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     const Q6Res res{s_bnd, n_groups, pb2};
     auto probe = [&](uint64_t v, uint32_t idx) {

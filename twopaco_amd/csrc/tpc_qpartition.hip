@@ -469,13 +469,37 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
     // (P6) An entry that found no room -- its ring full at the push, or its region full at a flush -> the overflow list's {full
     // permuted address, survivor id = edge | position << 3}.  Every snapshot empties the rings (below), so whatever sits in a ring
     // belongs to the zone at hand, next_g - 1, whose entries are of that group or the one below: the parity bit says which.
-    auto lost_p6 = [&](uint32_t b2, uint64_t val) {
-        const uint32_t z = next_g - 1u;
-        const uint64_t plow = (val >> (S6 + 3u)) & ((1ull << PB2) - 1ull);
-        const uint64_t g = (z & 1u) == ((uint32_t)(val >> 47) & 1u) ? z : z - 1u;
-        ovf.push(((uint64_t)b1 << shift1) | ((uint64_t)b2 << S6) | (val & ((1ull << S6) - 1ull)), ((val >> S6) & 7ull) | (((g << PB2) | plow) << 3), 3);
+    // (both handlers: one entry at a time from a push, a whole ring group with ONE reservation from a flush -- tpc_bins3.h:pt_bulk)
+    struct Lost6 {
+        QOverflow ovf; const uint32_t *next_g; uint32_t b1, S6, PB2; int shift1;
+        __device__ __forceinline__ void pair(uint32_t b2, uint64_t val, uint64_t &addr, uint64_t &sid) const
+        {
+            const uint32_t z = *next_g - 1u;
+            const uint64_t plow = (val >> (S6 + 3u)) & ((1ull << PB2) - 1ull);
+            const uint64_t g = (z & 1u) == ((uint32_t)(val >> 47) & 1u) ? z : z - 1u;
+            addr = ((uint64_t)b1 << shift1) | ((uint64_t)b2 << S6) | (val & ((1ull << S6) - 1ull));
+            sid = ((val >> S6) & 7ull) | (((g << PB2) | plow) << 3);
+        }
+        __device__ __forceinline__ void operator()(uint32_t b2, uint64_t val) const { uint64_t a, i; pair(b2, val, a, i); ovf.push(a, i, 3); }
+        __device__ __forceinline__ unsigned long long reserve(uint32_t n) const { return atomicAdd(ovf.cursor, (unsigned long long)n); }
+        __device__ __forceinline__ void put(uint32_t b2, uint64_t val, unsigned long long at) const
+        {
+            uint64_t a, i;
+            pair(b2, val, a, i);
+            if (at < ovf.cap) { ovf.list[2 * at] = a; ovf.list[2 * at + 1] = i; } else ovf.cursor[1] = 1ull;
+        }
     };
-    auto lost = [=](uint32_t, uint64_t val) { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); };
+    const Lost6 lost_p6{ovf, &next_g, b1, S6, PB2, shift1};
+    struct Lost8 {
+        QOverflow ovf; uint32_t b1; int shift1; uint64_t rem_mask;
+        __device__ __forceinline__ void operator()(uint32_t, uint64_t val) const { ovf.push(((uint64_t)b1 << shift1) | (val & rem_mask), val >> QE_E_SHIFT, 3); }
+        __device__ __forceinline__ unsigned long long reserve(uint32_t n) const { return atomicAdd(ovf.cursor, (unsigned long long)n); }
+        __device__ __forceinline__ void put(uint32_t, uint64_t val, unsigned long long at) const
+        {
+            if (at < ovf.cap) { ovf.list[2 * at] = ((uint64_t)b1 << shift1) | (val & rem_mask); ovf.list[2 * at + 1] = val >> QE_E_SHIFT; } else ovf.cursor[1] = 1ull;
+        }
+    };
+    const Lost8 lost{ovf, b1, shift1, rem_mask};
     // (P6) the snapshot: a FINAL-type flush -- every bin's last line goes out partly filled, the next entry starts a new line -- that
     // records, for the groups [lo, hi) it opens, where their zone starts (bnd, a whole number of lines) and, for the zone it closes,
     // where its entries end (vend: what follows up to the next line is garbage).  No entry ever waits in a ring across a boundary.
@@ -483,7 +507,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
       if constexpr (P6) {
         const uint32_t ng = n_groups;
         uint32_t *mb0 = my_bnd;  // per region: n_groups zone starts, then n_groups zone ends
-        bins.template flush_with<true, false>([&](uint32_t b2, uint64_t val, uint32_t) { lost_p6(b2, val); },
+        bins.template flush_with<true, false>(lost_p6,
             [lo, hi, ng, mb0](uint32_t b, uint32_t n) {
                 const uint32_t padded = (n + (uint32_t)PFmt6::GROUP - 1u) / (uint32_t)PFmt6::GROUP * (uint32_t)PFmt6::GROUP;
                 uint32_t *mb = mb0 + (uint64_t)b * 2u * ng, *mv = mb + ng;
@@ -552,13 +576,16 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
                     }
                     bins.template push_batch<LOADS>(bb, v6, ok, lost_p6);
                     bins.template flush<false>(lost_p6);
+
                     // is the NEXT round the first of a region that may hold groups without a boundary yet?  Then they start here.
                     if (r + 1 < n_seg && x1.base == 0u) {
                         const uint32_t gm = min(gmax(j + x1.t * wpb), n_groups - 1u);
                         if (gm >= next_g) snapshot(next_g, gm + 1u);
                     }
                 } else if constexpr (RB) bins.template push_batch<LOADS>(bb, cur, ok, reg, lost);
-                else { bins.template push_batch<LOADS>(bb, cur, ok, lost); bins.template flush<false>(lost); }
+                else {
+                    bins.template push_batch<LOADS>(bb, cur, ok, lost); bins.template flush<false>(lost);
+                }
                 x0 = x1; x1 = x2; r++;
             };
             while (true) {
@@ -611,7 +638,7 @@ struct SurvStage {
     uint32_t *hist;    // [QL_BUCKETS]
     uint32_t *scan;    // [32]
     uint32_t *ctl;     // [0] staged count, [2..3] flush base
-    uint64_t *my_list;
+    uint64_t *my_list, *surv0;  // the sub-list at hand, sub-list 0
     unsigned long long *surv_cur;
     uint64_t surv_cap;
     int list, shift;   // bucket = slice offset >> shift
@@ -690,6 +717,9 @@ struct SurvStage {
             if (threadIdx.x == 0) ctl[0] = 0;
         }
         __syncthreads();
+        // the next flush appends to another sub-list: a slice with hot addresses (a repeat family's k-mers: thousands of survivors) would
+        // otherwise put all of them into ONE of the 64 lists (the 62-genome text with repeat families: the fullest list held 27 M of 257 M)
+        if (m) { list = (list + 17) & (QS_LISTS - 1); my_list = surv0 + (uint64_t)list * surv_cap; }
     }
     // after a region: flush once the staging area is more than half full
     template <class Res = SurvIdentity>
@@ -722,7 +752,7 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     __syncthreads();
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
     st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     for (uint32_t j = 0; j < wpb; j++) {
         const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
@@ -802,7 +832,7 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     // ---- lookup (k_q_lookup) against the slice still in LDS
     const uint32_t slice_mask = (1u << slice_bits) - 1u;
     st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap;
+    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
     st.surv_cur = surv_cur; st.surv_cap = surv_cap;
     for (uint32_t j = 0; j < qwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
@@ -1621,7 +1651,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     const double avg1t = avg1 * pt_bucket_peak(pm, F, pl.b1);  // tight, as in tpc_part_plan_sharded: every query address is a function-0 address
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
-    pl.surv_cap = (uint64_t)((double)n_text * 0.6 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over
+    pl.surv_cap = (uint64_t)((double)n_text * 1.0 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over (repeat-rich input: 0.83 survivors per position)
     // Region sizes of the LAST level: a region is one filter slice, and every query address is a function-0
     // address whose density over the slices falls linearly from 2x to 0 (tpc_bins.h).  With three levels the
     // middle regions each collect 2^b3 slices spread over the whole filter by the permutation: uniform.

@@ -171,9 +171,12 @@ class PhaseWatchdog:
             t = threading.Thread(target=self._run, name="tpc-dist-watchdog", daemon=True)
             t.start()
 
-    def enter(self, phase):
+    def enter(self, phase, scale=1.0):
+        """scale: multiple of the limit for phases that also wait for a peer's SETUP (workload synthesis, context creation, the
+        lazy RCCL communicator of the first collective): TPC_DIST_SETUP_TIMEOUT_S (default 5 x the limit) for the first barrier."""
         with self._lock:
-            self._phase, self._deadline = phase, time.monotonic() + self.timeout
+            self._phase, self._deadline = phase, time.monotonic() + self.timeout * scale
+            self._started = time.time()
 
     def leave(self):
         with self._lock:
@@ -187,7 +190,8 @@ class PhaseWatchdog:
                 phase, deadline = self._phase, self._deadline
             if deadline is not None and time.monotonic() > deadline:
                 sys.stderr.write("twopaco_amd.dist: rank %d: collective phase '%s' exceeded TPC_DIST_TIMEOUT_S = %g s "
-                                 "(a peer never arrived): exiting with code %d\n" % (self.rank, phase, self.timeout, self.EXIT_CODE))
+                                 "(entered at %s; a peer never arrived): exiting with code %d\n" % (
+                                     self.rank, phase, self.timeout, time.strftime("%H:%M:%S", time.localtime(getattr(self, "_started", 0))), self.EXIT_CODE))
                 sys.stderr.flush()
                 os._exit(self.EXIT_CODE)
 
@@ -377,6 +381,20 @@ class _Comm:
             return out
         finally:
             self._leave()
+
+    def sum_ints(self, values):
+        """Element-wise sum over the ranks (the failure flag is agreed separately: a max)."""
+        torch = self.torch
+        self._enter("all_reduce(sum)")
+        try:
+            v = torch.as_tensor(list(values), dtype=torch.int64)
+            v = v.to(self.device) if self.direct else v
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+            out = [int(x) for x in v.cpu().tolist()]
+        finally:
+            self._leave()
+        self.max_ints([])  # agreement: every rank learns of a failed peer before the next payload moves
+        return out
 
     def max_ints(self, values):
         """Element-wise maximum over the ranks; this rank's failure flag rides along as one more element (agreement)."""
@@ -686,7 +704,7 @@ class AddressSharded:
             trace = (self._verify if self.fused else self._verify_unfused)(b, n, t0)
             survivors.append(trace)
             if len(trace) > 2 and not hasattr(self, "_fn1_pass_rate"):  # a lazy batch was measured: survivors of function 1 / first-probe survivors, all ranks
-                tot = self.comm.max_ints([trace[1], trace[0]])  # (max over ranks: a decision every rank takes alike)
+                tot = self.comm.sum_ints([trace[1], trace[0]])  # (sums over the ranks, as host/multigpu.cpp: both hosts take the same decision on the same input)
                 self._fn1_pass_rate = tot[0] / max(tot[1], 1)
         self.stats["survivors"] = survivors
         if not union:
@@ -931,8 +949,13 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     wd = PhaseWatchdog(rank)  # the bench's own barriers and reductions (the exchanges inside a step have theirs in _Comm)
     names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "shard_hash", "shard_apply"]
 
+    setup_scale = float(os.environ.get("TPC_DIST_SETUP_TIMEOUT_S", str(5 * wd.timeout))) / max(wd.timeout, 1e-9) if wd.timeout > 0 else 1.0
+    first = [True]
+
     def guarded(name, fn, *a, **kw):
-        wd.enter(name)
+        # the first guarded collective also waits for the slowest rank's setup (synthesis of the workload, context, the lazy communicator)
+        wd.enter(name, setup_scale if first[0] else 1.0)
+        first[0] = False
         try:
             return fn(*a, **kw)
         finally:

@@ -10,6 +10,11 @@ independent of numpy's RNG streams, cheap to regenerate on the GPU box.
       their clade ancestor, N runs (length 1..100) covering ~0.1 % (configs[2], k=25 f=36)
   m3: 7 "human-like" genomes x 160 Mbp (1.12 Gbp: more than 2^30 positions, so the partitioned query needs
       several tile batches), 0.1 % substitutions from a common root, N runs (configs[3]'s shape, k=25 f=38)
+  m2r: m2 made less kind (round 5: repeat families, fragmentation, low complexity, mixed strands -- what real assemblies have and
+      i.i.d. substitutions on a random root do not): 20 repeat families of 1-5 kbp copied 5-50 times into every genome (high-
+      multiplicity k-mers: hot exact-filter keys, address skew), poly-A and dinucleotide tracts of 50-500 bp, two genomes
+      reverse-complemented, and every genome cut into 50-300 contigs (records).  workload() then returns the records of all genomes
+      and p["files"] = the record range of every genome's FASTA file.
 Codes: A0 C1 G2 T3, N = 4.
 """
 import numpy as np
@@ -111,7 +116,63 @@ def workload(name, seed=12345, scale=1.0):
         root = random_genome(n, seed)
         recs = [add_n_runs(substitute(root, 0.001, seed + 4000 + g), 2e-6, seed + 5000 + g) for g in range(7)]
         return recs, dict(k=25, L=38, q=5)
+    if name == "m2r":
+        n = int(5_000_000 * scale)
+        root = random_genome(n, seed)
+        fam_len = [1000 + int(x % np.uint64(4001)) for x in _stream(seed, 20, 11)]
+        # (seeds far apart: _stream(seed + 1, i) == _stream(seed, i + 1), so neighbouring seeds would make the families shifted copies
+        #  of ONE sequence -- and, below, put copy i of family f + 1 where copy i + 1 of family f went)
+        fams = [(_stream(seed + 7000, fam_len[f], 100 + f) >> np.uint64(62)).astype(np.uint8) for f in range(20)]
+        recs, files = [], []
+        for g in range(62):
+            clade = g % 6
+            anc = substitute(root, 0.02, seed + 1000 + clade)
+            mem = np.array(substitute(anc, 0.002, seed + 2000 + g), dtype=np.uint8, copy=True)
+            # (i) repeat families: every family copied 5..50 times over random places of this genome (scaled with the genome)
+            copies = _stream(seed + g, 20, 12) % np.uint64(46) + np.uint64(5)
+            for f in range(20):
+                c = max(1, int(int(copies[f]) * min(1.0, scale * 4)))
+                at = _stream(seed + 8000 + g, c, 200 + f) % np.uint64(max(1, n - fam_len[f]))
+                for a in at:
+                    mem[int(a):int(a) + fam_len[f]] = fams[f][:max(0, min(fam_len[f], n - int(a)))]
+            # (iii) low-complexity tracts: poly-A, poly-T and (CA)n / (GT)n of 50..500 bp
+            nt = max(1, int(24 * min(1.0, scale * 4)))
+            t_at = _stream(seed + 9000 + g, nt, 14) % np.uint64(max(1, n - 500))
+            t_len = _stream(seed + 9000 + g, nt, 15) % np.uint64(451) + np.uint64(50)
+            t_kind = _stream(seed + 9000 + g, nt, 16) % np.uint64(4)
+            for a, l, kd in zip(t_at, t_len, t_kind):
+                a, l, kd = int(a), int(l), int(kd)
+                l = min(l, n - a)
+                unit = [[0], [3], [1, 0], [2, 3]][kd]
+                mem[a:a + l] = np.resize(np.array(unit, dtype=np.uint8), l)
+            mem = add_n_runs(mem, 2e-5, seed + 3000 + g)
+            # (iv) two genomes on the other strand
+            if g in (7, 31):
+                mem = np.where(mem == 4, 4, 3 - mem).astype(np.uint8)[::-1].copy()
+            # (ii) contigs: 50..300 records per genome (scaled), cut at random places
+            nc = max(1, int((50 + int(_stream(seed + g, 1, 17)[0] % np.uint64(251))) * min(1.0, scale * 4)))
+            cuts = np.unique(_stream(seed + 9500 + g, nc - 1, 18) % np.uint64(max(1, n))) if nc > 1 else np.zeros(0, dtype=np.uint64)
+            edges = [0] + [int(x) for x in cuts if 0 < int(x) < n] + [n]
+            first = len(recs)
+            for a, b in zip(edges[:-1], edges[1:]):
+                if b > a:
+                    recs.append(mem[a:b].copy())
+            files.append((first, len(recs)))
+        return recs, dict(k=25, L=36, q=5, files=files)
     raise ValueError("unknown workload " + name)
+
+
+def fasta_files(recs, p, directory, prefix="g"):
+    """Writes the workload as FASTA files -- one record per file, or p["files"] = the record range of every file (m2r: a genome's
+    contigs) -- and returns the paths."""
+    import os
+    groups = p.get("files") or [(i, i + 1) for i in range(len(recs))]
+    paths = []
+    for i, (a, b) in enumerate(groups):
+        path = os.path.join(str(directory), "%s%d.fa" % (prefix, i))
+        write_fasta(path, recs[a:b], first_id=a)
+        paths.append(path)
+    return paths
 
 
 def n_kmers(recs, k):
