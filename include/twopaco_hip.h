@@ -36,7 +36,6 @@ extern "C" {
 typedef struct tpc_ctx tpc_ctx;
 
 #define TPC_MAX_Q 64                   /* hash functions: 1..16 on the rolling kernels (direct and partitioned), 17..64 on closed-form direct kernels */
-#define TPC_MAX_K 600                  /* CAPACITY < 20 words, VE.h:4                    */
 #define TPC_INVALID_VERTEX INT64_MAX   /* graphconstructor/common.cpp:5                  */
 
 /* Kernel ids for tpc_kernel_ms (hipEvent-timed duration of the last launch of each). */

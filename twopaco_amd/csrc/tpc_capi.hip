@@ -408,7 +408,7 @@ int tpc_ctx_create(int device, tpc_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return -4;
     tpc_ctx *c = new tpc_ctx();
     c->device = device;
-    c->dbg_ovf = getenv("TPC_DEBUG_OVF") != nullptr; c->dbg_phases = getenv("TPC_PROFILE_PHASES") != nullptr; c->dbg_timing = getenv("TWOPACO_TIMING") != nullptr; c->no_lean = getenv("TPC_NO_LEAN") != nullptr;
+    c->dbg_ovf = getenv("TPC_DEBUG_OVF") != nullptr; c->dbg_phases = getenv("TPC_PROFILE_PHASES") != nullptr; c->dbg_timing = getenv("TWOPACO_TIMING") != nullptr; c->no_lean = TpcEnv::get().no_lean;
     if (const char *e = getenv("TPC_SHARD_TIGHT")) c->opt_shard_tight = atoi(e) ? 1 : 0;  // measurements: the one-GPU region slack on a sharded context
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -5; }
     for (int i = 0; i < TPC_K_COUNT; i++) {
@@ -962,7 +962,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             for (int i = 0; i < 64; i++) { tot += sc[i]; most = std::max(most, sc[i]); }
             fprintf(stderr, "[ovf] query: %llu overflow entries (cap %llu, flag %llu), survivors %llu (fullest list %llu of %llu, flag %llu) b1=%d b2=%d ppr=%d loads=%d\n", f1[0],
                     (unsigned long long)pl.ovf_cap, f1[1], tot, most, (unsigned long long)pl.surv_cap, f2, pl.b1, pl.b2, pl.pos_per_round, pl.loads);
-            if (const char *path = getenv("TPC_DUMP_SURV")) {  // development: the first-probe survivors of the last batch, one id per line
+            static const char *const dump_path = getenv("TPC_DUMP_SURV");
+            if (const char *path = dump_path) {  // development: the first-probe survivors of the last batch, one id per line
                 if (FILE *fp = fopen(path, "w")) {
                     for (int i = 0; i < 64; i++) {
                         const size_t n = (size_t)std::min<unsigned long long>(sc[i], pl.surv_cap);
@@ -973,7 +974,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     fclose(fp);
                 }
             }
-            if (getenv("TPC_DEBUG_OVF_REGIONS") && f1[0]) {  // where the overflow entries go: (permuted) slice histogram of the list
+            static const bool dbg_regions = getenv("TPC_DEBUG_OVF_REGIONS") != nullptr;
+            if (dbg_regions && f1[0]) {  // where the overflow entries go: (permuted) slice histogram of the list
                 const size_t n = (size_t)std::min<unsigned long long>(f1[0], 1u << 22);
                 std::vector<uint64_t> ent(2 * n);
                 (void)hipMemcpy(ent.data(), pl.ovf, 2 * n * 8, hipMemcpyDeviceToHost);
@@ -991,7 +993,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 for (size_t i = 0; i < std::min<size_t>(topa.size(), 6); i++) fprintf(stderr, " addr %llx x %u (edge %llu pos %llu);", (unsigned long long)topa[i].second, topa[i].first, 0ull, 0ull);
                 fprintf(stderr, "\n");
             }
-            if (getenv("TPC_DEBUG_OVF_REGIONS") && !pl.b3) {  // which level-2 regions are full
+            if (dbg_regions && !pl.b3 && pl.fmt == 0) {  // which level-2 regions are full
                 const size_t nreg = pl.off2_host.size() - 1;
                 std::vector<uint32_t> cnt(nreg);
                 (void)hipMemcpy(cnt.data(), pl.cnt2, nreg * 4, hipMemcpyDeviceToHost);

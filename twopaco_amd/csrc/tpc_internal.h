@@ -1,7 +1,32 @@
 // tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi.hip) and the kernels.
 #pragma once
 #include "tpc_device.h"
+#include <cstdlib>
 #include <vector>
+
+// Measurement switches of the kernels' launch and planning code: read from the environment ONCE per process (they used to be looked up
+// on every pass).  TPC_NO_LEAN: the generic hash kernels; TPC_RB_HASH: the barrier-free rings in the 512-bin hash; TPC_VERIFY_LAZY=0:
+// all q - 1 probes at once; TPC_GATED_FULL_REGIONS: gated rounds sized for all entries; TPC_PPR_INSERT / TPC_GATED_LOADS: round sizes.
+struct TpcEnv {
+    bool no_lean, rb_hash, verify_eager, gated_full;
+    int ppr_insert, gated_loads;  // 0: not set
+    static const TpcEnv &get()
+    {
+        static const TpcEnv e = [] {
+            TpcEnv v;
+            v.no_lean = getenv("TPC_NO_LEAN") != nullptr;
+            v.rb_hash = getenv("TPC_RB_HASH") != nullptr;
+            const char *lz = getenv("TPC_VERIFY_LAZY");
+            v.verify_eager = lz && lz[0] == '0';
+            v.gated_full = getenv("TPC_GATED_FULL_REGIONS") != nullptr;
+            const char *p = getenv("TPC_PPR_INSERT"), *g = getenv("TPC_GATED_LOADS");
+            v.ppr_insert = p ? atoi(p) : 0;
+            v.gated_loads = g ? atoi(g) : 0;
+            return v;
+        }();
+        return e;
+    }
+};
 
 #define TPC_TAB_MAXQ 64                // = TPC_MAX_Q (include/twopaco_hip.h)
 #define TPC_KERNEL_MAXQ 16             // the rolling kernels are instantiated for 1..16 functions; beyond that tpc_pass1_anyq.hip

@@ -567,7 +567,7 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     Overflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
-    if (perm.F <= 24 && !getenv("TPC_NO_LEAN")) {  // the instruction-lean kernel (a 24-bit slice index)
+    if (perm.F <= 24 && !TpcEnv::get().no_lean) {  // the instruction-lean kernel (a 24-bit slice index)
         const size_t fixed = Bins3<uint32_t, PH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 24 + (size_t)Q * 10 * 16 + 64 + 64;
         const size_t seed = (size_t)a.P.k * 5 * Q * 16;  // the seed table, when it fits beside the rings (160 KB per workgroup)
         const int seed_rows = fixed + seed <= (size_t)160 * 1024 - 256 ? a.P.k : 0;
@@ -765,8 +765,29 @@ bool tpc_part_plan(int L, int q, int slice_bits, uint64_t n_tiles, double frac, 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions are sized for the entries of all ranks
 // tight: level-1 regions sized at the expected fill + 6 sigma instead of 1.3 x + 8 sigma -- the regions of a sharded pass travel
 // whole (equal-block all_to_all: no packing pass), so slack is wire bytes; what does not fit goes the overflow list's way
+static bool part_plan_compute(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight, bool packed);
+
 bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight, bool packed)
+{   // the last plan per thread is kept (tpc_qpart_plan_sharded says why); the caller fills in the device pointers afterwards
+    struct Key { int L, q, slice_bits, levels, p3; uint64_t n_tiles; double frac; uint32_t rank, world; bool tight, packed; };
+    static thread_local Key last{};
+    static thread_local TpcPartPlan last_pl;
+    static thread_local bool have = false, last_ok = false;
+    const Key k{L, q, slice_bits, levels, tpc_test_insert_p3, n_tiles, frac, rank, world, tight, packed};
+    if (have && k.L == last.L && k.q == last.q && k.slice_bits == last.slice_bits && k.levels == last.levels && k.p3 == last.p3 && k.n_tiles == last.n_tiles &&
+        k.frac == last.frac && k.rank == last.rank && k.world == last.world && k.tight == last.tight && k.packed == last.packed) {
+        if (last_ok) pl = last_pl;
+        return last_ok;
+    }
+    last_ok = part_plan_compute(L, q, slice_bits, n_tiles, frac, rank, world, pl, levels, tight, packed);
+    last = k; have = true;
+    if (last_ok) last_pl = pl;
+    return last_ok;
+}
+
+static bool part_plan_compute(int L, int q, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcPartPlan &pl, int levels, bool tight, bool packed)
 {
+    pl = TpcPartPlan();
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
@@ -801,14 +822,14 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     // vertex-hash range), so a round can cover more positions before the rings fill
     int ppr = (int)(budget / (1024 * q * std::max(frac, 1.0 / 64)));  // k_part_hash: 1024 threads (two tiles) x pos_per_round
     pl.pos_per_round = std::max(1, std::min(32, ppr));
-    if (const char *e = getenv("TPC_PPR_INSERT")) pl.pos_per_round = std::max(1, std::min(32, atoi(e)));  // measurements: positions per ring round
+    if (TpcEnv::get().ppr_insert) pl.pos_per_round = std::max(1, std::min(32, TpcEnv::get().ppr_insert));  // measurements: positions per ring round
     const double a_max = (double)q * (double)n_text * 1.02 + 4096;
     // a workgroup takes ceil(pairs / nwg1) tile pairs: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t pairs = (pl.n_tiles + 1) / 2, pairs_wg = (pairs + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)(2 * pairs_wg) / (double)std::max<uint64_t>(pl.n_tiles, 1));
     // a gated round (frac < 1: only edges touching the round's vertex-hash range are inserted) fills that share of every region: sized for it,
     // a multi-round pass over a huge filter takes half the batches -- and every batch after the first sweeps the whole filter
-    const double a_exp = getenv("TPC_GATED_FULL_REGIONS") ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));
+    const double a_exp = TpcEnv::get().gated_full ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));
     const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;

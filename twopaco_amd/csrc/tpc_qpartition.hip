@@ -1484,7 +1484,7 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     const PtShard sh{pl.rank, pl.world};
     const bool rb = q_use_rbins(pl.b1);
     // the instruction-lean kernel: flush-per-round bins (two rounds per position at 512 bins), a 24-bit slice index
-    const bool lean = pl.b1 <= 9 && pl.sub_rounds <= 2 && perm.F <= 24 && !getenv("TPC_NO_LEAN") && !(rb && getenv("TPC_RB_HASH"));
+    const bool lean = pl.b1 <= 9 && pl.sub_rounds <= 2 && perm.F <= 24 && !TpcEnv::get().no_lean && !(rb && TpcEnv::get().rb_hash);
     if (lean) {
         const size_t lds = Bins3<uint64_t, QH_THREADS>::lds_bytes(pl.b1) + (size_t)(PT_THREADS + 1 + TPC_XW_MAX) * 12 + 160 + (size_t)QT_MAXK * 80 + 64;
 #define TPC_QHASH2_GO(G, S, H, X)                                                                                                           \
@@ -1565,9 +1565,8 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const size_t table = (size_t)(a.P.k + 1) * 4 * Q * 16;  // k_q_verify2's letter table
-    if (a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN")) {
-        const char *force = getenv("TPC_VERIFY_LAZY");  // measurements: 0 = all Q - 1 probes at once
-        const bool lazy = !(force && force[0] == '0');
+    if (a.P.k <= 31 && table <= 48 * 1024 && !TpcEnv::get().no_lean) {
+        const bool lazy = !TpcEnv::get().verify_eager;  // (TPC_VERIFY_LAZY=0, measurements: all Q - 1 probes at once)
         if (lazy) {
             (void)hipFuncSetAttribute((const void *)k_q_verify2<Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)table);
             hipLaunchKernelGGL((k_q_verify2<Q, true>), dim3(256, QS_LISTS), dim3(256), table, a.stream, a.P, a.tab, a.bases, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, gbase,
@@ -1591,8 +1590,32 @@ bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPl
 
 // n_tiles: the tiles THIS rank hashes; the level-2 regions cover the slices this rank owns and are sized
 // for the entries of all ranks
+static bool qpart_plan_compute(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight, bool packed);
+
 bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight, bool packed)
 {
+    // A plan costs ~0.5 ms of host time (the densest-bucket search and the per-slice region table: 65536 entries with a square root
+    // each) and every pass of every round asks for the same one while the GPU sits idle behind the previous call's synchronisation:
+    // the last plan per thread is kept (the device pointers of a plan are filled in by the caller afterwards and are not part of it).
+    struct Key { int L, slice_bits, levels, q6; uint64_t n_tiles; double frac; uint32_t rank, world; bool tight, packed; };
+    static thread_local Key last{};
+    static thread_local TpcQPlan last_pl;
+    static thread_local bool have = false, last_ok = false;
+    const Key k{L, slice_bits, levels, tpc_test_q6_pb2, n_tiles, frac, rank, world, tight, packed};
+    if (have && k.L == last.L && k.slice_bits == last.slice_bits && k.levels == last.levels && k.q6 == last.q6 && k.n_tiles == last.n_tiles && k.frac == last.frac &&
+        k.rank == last.rank && k.world == last.world && k.tight == last.tight && k.packed == last.packed) {
+        if (last_ok) pl = last_pl;
+        return last_ok;
+    }
+    last_ok = qpart_plan_compute(L, slice_bits, n_tiles, frac, rank, world, pl, levels, tight, packed);
+    last = k; have = true;
+    if (last_ok) last_pl = pl;
+    return last_ok;
+}
+
+static bool qpart_plan_compute(int L, int slice_bits, uint64_t n_tiles, double frac, uint32_t rank, uint32_t world, TpcQPlan &pl, int levels, bool tight, bool packed)
+{
+    pl = TpcQPlan();
     pl.rank = rank; pl.world = world;
     const uint64_t n_text = n_tiles * PT_THREADS * TPC_RUN;  // positions of this batch of 512-word tiles
     const int F = L - slice_bits;
@@ -1639,12 +1662,12 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     // (a range of half the hash space -- two rounds, two ranks: frac 0.58 -- is mild: its hot half takes 1.5 x; from a third down it is not)
     const bool gated_round = frac < 0.45;
     if (gated_round) pl.loads = std::max(1, pl.loads / 2);
-    if (const char *e = getenv("TPC_GATED_LOADS")) { if (gated_round) pl.loads = std::max(1, std::min(4, atoi(e))); }  // measurements
+    if (TpcEnv::get().gated_loads && gated_round) pl.loads = std::max(1, std::min(4, TpcEnv::get().gated_loads));  // measurements
     const double a_max = 6.0 * (double)n_text * 1.02 + 4096;
     // a workgroup takes ceil(n_tiles / nwg1) tiles: with few tiles per workgroup the busiest one holds well over the mean
     const uint64_t tiles_wg = (pl.n_tiles + pl.nwg1 - 1) / pl.nwg1;
     const double share1 = std::min(1.0, (double)tiles_wg / (double)std::max<uint64_t>(pl.n_tiles, 1));
-    const double a_exp = getenv("TPC_GATED_FULL_REGIONS") ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));  // a gated round: the share of the vertices inside its range (as tpc_part_plan_sharded)
+    const double a_exp = TpcEnv::get().gated_full ? a_max : a_max * std::min(1.0, std::max(frac, 1.0 / 64));  // a gated round: the share of the vertices inside its range (as tpc_part_plan_sharded)
     const double avg1 = a_exp * share1 / (double)(1 << pl.b1);
     const PtPerm pm = pt_make_perm(slice_bits, F);
     pl.perm_mult = pm.mult; pl.perm_inv = pm.inv;
@@ -1701,7 +1724,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     if (tpc_test_q6_pb2 >= 14 && tpc_test_q6_pb2 < PB2) PB2 = tpc_test_q6_pb2;  // tests: many groups on a small input
     const uint64_t tpw = (n_tiles + pl.nwg1 - 1) / pl.nwg1;  // level 1: contiguous tiles per workgroup
     const uint64_t groups = ((n_tiles * (uint64_t)(PT_THREADS * TPC_RUN)) + (1ull << PB2) - 1) >> PB2;
-    static const bool no_lean = getenv("TPC_NO_LEAN") != nullptr;  // (measurements: the generic hash kernel takes its tiles interleaved)
+    const bool no_lean = TpcEnv::get().no_lean;  // (measurements: the generic hash kernel takes its tiles interleaved)
     // (512 bins at level 2 -- f = 37, 38 -- stay on the 8-byte barrier-free rings: 40-entry rings allow rounds of 3072 entries only, and
     //  the 62-genome text at f = 38 measured 40.6 ms per step against 39.6; TPC_P6_MAXB2=9 lifts the gate for measurements)
     static const int max_b2 = [] { const char *e = getenv("TPC_P6_MAXB2"); return e ? atoi(e) : 8; }();
@@ -1900,7 +1923,7 @@ int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int 
     const uint64_t gbase = pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN);
     const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 4096));
     const size_t table = (size_t)(a.P.k + 1) * 4 * a.P.q * 16;  // k_v_addrs2's letter table
-    const bool lean = a.P.k <= 31 && table <= 48 * 1024 && !getenv("TPC_NO_LEAN");
+    const bool lean = a.P.k <= 31 && table <= 48 * 1024 && !TpcEnv::get().no_lean;
 #define CALL(Q_)                                                                                                                                         \
     do {                                                                                                                                                 \
         if (lean) {                                                                                                                                      \
