@@ -200,12 +200,40 @@ __device__ __forceinline__ bool keys_equal(const uint64_t (&a)[C], const uint64_
 
 // forward strand stored iff posHash0 < negHash0, tie -> LessSelfReverseComplement
 // (candidateoccurence.h:34, dnachar.cpp:98-114: first differing base decides, A<C<G<T)
+// One-word keys (k <= 32): the fold written out -- H(w) = XOR_t rotl(h0[w_t], k - 1 - t), and for the reverse complement r_t = 3 - w_(k-1-t):
+// H(r) = XOR_t rotl(h0[3 - w_t], t) -- so both strands come from ONE walk over the forward word: a 16-byte LDS read {forward term, reverse
+// term} and two XORs per base instead of two rotations, two lookups and two XORs (k_filter2 / k_emit were 75-78 % VALU issue on this
+// loop: profiles/r05_sq.csv).  The table is built per workgroup from function 0's four letter hashes.
+constexpr int CANON_TAB = 32 * 4;
+__device__ __forceinline__ uint64_t canon_rotl(uint64_t x, int r, int L, uint64_t lmask) { return r ? ((x << r) & lmask) | (x >> (L - r)) : x; }
+__device__ __forceinline__ void canon_tab_build(uint4 *s_ct, const uint64_t *s_h0, int k, int L, uint64_t lmask)  // the caller synchronises before and after
+{
+    for (int i = threadIdx.x; i < 4 * (k < 32 ? k : 32); i += blockDim.x) {
+        const int t = i >> 2, c = i & 3;
+        const uint64_t a = canon_rotl(s_h0[c], (k - 1 - t) % L, L, lmask), b = canon_rotl(s_h0[3 - c], t % L, L, lmask);
+        s_ct[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+}
+
 template <int C>
 __device__ __forceinline__ bool forward_is_canonical(const uint64_t (&fw)[C], const uint64_t (&rc)[C], int k,
-                                                     const uint64_t *s_h0, int L, uint64_t lmask)
+                                                     const uint64_t *s_h0, int L, uint64_t lmask, const uint4 *s_ct)
 {
-    const uint64_t hp = fold_h0<C>(fw, k, s_h0, L, lmask);
-    const uint64_t hn = fold_h0<C>(rc, k, s_h0, L, lmask);
+    uint64_t hp, hn;
+    if constexpr (C == 1) {
+        uint32_t pl = 0, ph = 0, nl = 0, nh = 0;
+        uint64_t y = fw[0];
+        for (int t = 0; t < k; t++) {
+            const uint4 e = s_ct[4 * t + (int)(y & 3)];
+            pl ^= e.x; ph ^= e.y; nl ^= e.z; nh ^= e.w;
+            y >>= 2;
+        }
+        hp = (uint64_t)pl | ((uint64_t)ph << 32);
+        hn = (uint64_t)nl | ((uint64_t)nh << 32);
+    } else {
+        hp = fold_h0<C>(fw, k, s_h0, L, lmask);
+        hn = fold_h0<C>(rc, k, s_h0, L, lmask);
+    }
     if (hp != hn) return hp < hn;
 #pragma unroll
     for (int w = 0; w < C; w++) {
@@ -245,15 +273,17 @@ k_filter2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__r
           unsigned long long *overflow)
 {
     __shared__ uint64_t s_h0[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_marks) return;
     const uint64_t g = marks[idx];
     uint64_t fw[C], rc[C];
     load_kmer<C>(bases, g, P.k, fw);
     revcomp_kmer<C>(fw, P.k, rc);
-    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
     int prev = tpc_text_char(bases, nmask, g - 1);
     int next = tpc_text_char(bases, nmask, g + P.k);
     if (!fwd) {  // candidateoccurence.h:43-45
@@ -309,14 +339,16 @@ k_mark_owner(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *
              uint64_t n_marks, uint32_t world, int32_t *__restrict__ owner)
 {
     __shared__ uint64_t s_h0[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_marks) return;
     uint64_t fw[C], rc[C];
     load_kmer<C>(bases, marks[idx], P.k, fw);
     revcomp_kmer<C>(fw, P.k, rc);
-    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
     uint64_t ck[C];
 #pragma unroll
     for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
@@ -332,15 +364,17 @@ k_mark_records(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t
                const uint64_t *__restrict__ marks, uint64_t n_marks, uint32_t world, uint64_t *__restrict__ records, int32_t *__restrict__ owner)
 {
     __shared__ uint64_t s_h0[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_marks) return;
     const uint64_t g = marks[idx];
     uint64_t fw[C], rc[C];
     load_kmer<C>(bases, g, P.k, fw);
     revcomp_kmer<C>(fw, P.k, rc);
-    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+    const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
     int prev = tpc_text_char(bases, nmask, g - 1);
     int next = tpc_text_char(bases, nmask, g + P.k);
     if (!fwd) {  // candidateoccurence.h:43-45
@@ -477,8 +511,10 @@ k_scan2_write(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t 
 {
     __shared__ uint64_t s_h0[4];
     __shared__ uint32_t s_w[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
     const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(cap, lo + chunk);
     uint64_t base = block_off[blockIdx.x];
     for (uint64_t s0 = lo; s0 < hi; s0 += 256) {
@@ -501,7 +537,7 @@ k_scan2_write(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t 
                 uint64_t fw[C], rc[C];
                 load_kmer<C>(bases, marks[sl.key], P.k, fw);
                 revcomp_kmer<C>(fw, P.k, rc);
-                const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+                const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
 #pragma unroll
                 for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
             }
@@ -542,8 +578,10 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
        const uint32_t *__restrict__ idtab, uint64_t cap, int64_t *__restrict__ ids, unsigned long long *n_valid)
 {
     __shared__ uint64_t s_h0[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
     if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
     __shared__ uint32_t s_w[4];
     unsigned valid = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -554,7 +592,7 @@ k_emit(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__rest
             uint64_t fw[C], rc[C], ck[C];
             load_kmer<C>(bases, g, P.k, fw);
             revcomp_kmer<C>(fw, P.k, rc);
-            const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask);
+            const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
 #pragma unroll
             for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
             const uint64_t mask = cap - 1;

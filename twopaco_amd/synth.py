@@ -94,8 +94,9 @@ def add_n_runs(codes, start_rate, seed, max_len=100):
     return out
 
 
-def workload(name, seed=12345, scale=1.0):
-    """Returns (list of uint8 code arrays, dict(k, L, q)).  scale shrinks the genome length."""
+def workload(name, seed=12345, scale=1.0, m2r_features=("families", "tracts", "strands", "contigs")):
+    """Returns (list of uint8 code arrays, dict(k, L, q)).  scale shrinks the genome length.  m2r_features: which of m2r's four departures
+    from m2 to apply (tools/m2r_ablate.py times them one at a time; the workload and its golden are all four)."""
     if name == "m1":
         n = int(5_000_000 * scale)
         base = random_genome(n, seed)
@@ -130,13 +131,13 @@ def workload(name, seed=12345, scale=1.0):
             mem = np.array(substitute(anc, 0.002, seed + 2000 + g), dtype=np.uint8, copy=True)
             # (i) repeat families: every family copied 5..50 times over random places of this genome (scaled with the genome)
             copies = _stream(seed + g, 20, 12) % np.uint64(46) + np.uint64(5)
-            for f in range(20):
+            for f in range(20 if "families" in m2r_features else 0):
                 c = max(1, int(int(copies[f]) * min(1.0, scale * 4)))
                 at = _stream(seed + 8000 + g, c, 200 + f) % np.uint64(max(1, n - fam_len[f]))
                 for a in at:
                     mem[int(a):int(a) + fam_len[f]] = fams[f][:max(0, min(fam_len[f], n - int(a)))]
             # (iii) low-complexity tracts: poly-A, poly-T and (CA)n / (GT)n of 50..500 bp
-            nt = max(1, int(24 * min(1.0, scale * 4)))
+            nt = max(1, int(24 * min(1.0, scale * 4))) if "tracts" in m2r_features else 0
             t_at = _stream(seed + 9000 + g, nt, 14) % np.uint64(max(1, n - 500))
             t_len = _stream(seed + 9000 + g, nt, 15) % np.uint64(451) + np.uint64(50)
             t_kind = _stream(seed + 9000 + g, nt, 16) % np.uint64(4)
@@ -147,10 +148,10 @@ def workload(name, seed=12345, scale=1.0):
                 mem[a:a + l] = np.resize(np.array(unit, dtype=np.uint8), l)
             mem = add_n_runs(mem, 2e-5, seed + 3000 + g)
             # (iv) two genomes on the other strand
-            if g in (7, 31):
+            if g in (7, 31) and "strands" in m2r_features:
                 mem = np.where(mem == 4, 4, 3 - mem).astype(np.uint8)[::-1].copy()
             # (ii) contigs: 50..300 records per genome (scaled), cut at random places
-            nc = max(1, int((50 + int(_stream(seed + g, 1, 17)[0] % np.uint64(251))) * min(1.0, scale * 4)))
+            nc = max(1, int((50 + int(_stream(seed + g, 1, 17)[0] % np.uint64(251))) * min(1.0, scale * 4))) if "contigs" in m2r_features else 1
             cuts = np.unique(_stream(seed + 9500 + g, nc - 1, 18) % np.uint64(max(1, n))) if nc > 1 else np.zeros(0, dtype=np.uint64)
             edges = [0] + [int(x) for x in cuts if 0 < int(x) < n] + [n]
             first = len(recs)
