@@ -147,6 +147,9 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
                 sharded[name.strip()] = sharded.get(name.strip(), 0.0) + float(val)
         if sharded:
             ph["__sharded__"] = sharded
+        m = re.search(r"\[timing\] device memory in use after the rounds: ([0-9.eE+-]+) GB", err)
+        if m:
+            ph["__device_GB__"] = float(m.group(1))
         phases.append((wall, ph))
         occ = int(re.search(r"True marks count: (\d+)", res.stdout.decode()).group(1))
         if rep == 0 and golden:
@@ -169,6 +172,7 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
     detail["all runs"] = [ph.get("warm-up thread: code objects") for _, ph in order]
     return {"e2e_wall_s": med, "breakdown_ms": breakdown(order[len(order) // 2][1]), "code_objects_ms": detail, "e2e_wall_s_min": walls[0], "e2e_wall_s_p50": med, "e2e_wall_s_max": walls[-1],
             "e2e_wall_s_all": walls, "slowest_run_breakdown_ms": breakdown(order[-1][1]), "settle_s_between_runs": settle_s,
+            "device_bytes_allocated": int(median_ph["__device_GB__"] * 1e9) if median_ph.get("__device_GB__") else None,
             "e2e_junction_occurrences_per_sec": occ / med,
             "junction_occurrences": occ, "runs": runs, "host_threads": int(threads), "gpus": gpus,
             "output_sha256_equals_reference": sha_ok,

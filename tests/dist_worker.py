@@ -122,7 +122,8 @@ def addr_worker(rank, world, port, spec, result_path):
             out["rounds"].append({"geom": geom, "qgeom": qgeom, "shard": shard, "mask": ctx.mask_download(False),
                                   "survivors": sh.stats["survivors"]})
         st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True, sharded_pass2=sp.get("sharded_pass2", False))
-        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], step_marks=st["marks"], moved=sh.comm.bytes_moved, region_bytes_sent=sh.stats.get("region_bytes_sent", 0))
+        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], step_marks=st["marks"], moved=sh.comm.bytes_moved, region_bytes_sent=sh.stats.get("region_bytes_sent", 0),
+                   relaxed_regions=sh.stats.get("relaxed_regions", 0), overflow_entries=sh.stats.get("overflow_entries", 0))
         gathered = [None] * world
         dist.all_gather_object(gathered, out)
         results.append(gathered)

@@ -126,6 +126,39 @@ def test_address_sharded_synthetic_batches(world, budget, tmp_path):
     check(spec, o, gathered, world)
 
 
+def _synthetic(workload, scale, L, seed, options, **extra):
+    from twopaco_amd import synth
+    recs, _ = synth.workload(workload, scale=scale)
+    spec = dict({"workload": workload, "scale": scale, "k": 25, "L": L, "q": 5, "seed": seed, "ranges": [(0, 1 << L)], "abundance": (1 << 64) - 1, "options": options}, **extra)
+    o = O.Oracle(25, L, 5, O.seed_table(seed, 5, L))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    return spec, o
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_overflowing_tight_regions_are_replanned_once(world, tmp_path):
+    """A sharded filter has no direct-kernel fallback behind its overflow lists.  With the tight level-1 regions pinched
+    to half their expected fill and a 64-entry list (option test_tight_pinch) both passes overflow on every rank; AddressSharded then
+    goes back to the one-GPU region size ONCE, for the rest of the object's life, and starts the pass again: oracle's filter, masks, ids."""
+    spec, o = _synthetic("m1", 0.01, 26, 11, {"slice_bits": 14, "part_min_tiles": 1, "test_tight_pinch": 50}, compact_exchange=False)
+    gathered = run(spec, world, tmp_path)
+    assert all(g["relaxed_regions"] == 1 for g in gathered)
+    check(spec, o, gathered, world)
+
+
+@pytest.mark.parametrize("world,compact", [(2, False), (4, True)])
+def test_low_complexity_input_through_the_sharded_path(world, compact, tmp_path):
+    """m2r at 1/50 scale -- repeat families, poly-A / poly-T / (CA)n / (GT)n tracts, two genomes on the other strand, contigs -- with the
+    default tight regions: the tracts' entries overflow their regions (thousands of identical addresses per workgroup), travel as
+    all-gathered lists and are applied by their owners; filter, masks and ids are the oracle's."""
+    spec, o = _synthetic("m2r", 0.02, 26, 7, {"slice_bits": 14, "part_min_tiles": 1}, compact_exchange=compact)
+    gathered = run(spec, world, tmp_path)
+    assert sum(g["overflow_entries"] for g in gathered) > 0
+    check(spec, o, gathered, world)
+
+
 @pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("rand6_k25_q3", 12, 4), ("c2_k51_r2", 16, 2), ("rand6_k9_a3", 8, 4),
                                                    ("c2_k125", 14, 2), ("edge_k5", 7, 2), ("edge_k5", 7, 4), ("example_k11", 8, 4)])
 def test_address_sharded_key_sharded_pass2(name, slice_bits, world, tmp_path):

@@ -150,6 +150,7 @@ int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n
                             uint64_t *off, uint64_t *sorted, uint32_t rank = 0, uint32_t world = 1, int log_nb2 = 0);  // world > 1: local slices of this rank's shard
 #define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
+extern int tpc_test_tight_pinch;     // tpc_partition.hip: option "test_tight_pinch" (tests: tight regions of a sharded pass at N % of their expected fill + a 64-entry overflow list)
 extern int tpc_test_q6_pb2;          // tpc_qpartition.hip: option "test_q6_pb2" (tests: position bits of a 6-byte level-2 entry, to get many groups on small inputs; process-wide)
 extern int tpc_test_insert_p3;       // tpc_partition.hip: option "insert_entry_fmt" (3: the level-2 insert entries as blocked 24-bit lines; process-wide)
 extern uint32_t tpc_test_sched_cap;  // tpc_partition.hip: option "test_sched_cap" (tests: rounds per schedule segment of the split kernels)

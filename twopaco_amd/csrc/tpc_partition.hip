@@ -41,6 +41,7 @@
 
 #if TPC_PARTITION_PART == 0
 uint32_t tpc_test_sched_cap = 0;  // see tpc_bins.h:pt_schedule_dims
+int tpc_test_tight_pinch = 0;    // option "test_tight_pinch" (tests): tight level-1 regions at this percentage of their expected fill and a 64-entry overflow list -- a tight plan that must fail
 int tpc_test_insert_p3 = 0;       // option "insert_entry_fmt" = 3: 24-bit level-2 insert entries (tpc_part_plan_sharded)
 #endif
 int tpc_launch_insert_part_hash_other_q(const TpcLaunch &a, const TpcPartPlan &pl, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_kmers);  // part 1
@@ -773,7 +774,7 @@ bool tpc_part_plan_sharded(int L, int q, int slice_bits, uint64_t n_tiles, doubl
     static thread_local Key last{};
     static thread_local TpcPartPlan last_pl;
     static thread_local bool have = false, last_ok = false;
-    const Key k{L, q, slice_bits, levels, tpc_test_insert_p3, n_tiles, frac, rank, world, tight, packed};
+    const Key k{L, q, slice_bits, levels, (int)tpc_test_insert_p3 + (tpc_test_tight_pinch << 8), n_tiles, frac, rank, world, tight, packed};
     if (have && k.L == last.L && k.q == last.q && k.slice_bits == last.slice_bits && k.levels == last.levels && k.p3 == last.p3 && k.n_tiles == last.n_tiles &&
         k.frac == last.frac && k.rank == last.rank && k.world == last.world && k.tight == last.tight && k.packed == last.packed) {
         if (last_ok) pl = last_pl;
@@ -858,6 +859,10 @@ static bool part_plan_compute(int L, int q, int slice_bits, uint64_t n_tiles, do
     const double avg3 = a_l2 * world / ((double)(1ull << F) * pl.wpb3);
     pl.cap3 = pl.b3 ? ((uint64_t)(avg3 * 1.5 + 8 * std::sqrt(avg3) + 128) + 31) & ~31ull : 0;
     pl.ovf_cap = (uint64_t)(a_max / 16) + 65536;
+    if (tight && tpc_test_tight_pinch > 0) {  // (tests: dist.py's one re-plan with shard_tight_regions = 0)
+        pl.cap1 = std::max<uint64_t>(32, ((uint64_t)(avg1t * tpc_test_tight_pinch / 100.0) + 31) & ~31ull);
+        pl.ovf_cap = 64;
+    }
     return true;
 }
 

@@ -1601,7 +1601,7 @@ bool tpc_qpart_plan_sharded(int L, int slice_bits, uint64_t n_tiles, double frac
     static thread_local Key last{};
     static thread_local TpcQPlan last_pl;
     static thread_local bool have = false, last_ok = false;
-    const Key k{L, slice_bits, levels, tpc_test_q6_pb2, n_tiles, frac, rank, world, tight, packed};
+    const Key k{L, slice_bits, levels, tpc_test_q6_pb2 + (tpc_test_tight_pinch << 8), n_tiles, frac, rank, world, tight, packed};
     if (have && k.L == last.L && k.slice_bits == last.slice_bits && k.levels == last.levels && k.q6 == last.q6 && k.n_tiles == last.n_tiles && k.frac == last.frac &&
         k.rank == last.rank && k.world == last.world && k.tight == last.tight && k.packed == last.packed) {
         if (last_ok) pl = last_pl;
@@ -1674,6 +1674,10 @@ static bool qpart_plan_compute(int L, int slice_bits, uint64_t n_tiles, double f
     const double avg1t = avg1 * pt_bucket_peak(pm, F, pl.b1);  // tight, as in tpc_part_plan_sharded: every query address is a function-0 address
     pl.cap1 = ((uint64_t)(tight ? avg1t + 6 * std::sqrt(avg1t) + 128 : avg1 * 1.3 + 8 * std::sqrt(avg1) + 128) + 15) & ~15ull;
     pl.ovf_cap = (uint64_t)(a_max / 32) + 65536;
+    if (tight && tpc_test_tight_pinch > 0) {  // (tests, as in tpc_part_plan_sharded: a tight plan that must fail)
+        pl.cap1 = std::max<uint64_t>(16, ((uint64_t)(avg1t * tpc_test_tight_pinch / 100.0) + 15) & ~15ull);
+        pl.ovf_cap = 64;
+    }
     pl.surv_cap = (uint64_t)((double)n_text * 1.0 / QS_LISTS) + 65536;  // per sub-list; beyond it the direct kernel takes over (repeat-rich input: 0.83 survivors per position)
     // Region sizes of the LAST level: a region is one filter slice, and every query address is a function-0
     // address whose density over the slices falls linearly from 2x to 0 (tpc_bins.h).  With three levels the

@@ -145,6 +145,10 @@ def sharded_step(backend, dist, L, abundance=(1 << 64) - 1, fetch=False):
     return st
 
 
+class _ListOverflow(RuntimeError):
+    """An overflow list of a sharded pass overflowed (seen by every rank in the same all-reduce): AddressSharded re-plans once."""
+
+
 class DistAbort(RuntimeError):
     """Every rank raises this together: some rank's local work failed before the collective named in the message."""
 
@@ -511,8 +515,8 @@ class AddressSharded:
         # one tiny all-reduce BEFORE anything moves: the largest overflow list of the batch and every rank's failure flag
         m = self.comm.max_ints([n_ovf])[0]
         self.stats["overflow_entries"] = self.stats.get("overflow_entries", 0) + (n_ovf if n_ovf < (1 << 62) else 0)
-        if m >= (1 << 62):
-            raise RuntimeError("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
+        if m >= (1 << 62):  # (the all-reduced maximum: every rank is here together)
+            raise _ListOverflow("address-sharded pass: an overflow list overflowed (adversarial address skew); use the vertex-hash-range decomposition")
         recv_c = self.comm.a2a_equal(send_c)
         if self.compact:
             # the regions are ~3/4 full: pack their used prefixes, move exactly those (block sizes are multiples of 128 bytes)
@@ -554,7 +558,26 @@ class AddressSharded:
             return self._try(self.ctx.shard_apply_packed, which, b, recv_r.data_ptr(), recv_c.data_ptr())
         return self._try(self.ctx.shard_apply_inplace, which, b, recv_r.data_ptr() if recv_r is not None else 0, recv_c.data_ptr(), send_r.data_ptr(), send_c.data_ptr())
 
+    def _relax(self, exc):
+        """An overflow list overflowed on some rank (every rank sees it in the same all-reduce).  Once per object: the level-1 regions go
+        back from the tight size (expected fill of the densest bucket + 6 sigma) to the one-GPU size (1.3 x + 8 sigma: 30 % more bytes
+        on the wire below eight ranks) and the pass starts again -- a sharded filter has no direct-kernel fallback behind its lists, and
+        repeat-rich input (microsatellites: one k-mer in the same bucket thousands of times per workgroup) is what overflows them first."""
+        if getattr(self, "_relaxed", False):
+            raise RuntimeError(str(exc))
+        self._relaxed = True
+        self.stats["relaxed_regions"] = 1
+        self._try(self.ctx.set_option, "shard_tight_regions", 0)
+        self._bufs.clear()  # the block sizes of the exchange buffers change with the plan
+
     def insert(self, lo=0, hi=None):
+        try:
+            return self._insert(lo, hi)
+        except _ListOverflow as e:
+            self._relax(e)
+            return self._insert(lo, hi)  # (filter_reset first: what the failed attempt applied is gone)
+
+    def _insert(self, lo=0, hi=None):
         self.comm.phase = "insert plan"
         geom = self._try(self.ctx.shard_plan, INSERT, lo, hi, default=None)
         self.comm.agree()  # every rank has a plan (the batch geometry must agree) before the first exchange
@@ -690,6 +713,13 @@ class AddressSharded:
 
     def query(self, lo=0, hi=None, union=True):
         """union = False: every rank keeps only the marks of the positions it hashed (for the key-sharded second pass)."""
+        try:
+            return self._query(lo, hi, union)
+        except _ListOverflow as e:
+            self._relax(e)
+            return self._query(lo, hi, union)  # (marks of the failed attempt are marks of this round: setting them again changes nothing)
+
+    def _query(self, lo=0, hi=None, union=True):
         torch, ctx, W = self.torch, self.ctx, self.world
         self.comm.phase = "query plan"
         geom = self._try(ctx.shard_plan, QUERY, lo, hi, default=None)

@@ -735,6 +735,12 @@ namespace TwoPaCo
 				}
 
 				timer.Lap("sort + id lookup + junction stream");
+				if (std::getenv("TWOPACO_TIMING") && ctx_)
+				{
+					// what the run holds on the device at its peak (filter, text, partition buffers, second pass, stream): total - free, for a process alone on the device
+					std::cerr << "[timing] device memory in use after the rounds: " << double(tpc_get_stat(ctx_, "device_total_bytes") - tpc_get_stat(ctx_, "device_free_bytes")) / 1e9
+						<< " GB" << std::endl;
+				}
 				{
 					const int fd = ::open(outFileName.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
 					if (fd < 0)
