@@ -9,7 +9,7 @@
 // all q - 1 probes at once; TPC_GATED_FULL_REGIONS: gated rounds sized for all entries; TPC_PPR_INSERT / TPC_GATED_LOADS: round sizes.
 struct TpcEnv {
     bool no_lean, rb_hash, verify_eager, gated_full;
-    int ppr_insert, gated_loads;  // 0: not set
+    int ppr_insert, gated_loads, split_loads9;  // 0: not set
     static const TpcEnv &get()
     {
         static const TpcEnv e = [] {
@@ -22,6 +22,8 @@ struct TpcEnv {
             const char *p = getenv("TPC_PPR_INSERT"), *g = getenv("TPC_GATED_LOADS");
             v.ppr_insert = p ? atoi(p) : 0;
             v.gated_loads = g ? atoi(g) : 0;
+            const char *s9 = getenv("TPC_SPLIT_LOADS9");  // (measurements: entries per thread and round of k_part_split at 512 bins)
+            v.split_loads9 = s9 ? atoi(s9) : 0;
             return v;
         }();
         return e;

@@ -609,9 +609,13 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
 // entries per thread and round of k_part_split for a level with 2^bits bins: 5/8 of the ring storage, less the leftovers (< one line) per bin
 int split_loads(int bits, bool p3 = false)
 {
+    if (bits == 9 && !p3 && TpcEnv::get().split_loads9 > 0) return std::min(14, TpcEnv::get().split_loads9);
     const int group = p3 ? PFmt3::GROUP : 32;
     const int cap = p3 ? (int)BinsP<PFmt3, PS_THREADS>::cap_for(bits) : (PT_BIN_BYTES / 4) >> bits;
-    return std::max(1, std::min(p3 ? 16 : 14, (1 << bits) * std::max(cap - group, 4) * 5 / 8 / PS_THREADS));
+    // (512 bins: rings of 64 entries -- 10 loads put 20 entries into a bin per round against 33 free slots at worst, and 1.5 rings per round
+    //  overflow into the wait path; 8 measured 0.18 ms better on the 62-genome text at f = 38, 6 the same, 12 far worse: TPC_SPLIT_LOADS9)
+    const int most = p3 ? 16 : bits >= 9 ? 8 : 14;
+    return std::max(1, std::min(most, (1 << bits) * std::max(cap - group, 4) * 5 / 8 / PS_THREADS));
 }
 
 int launch_split(const TpcLaunch &a, const TpcPartPlan &pl)
