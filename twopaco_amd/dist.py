@@ -881,10 +881,21 @@ def merge_records(parts, rec_start, rec_length, k, n_junctions):
     return out
 
 
+_LINE_FD = None  # the process's real stdout while a bench run keeps descriptor 1 on stderr (bench_main)
+
+
 def bench_main(args, rank, world, local_rank, backend_factory=None, golden=None, cpu_baseline=None, e2e=None):
     """Fail-fast wrapper: any exception on any rank ends THAT process with a non-zero exit code at once (the phase it was in on
     stderr) -- under torch.distributed.run the agent then stops the other ranks; ranks blocked in a collective are ended by
     their own watchdog (PhaseWatchdog).  No line is printed by a run that did not complete on every rank."""
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner there when its first communicator comes up (at the first
+    # collective, not at init_process_group), and whatever else a library writes to file descriptor 1 would land beside the line too: for
+    # the length of the run descriptor 1 points at stderr, and the line goes to the real stdout (_LINE_FD) at the very end.
+    global _LINE_FD
+    sys.stdout.flush()
+    if _LINE_FD is None:
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
     try:
         return _bench_main(args, rank, world, local_rank, backend_factory, golden, cpu_baseline, e2e)
     except SystemExit:
@@ -1163,5 +1174,10 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         ctypes.CDLL(None).fflush(None)
     except Exception:  # noqa: BLE001
         pass
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    line = (json.dumps(out) + "\n").encode()
+    if _LINE_FD is not None:
+        os.write(_LINE_FD, line)
+    else:
+        os.write(1, line)
     return 0
