@@ -400,6 +400,90 @@ def test_partitioned_query_adversarial_skew(capi, slice_bits):
     assert (masks[0][1] == masks[1][1]).all()
 
 
+def _tract_records(rng, n_bases, k):
+    """Random sequence with homopolymer / dinucleotide / trinucleotide tracts -- also across the 16384-position tile boundaries, with an N
+    inside some, at the very start and end of records -- plus short records."""
+    a = rng.integers(0, 4, n_bases).astype(np.uint8)
+    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [2]]
+    for t in range(60):
+        unit = units[t % len(units)]
+        ln = int(rng.integers(k + 3, 900))
+        at = int(rng.integers(0, n_bases - ln))
+        if t % 4 == 0:  # straddle a tile boundary of the global text (record starts are offset by one separator each: close enough, and varied)
+            at = min(n_bases - ln, max(0, 16384 * int(rng.integers(1, max(2, n_bases // 16384))) - int(rng.integers(0, ln))))
+        a[at:at + ln] = np.resize(np.array(unit, dtype=np.uint8), ln)
+        if t % 5 == 0:
+            a[at + ln // 2] = 4  # an N inside the tract
+    a[:300] = 0          # the record begins inside a tract
+    a[-200:] = np.resize(np.array([1, 0], dtype=np.uint8), 200)  # and ends inside one
+    recs = [a, np.zeros(k + 1, dtype=np.uint8), np.zeros(k - 1, dtype=np.uint8), np.resize(np.array([1, 0], dtype=np.uint8), 5000), np.zeros(40000, dtype=np.uint8)]
+    return recs
+
+
+@pytest.mark.parametrize("k,L,q,budget", [(25, 28, 5, 0), (5, 22, 3, 0), (51, 28, 2, 0), (25, 28, 5, 2 << 20), (31, 34, 5, 0)])
+def test_periodic_windows_are_skipped_and_copied(capi, k, L, q, budget):
+    """Positions whose window repeats the one 1 or 2 positions earlier (poly-A, (CA)n) send nothing in the partitioned passes: the insert
+    drops their out-edge (per_i), the query drops their probes and k_periodic_copy gives them the twin's verdict (tpc_qpartition.hip:
+    k_periodic_build).  Filter bitmap, candidate mask and count equal the oracle's -- whole range and two gated half ranges -- and equal the
+    run with option periodic_skip = 0; tracts across tile boundaries, with N inside, at record ends, records shorter than k, in batches."""
+    rng = np.random.default_rng(17 + k)
+    recs = _tract_records(rng, 150000, k)
+    text = capi.PackedText.from_codes(recs)
+    o = O.Oracle(k, L, q, O.seed_table(23, q, L))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for r in recs:
+        o.add_record(letters[r].tobytes())
+    half = 1 << (L - 1)
+    for skip in (1, 0):
+        ctx = capi.Context(0)
+        try:
+            for opt, val in (("insert_mode", 2), ("query_mode", 2), ("periodic_skip", skip)):
+                ctx.set_option(opt, val)
+            if budget:
+                ctx.set_option("part_min_tiles", 1)
+                ctx.set_option("part_budget_bytes", budget)
+            ctx.set_params(k, L, q, capi.seed_table(q, L, seed=23))
+            ctx.seq_upload(text)
+            for lo, hi in ((0, 1 << L), (0, half - 1), (half, (1 << L) - 1)):
+                o.fill_only(lo, hi)
+                marks = o.check_only(lo, hi)
+                ctx.filter_reset()
+                ctx.pass1_insert(lo, hi)
+                assert ctx.pass1_query(lo, hi) == marks, (skip, lo, hi)
+                if skip:  # (without it the 40 kbp poly-A record overflows the query's lists and the direct kernel completes the pass: path 12)
+                    assert ctx.stat("insert_path") in (2, 3) and ctx.stat("query_path") in (2, 3)
+                assert ctx.stat("periodic_skip") == skip
+                assert (ctx.mask_download(False) == o.round_mask).all(), (skip, lo, hi)
+                assert (ctx.filter_download() == o.filter).all(), (skip, lo, hi)
+        finally:
+            ctx.close()
+
+
+def test_periodic_skip_takes_the_tracts_out_of_the_overflow_lists(capi):
+    """Poly-A and (CA)n tracts at m2r's density on a 2 Mbp text: with every position probing, their entries overflow rings and regions
+    by the tens of thousands; skipped at the source almost none do, and the k-mer count (now its own kernel) is the oracle's."""
+    from twopaco_amd import synth
+    recs, p = synth.workload("m2r", scale=0.004, m2r_features=("tracts",))
+    text = capi.PackedText.from_codes(recs)
+    got = {}
+    for skip in (1, 0):
+        ctx = capi.Context(0)
+        try:
+            for opt, val in (("insert_mode", 2), ("query_mode", 2), ("periodic_skip", skip)):
+                ctx.set_option(opt, val)
+            ctx.set_params(25, 30, 5, capi.seed_table(5, 30, seed=3))
+            ctx.seq_upload(text)
+            ctx.filter_reset()
+            kmers = ctx.pass1_insert(count=True)
+            n = ctx.pass1_query()
+            got[skip] = (n, ctx.mask_download(False), ctx.filter_download(), ctx.stat("insert_overflow_entries") + ctx.stat("query_overflow_entries"), kmers)
+        finally:
+            ctx.close()
+    assert got[1][0] == got[0][0] > 0 and (got[1][1] == got[0][1]).all() and (got[1][2] == got[0][2]).all()
+    assert got[1][4] == got[0][4] == synth.n_kmers(recs, 25)
+    assert got[1][3] * 4 < got[0][3] + 4, (got[1][3], got[0][3])
+
+
 @pytest.mark.parametrize("budget", [0, 3 << 20])
 def test_six_byte_query_entries_many_groups(capi, budget):
     """The 48-bit level-2 query entries (tpc_qpart6.h) carry the low bits of a position; its GROUP is implicit in where the entry

@@ -28,6 +28,11 @@ struct tpc_ctx {
     uint64_t *bases = nullptr;
     uint32_t *nmask = nullptr;
     uint64_t n_text = 0, n_words = 0, n_words_alloc = 0, n_tiles = 0;
+    // periodic-window masks of the text (tpc_internal.h:TpcLaunch): [3][n_words_alloc] = per_qs, per_q1, per_i; built at the first
+    // partitioned pass after an upload / a change of k (ensure_periodic), option "periodic_skip" (default on)
+    uint32_t *periodic = nullptr;
+    bool periodic_valid = false;
+    int opt_periodic = 1;
     // sharded contexts may hold only the words of the tiles they hash (+ halo): bases / nmask then point text_w0 words BEFORE
     // the allocations, so that kernels keep indexing by global word
     uint64_t *bases_alloc = nullptr;
@@ -172,6 +177,27 @@ TpcLaunch make_launch(const tpc_ctx *c)
     a.P = c->P; a.tab = c->tab; a.bases = c->bases; a.nmask = c->nmask; a.n_text = c->n_text;
     a.n_tiles = c->n_tiles; a.filter = c->filter; a.stream = c->stream;
     return a;
+}
+
+// make_launch + the periodic-window masks: for the hash kernels of tpc_pass1_insert / tpc_pass1_query only (their query copies the verdicts
+// afterwards; the sharded calls mark through other kernels and keep every position probing)
+TpcLaunch make_launch_periodic(const tpc_ctx *c)
+{
+    TpcLaunch a = make_launch(c);
+    if (c->periodic && c->periodic_valid) { a.per_qs = c->periodic; a.per_q1 = c->periodic + c->n_words_alloc; a.per_i = c->periodic + 2 * c->n_words_alloc; }
+    return a;
+}
+
+// The periodic-window masks of this text and k, built once (0.6 ms on the 62-genome text).  Not for sharded contexts (their verification
+// marks through other calls: every position probes there) nor for a text window.  A failed allocation just leaves the feature off.
+void ensure_periodic(tpc_ctx *c)
+{
+    if (c->periodic_valid || !c->opt_periodic || c->sh_world > 1 || c->text_windowed || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
+    if (!c->periodic && hipMalloc((void **)&c->periodic, 3 * c->n_words_alloc * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
+    TpcLaunch a = make_launch(c);
+    if (hipMemsetAsync(c->periodic, 0, 3 * c->n_words_alloc * sizeof(uint32_t), c->stream) != hipSuccess) return;
+    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, c->n_words);
+    c->periodic_valid = true;
 }
 
 uint64_t rotln_host(uint64_t x, int L, int r)
@@ -432,6 +458,7 @@ void tpc_ctx_destroy(tpc_ctx *c)
     stream_part_release(c);
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
+    if (c->periodic) (void)hipFree(c->periodic);
     if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
     if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
     if (c->iovf_off) (void)hipFree(c->iovf_off);
@@ -457,6 +484,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     if (!strcmp(name, "test_q6_pb2")) { tpc_test_q6_pb2 = (int)value; return 0; }  // process-wide, tests only
     if (!strcmp(name, "insert_entry_fmt")) { tpc_test_insert_p3 = value == 3; return 0; }  // process-wide; 3 = blocked 24-bit level-2 insert entries (off by default: tpc_partition.hip)
+    if (!strcmp(name, "periodic_skip")) { c->opt_periodic = value != 0; if (!value) c->periodic_valid = false; return 0; }  // 0: every position inserts and probes for itself
     if (!strcmp(name, "test_tight_pinch")) { tpc_test_tight_pinch = (int)value; c->sh_have[0] = c->sh_have[1] = false; return 0; }  // process-wide, tests only
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
@@ -503,6 +531,7 @@ int64_t tpc_get_stat(const tpc_ctx *c, const char *name)
     if (!strcmp(name, "fused_lookups")) return c->stat_fused;
     if (!strcmp(name, "query_overflow_entries")) return c->stat_query_overflow;
     if (!strcmp(name, "insert_overflow_entries")) return c->stat_insert_overflow;
+    if (!strcmp(name, "periodic_skip")) return c->periodic_valid ? 1 : 0;
     if (!strcmp(name, "pbuf_releases")) return c->stat_pbuf_releases;
     if (!strcmp(name, "text_words")) return (int64_t)(c->text_w1 - c->text_w0);  // packed words of the text this context holds
     if (!strcmp(name, "device_free_bytes") || !strcmp(name, "device_total_bytes")) {  // hipMemGetInfo of the context's device, now
@@ -544,6 +573,7 @@ int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
         c->filter_words = fw;
     }
     c->have_params = true;
+    c->periodic_valid = false;  // (k)
     c->pending_apply = false;
     c->n_keys = 0; c->finalized = false; c->rounds_done = 0; c->mask_dirty = false; c->marks_valid = false; c->rmask_sums_valid = false;
     return 0;
@@ -573,8 +603,9 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
         w1 = std::min<uint64_t>(alloc, tb * 512 + TPC_XW_MAX + 2);
         if (w1 <= w0) w1 = w0 + 1;
     }
-    for (void *p : { (void *)c->bases_alloc, (void *)c->nmask_alloc, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums })
+    for (void *p : { (void *)c->bases_alloc, (void *)c->nmask_alloc, (void *)c->rmask, (void *)c->mask, (void *)c->block_sums, (void *)c->periodic })
         if (p) (void)hipFree(p);
+    c->periodic = nullptr; c->periodic_valid = false;
     c->bases = nullptr; c->nmask = nullptr; c->bases_alloc = nullptr; c->nmask_alloc = nullptr; c->rmask = nullptr; c->mask = nullptr; c->block_sums = nullptr;
     const uint64_t wn = w1 - w0;
     // through dev_malloc: a reservation made before the upload (tpc_reserve) is given back when the text does not fit beside it
@@ -639,6 +670,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }
+    ensure_periodic(c);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
     TpcPartPlan pl;
     const double m_ins = gated ? range_mass(c, lo, hi) : 1.0;
@@ -708,7 +740,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                 if (defer) {  // levels 1 and 2 only; whether the apply can wait is known once the overflow count is back
                     TpcPartPlan p1 = pl;
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
-                    if (tpc_launch_insert_part_hash(make_launch(c), p1, lo, hi, gated, n_kmers ? c->counters : nullptr) ||
+                    if (tpc_launch_insert_part_hash(make_launch_periodic(c), p1, lo, hi, gated, n_kmers ? c->counters : nullptr) ||
                         tpc_launch_insert_part_split(make_launch(c), p1)) return fail(c, -1, "partitioned insert launch failed");
                     HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -739,7 +771,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                     else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
                     break;
                 }
-                if (tpc_launch_insert_partitioned(make_launch(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
+                if (tpc_launch_insert_partitioned(make_launch_periodic(c), pl, lo, hi, gated, fresh, n_kmers ? c->counters : nullptr))
                     return fail(c, -1, "partitioned insert launch failed");
                 fresh = false;  // later batches OR into the slices
                 HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
@@ -874,6 +906,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     c->marks_valid = false; c->rmask_sums_valid = false;
+    ensure_periodic(c);
     TpcQPlan pl;
     const uint64_t tiles = text_tiles512(c);
     bool part = plan_query(c, lo, hi, gated, pl);
@@ -916,7 +949,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
                     c->pending_apply = false;
                     c->stat_fused++;
-                    if (tpc_launch_query_part_hash(make_launch(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+                    if (tpc_launch_query_part_hash(make_launch_periodic(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                     {
                         Timed tf(c, TPC_K_FUSED);
                         if (tpc_launch_query_part_fused_lookup(make_launch(c), p1, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
@@ -924,7 +957,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     }
                     if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");
                 } else
-                if (tpc_launch_query_partitioned(make_launch(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+                if (tpc_launch_query_partitioned(make_launch_periodic(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                 HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
                 if (t0 + per < tiles) {
@@ -945,6 +978,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     if (surv > 0) pl.group_survivors = batch_marks * 4 >= surv;
                 }
             }
+            if (c->periodic_valid) tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);  // positions that sent no probes take their twin's verdict
             tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
         }
         HIPCHK(c, hipGetLastError());

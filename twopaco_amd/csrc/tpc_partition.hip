@@ -186,8 +186,11 @@ template <int Q, bool GATED, bool SHARDED, bool LHI>
 __global__ void __launch_bounds__(PH_THREADS)
 k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
              const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
-             uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows)
-{   // LHI: L > 32.  Every L-bit value lives in two separate 32-bit registers (LeanV, tpc_lean.h: round 4); for L <= 32 the high
+             uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows,
+             const uint32_t *__restrict__ skip32)
+{   // skip32 (tpc_qpartition.hip:k_periodic_build's per_i, or nullptr): positions whose out-edge repeats the one of the position one or two
+    // before them insert nothing.
+    // LHI: L > 32.  Every L-bit value lives in two separate 32-bit registers (LeanV, tpc_lean.h: round 4); for L <= 32 the high
     // halves do not exist.
     using V = LeanV<LHI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,7 +229,6 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
     S.set(perm, LOG_NB);
     const int xw = (k + 1) / 32 + 2;
     const uint32_t p0 = 32u + (uint32_t)lt * 32u;  // my first position relative to the first staged word (the one before the tile)
-    unsigned hashed = 0;
     int since_flush = 0;
     // the q Bloom addresses of one edge -> bins
     auto emit_edge = [&](const V (&a)[Q]) {
@@ -248,6 +250,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
         const uint64_t tile = pair + half;
         const bool have = tile < tile0 + n_tiles;
         const uint64_t wfirst = tile * PT_THREADS;
+        const uint32_t sk = have && skip32 ? skip32[wfirst + (uint64_t)lt] : 0u;  // (issued with the staging loads: its round trip hides behind theirs)
         for (int i = lt; i < PT_THREADS + 1 + xw; i += PT_THREADS) {
             const int64_t w = (int64_t)wfirst - 1 + i;
             uint64_t b = have && w >= 0 ? bases[w] : 0ull;
@@ -319,7 +322,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                 const uint64_t first = lv_u64<LHI>(lv_min<LHI>(pos[0], neg[0])), second = lv_u64<LHI>(lv_min<LHI>(np0, nn0));
                 go = (first >= lo && first <= hi) || (second >= lo && second <= hi);
             }
-            const bool main_edge = go && cn < 4u;
+            const bool main_edge = go && cn < 4u && !__builtin_amdgcn_ubfe(sk, (uint32_t)s, 1u);
             if (go && (cn | cp) >= 4u) {  // rare: the dummy edges beside an N (VE.h:1048-1058), from the window's hashes before they roll
                 const bool out_side = cn >= 4u, in_side = cp >= 4u;
 #pragma unroll 1
@@ -368,7 +371,6 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
                 neg[i] = R.rotr1(lv_xor<LHI>(en, eF.z, eF.w));
             }
             if (main_edge) emit_edge(a);
-            hashed += vertex;
             ncnt += (int)(cn >> 2) - (int)(cf >> 2);
             cp = cf;
             if (++since_flush == pos_per_round) { bins.template flush<false>(lost); since_flush = 0; }
@@ -376,15 +378,30 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
     }
     bins.template flush<true>(lost);
     bins.store_counts(cnt1, ridx);
-    if (n_kmers) {
-        for (int off = 32; off > 0; off >>= 1) hashed += __shfl_down(hashed, off, 64);
-        if ((tid & 63) == 0) s_w[tid >> 6] = hashed;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned t = 0;
-            for (int i = 0; i < PH_THREADS / 64; i++) t += s_w[i];
-            if (t) atomicAdd(n_kmers, (unsigned long long)t);
+    (void)n_kmers;  // (the vertex count is a property of the text: k_count_kmers, launched beside this kernel when a count is asked for --
+                    //  it cost this kernel a register and an instruction per position, used or not)
+}
+
+// vertex k-mers (windows of k definite characters) starting in the words [w0, w1): what FilterFillerWorker counts as it goes (VE.h:1033)
+__global__ void __launch_bounds__(256) k_count_kmers(const uint32_t *__restrict__ nmask, int k, uint64_t w0, uint64_t w1, unsigned long long *n_kmers)
+{
+    __shared__ uint32_t s_w[4];
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t n = 0;
+    if (w < w1) {
+        const uint64_t first = w << 5;
+        int run = 0;
+        for (uint64_t j = first; j < first + 31 + (uint64_t)k; j++) {
+            run = (nmask[j >> 5] >> (j & 31u)) & 1u ? 0 : run + 1;
+            if (j + 1 >= first + (uint64_t)k && run >= k) n++;
         }
+    }
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (t) atomicAdd(n_kmers, (unsigned long long)t);
     }
 }
 
@@ -577,7 +594,8 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
     do {                                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_part_hash2<Q, G, S, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         hipLaunchKernelGGL((k_part_hash2<Q, G, S, H>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
-                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers, seed_rows);  \
+                           pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers, seed_rows,   \
+                           pl.world == 1 ? a.per_i : (const uint32_t *)nullptr);                                                          \
     } while (0)
 #define TPC_HASH2_GS(H)                                                                                                                     \
     do {                                                                                                                                    \
@@ -585,6 +603,10 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
         else { if (gated) TPC_HASH2_GO(true, false, H); else TPC_HASH2_GO(false, false, H); }                                               \
     } while (0)
         if (a.P.L > 32) TPC_HASH2_GS(true); else TPC_HASH2_GS(false);  // L-bit values on 32-bit halves: no high halves at all for L <= 32
+        if (n_kmers && pl.n_tiles) {
+            const uint64_t w0 = pl.tile0 * PT_THREADS, w1 = (pl.tile0 + pl.n_tiles) * PT_THREADS;
+            hipLaunchKernelGGL(k_count_kmers, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, a.stream, a.nmask, a.P.k, w0, w1, n_kmers);
+        }
 #undef TPC_HASH2_GS
 #undef TPC_HASH2_GO
         return 0;

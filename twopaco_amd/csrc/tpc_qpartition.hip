@@ -252,8 +252,10 @@ __global__ void __launch_bounds__(QH_THREADS)
 k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases,
           const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round,
           uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
-          uint64_t gbase, uint32_t *__restrict__ rmask, uint32_t tiles_per_wg)
+          uint64_t gbase, uint32_t *__restrict__ rmask, uint32_t tiles_per_wg, const uint16_t *__restrict__ skip16)
 {   // LHI: L > 32; L-bit values on two separate 32-bit registers (LeanV, tpc_lean.h: round 4)
+    // skip16 (k_periodic_build's per_qs, or nullptr): positions whose k + 2 characters repeat those of the position one or two before
+    // them send no probes -- k_periodic_copy gives them that position's verdict after the verification
     // tiles_per_wg > 0: workgroup w takes the tiles [w T, (w + 1) T) of the batch instead of w, w + nwg, ...: its regions then hold
     // ascending positions, which the 6-byte level-2 entries rely on (k_q_split<.., P6>)
     using V = LeanV<LHI>;
@@ -303,8 +305,9 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
     const uint64_t t_end = tiles_per_wg ? min(tile0 + n_tiles, t_first + tiles_per_wg) : tile0 + n_tiles;
     const uint64_t t_step = tiles_per_wg ? 1u : gridDim.x;
     for (uint64_t tile = t_first; tile < t_end; tile += t_step) {
-        __syncthreads();
         const uint64_t wfirst = tile * PT_THREADS;
+        __syncthreads();
+        const uint32_t sk = skip16 ? (uint32_t)skip16[(wfirst * 2) + tid] : 0u;  // (issued with the staging loads below: its round trip hides behind theirs)
         for (int i = (int)tid; i < PT_THREADS + 1 + xw; i += QH_THREADS) {
             const int64_t w = (int64_t)wfirst - 1 + i;
             uint64_t b = w >= 0 ? bases[w] : 0ull;
@@ -360,7 +363,7 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
             uint64_t ev[8];
             bool eok[8];
             bool probing = false;
-            if (check && !nadj) {
+            if (check && !nadj && !__builtin_amdgcn_ubfe(sk, (uint32_t)s, 1u)) {
                 const uint32_t hi_s = sid0 + (uint32_t)(s << 2);  // (survivor id >> 1) without the edge: position << 2
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -1492,7 +1495,8 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
         (void)hipFuncSetAttribute((const void *)k_q_hash2<G, S, H, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         hipLaunchKernelGGL((k_q_hash2<G, S, H, X>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
-                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask, pl.fmt == 6 ? pl.tiles_per_wg : 0u);                 \
+                           pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask, pl.fmt == 6 ? pl.tiles_per_wg : 0u,                  \
+                           pl.world == 1 ? reinterpret_cast<const uint16_t *>(a.per_qs) : (const uint16_t *)nullptr);                       \
     } while (0)
 #define TPC_QHASH2_GS(H, X)                                                                                                                 \
     do {                                                                                                                                    \
@@ -1522,6 +1526,80 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
     if (rb) TPC_QHASH_GS(true); else TPC_QHASH_GS(false);
 #undef TPC_QHASH_GS
 #undef TPC_QHASH_GO
+}
+
+// ------------------------------------------------------------------------------------------ periodic windows
+// A homopolymer or dinucleotide tract sends the SAME six probes (and the same q insert addresses) from hundreds of consecutive positions:
+// bursts of identical entries for one ring of one level-2 workgroup, in every such tract of the input -- m2r's tracts, 0.13 % of its text,
+// cost the two split kernels 2.4 ms (DESIGN_HISTORY.md, round 5; four attempts to make the overflow path cheap enough failed).  They are
+// removed at the source instead.  Both passes are functions of a window of the text: the first-pass verdict of the vertex at i of the
+// k + 2 characters T[i - 1 .. i + k] (VE.h:633-674), the insert of its out-edge of T[i .. i + k] (VE.h:1035-1092).  When such a window
+// equals the one p = 1 or 2 positions earlier, character for character and all of them definite, the position repeats that one's work:
+// its insert is dropped (per_i; OR is idempotent), and its probes are dropped (per_qs) and its mark copied from position i - p once the
+// verification is done (k_periodic_copy).  The masks depend on the text and k alone: built once per upload.
+// Thread = one word of 32 positions.  c_p(j) = length of the run of j' <= j with T[j'] == T[j' - p], both definite; window ending at j = i + k.
+__global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
+                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t n_words)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t oqs = 0, oq1 = 0, oin = 0;
+    const int64_t first = (int64_t)(w << 5);
+    if ((uint64_t)first < n_text) {
+        auto ch_at = [&](int64_t j) { return j >= 0 && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
+        const int64_t j0 = first - 2;  // (run lengths only matter up to k + 2: starting k + 2 characters before the first window's end is exact)
+        int prev1 = ch_at(j0 - 1), prev2 = ch_at(j0 - 2), c1 = 0, c2 = 0;
+        for (int64_t j = j0; j <= first + 31 + k; j++) {
+            const int ch = ch_at(j);
+            c1 = ch < 4 && ch == prev1 ? c1 + 1 : 0;
+            c2 = ch < 4 && ch == prev2 ? c2 + 1 : 0;
+            prev2 = prev1; prev1 = ch;
+            const int64_t i = j - k;
+            if (i < first) continue;
+            const uint32_t bit = 1u << (uint32_t)(i - first);
+            if (c1 >= k + 1 || c2 >= k + 1) oin |= bit;
+            // the position it copies from lies in the same 512-word tile, and the first two positions of a tile always probe: a run of
+            // copying positions never crosses a tile (batches and ranks are made of tiles) and k_periodic_copy's walks end there
+            if (((uint32_t)i & (uint32_t)(PT_THREADS * TPC_RUN - 1)) >= 2u) {
+                if (c1 >= k + 2) { oqs |= bit; oq1 |= bit; }
+                else if (c2 >= k + 2) oqs |= bit;
+            }
+        }
+    }
+    qs[w] = oqs; q1[w] = oq1; ins[w] = oin;
+}
+
+// mark(i) = mark(i - 1) where q1 is set, mark(i - 2) where only qs is.  A segment = a maximal stretch of positions in which no two
+// consecutive ones probe themselves; it starts at a copying position whose two predecessors probed (their marks are final) and is
+// walked by one thread, so every position's source -- inside the segment or one of those two -- is known when it is needed.
+__global__ void __launch_bounds__(256) k_periodic_copy(uint32_t *__restrict__ rmask, const uint32_t *__restrict__ qs, const uint32_t *__restrict__ q1, uint64_t n_words)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t S = qs[w];
+    if (S == 0u) return;
+    const uint32_t Sp = w ? qs[w - 1] : 0u;
+    uint32_t starts = S & ~((S << 1) | (Sp >> 31)) & ~((S << 2) | (Sp >> 30));
+    auto bit_of = [](const uint32_t *m, uint64_t i) { return (m[i >> 5] >> (i & 31u)) & 1u; };
+    const uint64_t n_pos = n_words << 5;
+    while (starts) {
+        const uint32_t b = (uint32_t)__ffs((int)starts) - 1u;
+        starts &= starts - 1u;
+        uint64_t i = (w << 5) + b;  // (>= 2: the first two positions of a tile never copy)
+        uint32_t m1 = bit_of(rmask, i - 1), m2 = bit_of(rmask, i - 2);
+        for (int zeros = 0; i < n_pos; i++) {
+            uint32_t m;
+            if (bit_of(qs, i)) {
+                zeros = 0;
+                m = bit_of(q1, i) ? m1 : m2;
+                if (m) atomicOr(&rmask[i >> 5], 1u << (i & 31u));
+            } else {
+                if (++zeros == 2) break;
+                m = bit_of(rmask, i);
+            }
+            m2 = m1; m1 = m;
+        }
+    }
 }
 
 // one level of k_q_split: log_nb1 bits already binned, log_nb2 bits binned here; nvw source regions per bucket
@@ -2030,3 +2108,15 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
 // tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_qpartition() {}
 int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }
+
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t n_words)
+{
+    if (n_words) hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, q1, ins, n_words);
+    return 0;
+}
+
+int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *q1, uint64_t n_words)
+{
+    if (n_words) hipLaunchKernelGGL(k_periodic_copy, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, rmask, qs, q1, n_words);
+    return 0;
+}
