@@ -1581,24 +1581,35 @@ __global__ void __launch_bounds__(256) k_periodic_copy(uint32_t *__restrict__ rm
     const uint32_t Sp = w ? qs[w - 1] : 0u;
     uint32_t starts = S & ~((S << 1) | (Sp >> 31)) & ~((S << 2) | (Sp >> 30));
     auto bit_of = [](const uint32_t *m, uint64_t i) { return (m[i >> 5] >> (i & 31u)) & 1u; };
-    const uint64_t n_pos = n_words << 5;
     while (starts) {
         const uint32_t b = (uint32_t)__ffs((int)starts) - 1u;
         starts &= starts - 1u;
         uint64_t i = (w << 5) + b;  // (>= 2: the first two positions of a tile never copy)
         uint32_t m1 = bit_of(rmask, i - 1), m2 = bit_of(rmask, i - 2);
-        for (int zeros = 0; i < n_pos; i++) {
+        // the walk keeps the three words of the 32 positions at hand in registers (a 500-position tract is 16 word fetches, not 1500 loads
+        // one after the other: the kernel lasts as long as its longest walk)
+        uint64_t cw = i >> 5;
+        uint32_t sw = S, qw = q1[cw], rw = rmask[cw], add = 0;
+        for (int zeros = 0;; i++) {
+            if ((i >> 5) != cw) {
+                if (add) atomicOr(&rmask[cw], add);
+                cw = i >> 5;
+                if (cw >= n_words) { add = 0; break; }
+                sw = qs[cw]; qw = q1[cw]; rw = rmask[cw]; add = 0;
+            }
+            const uint32_t bi = (uint32_t)i & 31u;
             uint32_t m;
-            if (bit_of(qs, i)) {
+            if ((sw >> bi) & 1u) {
                 zeros = 0;
-                m = bit_of(q1, i) ? m1 : m2;
-                if (m) atomicOr(&rmask[i >> 5], 1u << (i & 31u));
+                m = (qw >> bi) & 1u ? m1 : m2;
+                add |= m << bi;
             } else {
                 if (++zeros == 2) break;
-                m = bit_of(rmask, i);
+                m = (rw >> bi) & 1u;  // (a probing position: its mark is final, and no walk ever sets it)
             }
             m2 = m1; m1 = m;
         }
+        if (add) atomicOr(&rmask[cw], add);
     }
 }
 
