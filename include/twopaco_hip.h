@@ -217,6 +217,15 @@ void tpc_host_free(void *ptr);
  * so none of the routing calls below is needed (reference: CandidateCheckingWorker's remaining probes, vertexenumerator.h:640-660). */
 int tpc_shard_verify_local(tpc_ctx *ctx);
 
+/* Periodic windows under sharding.  A position whose k + 2 characters repeat those of the position 1 or 2 before it (homopolymer and
+ * dinucleotide tracts) would send the same probes and the same insert as that position (CandidateCheckingWorker / FilterFillerWorker see
+ * the same window: vertexenumerator.h:633-674, 1035-1092); the one-GPU passes skip such positions and copy the verdict afterwards.  A host
+ * of the sharded calls opts in with tpc_set_option(ctx, "shard_periodic_skip", 1) before tpc_shard_plan -- tpc_shard_hash then skips them
+ * too -- and MUST call tpc_shard_periodic_copy once per round, after the marks of the round's last query batch (tpc_shard_finish /
+ * tpc_shard_mark / tpc_shard_verify_local) and before anything reads the round mask (mask union, tpc_pass2_marks).  The source of a copy
+ * lies in the same 512-word tile, i.e. on the same rank.  Without the option nothing is skipped and the call does nothing. */
+int tpc_shard_periodic_copy(tpc_ctx *ctx);
+
 /* ---- address-sharded filter (multi-GPU) -------------------------------------------------
  * The Bloom filter (ConcurrentBitVector bitVector, VE.h:257) is cut over `world` ranks (a power of
  * two) by bit address: the partitioned passes route every address to the workgroup that owns its

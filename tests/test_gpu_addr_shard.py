@@ -148,14 +148,19 @@ def test_overflowing_tight_regions_are_replanned_once(world, tmp_path):
     check(spec, o, gathered, world)
 
 
-@pytest.mark.parametrize("world,compact", [(2, False), (4, True)])
-def test_low_complexity_input_through_the_sharded_path(world, compact, tmp_path):
+@pytest.mark.parametrize("world,compact,periodic", [(2, False, 0), (4, True, 0), (2, True, 1), (4, False, 1)])
+def test_low_complexity_input_through_the_sharded_path(world, compact, periodic, tmp_path, monkeypatch):
     """m2r at 1/50 scale -- repeat families, poly-A / poly-T / (CA)n / (GT)n tracts, two genomes on the other strand, contigs -- with the
-    default tight regions: the tracts' entries overflow their regions (thousands of identical addresses per workgroup), travel as
-    all-gathered lists and are applied by their owners; filter, masks and ids are the oracle's."""
-    spec, o = _synthetic("m2r", 0.02, 26, 7, {"slice_bits": 14, "part_min_tiles": 1}, compact_exchange=compact)
+    default tight regions.  periodic = 0 (TPC_SHARD_PERIODIC=0): every position probes; the tracts' entries overflow their regions
+    (thousands of identical addresses per workgroup), travel as all-gathered lists and are applied by their owners.  periodic = 1 (the
+    default): positions that repeat their neighbour's window send nothing (option shard_periodic_skip) and tpc_shard_periodic_copy gives
+    them its verdict after the last batch -- on ranks that hold only their window of the text as well.  Filter, masks and ids are the oracle's."""
+    monkeypatch.setenv("TPC_SHARD_PERIODIC", str(periodic))
+    spec, o = _synthetic("m2r", 0.02, 26, 7, {"slice_bits": 14, "part_min_tiles": 1}, compact_exchange=compact, sharded_pass2="records" if periodic and world == 4 else False,
+                         text_window=bool(periodic and world == 4))
     gathered = run(spec, world, tmp_path)
-    assert sum(g["overflow_entries"] for g in gathered) > 0
+    if not periodic:
+        assert sum(g["overflow_entries"] for g in gathered) > 0
     check(spec, o, gathered, world)
 
 

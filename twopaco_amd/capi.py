@@ -25,7 +25,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part",
-               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish", "tpc_shard_verify_local"]
+               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish", "tpc_shard_verify_local", "tpc_shard_periodic_copy"]
 
 _hip = None
 _host = None
@@ -103,6 +103,7 @@ def hip():
         L.tpc_shard_verify_send.argtypes = [p, ci, ci, p, u64, p, p, p, p]
         L.tpc_shard_finish.argtypes = [p, p, u64, ci, p, p, p]
         L.tpc_shard_verify_local.argtypes = [p]
+        L.tpc_shard_periodic_copy.argtypes = [p]
         L.tpc_shard_survivors.argtypes = [p, p]
         L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
         L.tpc_shard_survivor_sources.argtypes = [p, p, u64, p]
@@ -471,6 +472,10 @@ class Context:
         m = ctypes.c_uint64(0)
         self._ck(hip().tpc_shard_finish(self._h, sid_ptr, n, fn_count, hit_ptr, perm_ptr, ctypes.byref(m)))
         return m.value
+
+    def shard_periodic_copy(self):
+        """After a round's last query batch on a context with option shard_periodic_skip: positions that sent no probes take their twin's verdict."""
+        self._ck(hip().tpc_shard_periodic_copy(self._h))
 
     def shard_verify_local(self):
         """One rank: verifies and marks the survivors of the last shard_apply(QUERY) where they are."""

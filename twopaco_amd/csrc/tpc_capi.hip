@@ -33,6 +33,7 @@ struct tpc_ctx {
     uint32_t *periodic = nullptr;
     bool periodic_valid = false;
     int opt_periodic = 1;
+    bool opt_shard_periodic = false;  // option shard_periodic_skip: the tpc_shard_hash kernels skip too, the host calls tpc_shard_periodic_copy
     // sharded contexts may hold only the words of the tiles they hash (+ halo): bases / nmask then point text_w0 words BEFORE
     // the allocations, so that kernels keep indexing by global word
     uint64_t *bases_alloc = nullptr;
@@ -188,15 +189,20 @@ TpcLaunch make_launch_periodic(const tpc_ctx *c)
     return a;
 }
 
-// The periodic-window masks of this text and k, built once (0.6 ms on the 62-genome text).  Not for sharded contexts (their verification
-// marks through other calls: every position probes there) nor for a text window.  A failed allocation just leaves the feature off.
+// The periodic-window masks of this text and k, built once (0.6 ms on the 62-genome text).  The one-GPU passes use them by default; a sharded
+// context only when its host opted in (option shard_periodic_skip: that host calls tpc_shard_periodic_copy after a round's last batch).  A
+// context that holds a window of the text builds the masks of its window (characters outside count as N: no skipping across its edges).
+// A failed allocation just leaves the feature off.
 void ensure_periodic(tpc_ctx *c)
 {
-    if (c->periodic_valid || !c->opt_periodic || c->sh_world > 1 || c->text_windowed || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
+    if (c->periodic_valid || !c->opt_periodic || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
+    if ((c->sh_world > 1 || c->text_windowed) && !c->opt_shard_periodic) return;
     if (!c->periodic && hipMalloc((void **)&c->periodic, 3 * c->n_words_alloc * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
     TpcLaunch a = make_launch(c);
     if (hipMemsetAsync(c->periodic, 0, 3 * c->n_words_alloc * sizeof(uint32_t), c->stream) != hipSuccess) return;
-    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, c->n_words);
+    const uint64_t w0 = c->text_windowed ? c->text_w0 : 0, w1 = c->text_windowed ? std::min(c->text_w1, c->n_words) : c->n_words;
+    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, w0, w1, w0 << 5, c->text_windowed ? c->text_w1 << 5 : ~0ull);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return;  // (a sharded hash may run on the second stream)
     c->periodic_valid = true;
 }
 
@@ -484,6 +490,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "fuse_apply_lookup")) { c->opt_fuse = value != 0; return 0; }
     if (!strcmp(name, "test_q6_pb2")) { tpc_test_q6_pb2 = (int)value; return 0; }  // process-wide, tests only
     if (!strcmp(name, "insert_entry_fmt")) { tpc_test_insert_p3 = value == 3; return 0; }  // process-wide; 3 = blocked 24-bit level-2 insert entries (off by default: tpc_partition.hip)
+    if (!strcmp(name, "shard_periodic_skip")) { c->opt_shard_periodic = value != 0; return 0; }  // the host promises tpc_shard_periodic_copy after every round's last query batch
     if (!strcmp(name, "periodic_skip")) { c->opt_periodic = value != 0; if (!value) c->periodic_valid = false; return 0; }  // 0: every position inserts and probes for itself
     if (!strcmp(name, "test_tight_pinch")) { tpc_test_tight_pinch = (int)value; c->sh_have[0] = c->sh_have[1] = false; return 0; }  // process-wide, tests only
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
@@ -1633,6 +1640,7 @@ int tpc_shard_plan(tpc_ctx *c, int pass, uint64_t lo, uint64_t hi, uint64_t *geo
                     c->P.q, c->P.L, c->opt_slice_bits);
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     if (pass == TPC_SHARD_INSERT) { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }  // (its regions are about to be re-planned)
+    if (c->opt_shard_periodic) ensure_periodic(c);
     const uint64_t W = c->sh_world, tiles = text_tiles512(c);
     const uint64_t per_total = (tiles + W - 1) / W;
     const double m = gated ? range_mass(c, lo, hi) : 1.0;
@@ -1748,7 +1756,7 @@ int shard_hash_impl(tpc_ctx *c, int pass, uint64_t batch, uint64_t lo, uint64_t 
     const uint64_t n = t0 < c1 ? std::min<uint64_t>(per, c1 - t0) : 0;
     unsigned long long *ov = c->sh_ov_host[pass];
     ov[0] = ov[1] = 0;
-    TpcLaunch a = make_launch(c);
+    TpcLaunch a = c->opt_shard_periodic ? make_launch_periodic(c) : make_launch(c);
     a.stream = st;
     if (pass == TPC_SHARD_INSERT) {
         TpcPartPlan pl = c->sh_ipl;
@@ -1816,6 +1824,19 @@ int tpc_shard_hash_end(tpc_ctx *c, int pass, uint64_t *n_overflow)
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     const unsigned long long *ov = c->sh_ov_host[pass];
     if (n_overflow) *n_overflow = ov[1] ? (1ull << 62) : (uint64_t)ov[0];
+    return 0;
+}
+
+int tpc_shard_periodic_copy(tpc_ctx *c)
+{
+    if (!c || !c->rmask) return fail(c, -1, "no text");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->opt_shard_periodic && c->periodic_valid) {
+        tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->marks_valid = false; c->rmask_sums_valid = false;
+    }
     return 0;
 }
 

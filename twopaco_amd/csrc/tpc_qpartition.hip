@@ -1539,14 +1539,14 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 // verification is done (k_periodic_copy).  The masks depend on the text and k alone: built once per upload.
 // Thread = one word of 32 positions.  c_p(j) = length of the run of j' <= j with T[j'] == T[j' - p], both definite; window ending at j = i + k.
 __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
-                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t n_words)
-{
-    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo, uint64_t pos_hi)
+{   // words [w_begin, n_words); characters outside [pos_lo, pos_hi) -- a context that holds only its window of the text -- count as N
+    const uint64_t w = w_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
     uint32_t oqs = 0, oq1 = 0, oin = 0;
     const int64_t first = (int64_t)(w << 5);
     if ((uint64_t)first < n_text) {
-        auto ch_at = [&](int64_t j) { return j >= 0 && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
+        auto ch_at = [&](int64_t j) { return j >= (int64_t)pos_lo && (uint64_t)j < pos_hi && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
         const int64_t j0 = first - 2;  // (run lengths only matter up to k + 2: starting k + 2 characters before the first window's end is exact)
         int prev1 = ch_at(j0 - 1), prev2 = ch_at(j0 - 2), c1 = 0, c2 = 0;
         for (int64_t j = j0; j <= first + 31 + k; j++) {
@@ -2120,9 +2120,11 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
 __global__ void k_warm_qpartition() {}
 int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }
 
-int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t n_words)
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi)
 {
-    if (n_words) hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, q1, ins, n_words);
+    if (w_end > w_begin)
+        hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, q1, ins, w_begin, w_end,
+                           pos_lo, pos_hi);
     return 0;
 }
 

@@ -468,6 +468,11 @@ class AddressSharded:
         self.rank, self.world = self.comm.rank, self.comm.world
         if configure:  # False: the caller did it before tpc_seq_upload (needed for option text_window to take effect)
             ctx.shard_config(self.rank, self.world)
+        # positions inside homopolymer / dinucleotide tracts repeat their neighbour's window: they send nothing, query() copies their verdicts
+        # after the last batch (tpc_shard_periodic_copy).  A sharded filter has no fallback behind its overflow lists, and tracts are what fills them.
+        self.periodic = os.environ.get("TPC_SHARD_PERIODIC", "1") != "0"
+        if self.periodic:
+            ctx.set_option("shard_periodic_skip", 1)
         self._bufs = {}
         self.stats = {}
         self.t = {}   # seconds per phase, accumulated (host clock; every phase ends synchronised)
@@ -737,6 +742,10 @@ class AddressSharded:
                 tot = self.comm.sum_ints([trace[1], trace[0]])  # (sums over the ranks, as host/multigpu.cpp: both hosts take the same decision on the same input)
                 self._fn1_pass_rate = tot[0] / max(tot[1], 1)
         self.stats["survivors"] = survivors
+        if self.periodic:
+            t0 = time.perf_counter()
+            self._try(ctx.shard_periodic_copy)
+            self._tick("query_periodic_copy", t0)
         if not union:
             return geom
         t0 = time.perf_counter()

@@ -685,6 +685,9 @@ namespace TwoPaCo
 		r.PhasePrint("sharded first pass");
 		}
 
+		// positions inside homopolymer / dinucleotide tracts sent no probes (option shard_periodic_skip, set with the rank's context): they take
+		// the verdict of the position whose window they repeat -- same tile, so same rank -- before anything reads the round mask
+		LibCheck(r.ctx, tpc_shard_periodic_copy(r.ctx), "shard_periodic_copy");
 		if (r.shardedSecondPass) return;  // the marks stay on the rank that found them (ShardedSecondPass)
 		MaskUnion(r, net);
 	}

@@ -224,6 +224,8 @@ namespace TwoPaCo
 				int logGpus = 0;
 				while ((1 << logGpus) < gpus) ++logGpus;
 				const int shardSliceBits = int(std::min<int64_t>(20, std::max<int64_t>(6, int64_t(filterSize) - std::max(2, 2 * logGpus))));
+				const char * shardPeriodicEnv = std::getenv("TWOPACO_SHARD_PERIODIC");
+				const bool shardPeriodic = !(shardPeriodicEnv && shardPeriodicEnv[0] == '0');
 				if (gpus > 64 || (gpus & (gpus - 1)))
 				{
 					throw std::runtime_error("The number of GPUs must be a power of two (the Bloom filter is cut by bit address)");
@@ -312,6 +314,8 @@ namespace TwoPaCo
 							Check(tpc_set_option(ctx_, "slice_bits", shardSliceBits), "set_option");
 							// with the second pass sharded by key hash no rank needs more than its chunk of the text, rank 0 included
 							if (shardedPass2) Check(tpc_set_option(ctx_, "text_window", 1), "set_option");
+							// tracts send nothing (multigpu.cpp:ShardedFirstPass copies their verdicts); TWOPACO_SHARD_PERIODIC=0: every position probes
+							Check(tpc_set_option(ctx_, "shard_periodic_skip", shardPeriodic ? 1 : 0), "set_option");
 							Check(tpc_shard_config(ctx_, 0, uint32_t(gpus)), "shard_config");
 						}
 
@@ -421,6 +425,7 @@ namespace TwoPaCo
 								check(tpc_set_option(me.ctx, "slice_bits", shardSliceBits), "set_option");
 								check(tpc_set_option(me.ctx, "part_budget_bytes", partBudget), "set_option");
 								check(tpc_set_option(me.ctx, "text_window", 1), "set_option");  // ranks other than 0 keep only their chunk of the text (rank 0 runs the second pass)
+								check(tpc_set_option(me.ctx, "shard_periodic_skip", shardPeriodic ? 1 : 0), "set_option");
 								check(tpc_shard_config(me.ctx, uint32_t(r), uint32_t(gpus)), "shard_config");
 								check(tpc_set_params(me.ctx, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 								check(tpc_seq_upload(me.ctx, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
