@@ -32,6 +32,7 @@ struct tpc_ctx {
     // partitioned pass after an upload / a change of k (ensure_periodic), option "periodic_skip" (default on)
     uint32_t *periodic = nullptr;
     bool periodic_valid = false;
+    bool periodic_any_q = false, periodic_any_i = false;  // some position copies its verdict / drops its insert (else the masks are never read)
     int opt_periodic = 1;
     bool opt_shard_periodic = false;  // option shard_periodic_skip: the tpc_shard_hash kernels skip too, the host calls tpc_shard_periodic_copy
     // sharded contexts may hold only the words of the tiles they hash (+ halo): bases / nmask then point text_w0 words BEFORE
@@ -185,7 +186,10 @@ TpcLaunch make_launch(const tpc_ctx *c)
 TpcLaunch make_launch_periodic(const tpc_ctx *c)
 {
     TpcLaunch a = make_launch(c);
-    if (c->periodic && c->periodic_valid) { a.per_qs = c->periodic; a.per_q1 = c->periodic + c->n_words_alloc; a.per_i = c->periodic + 2 * c->n_words_alloc; }
+    if (c->periodic && c->periodic_valid) {
+        if (c->periodic_any_q) { a.per_qs = c->periodic; a.per_q1 = c->periodic + c->n_words_alloc; }
+        if (c->periodic_any_i) a.per_i = c->periodic + 2 * c->n_words_alloc;
+    }
     return a;
 }
 
@@ -197,12 +201,17 @@ void ensure_periodic(tpc_ctx *c)
 {
     if (c->periodic_valid || !c->opt_periodic || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
     if ((c->sh_world > 1 || c->text_windowed) && !c->opt_shard_periodic) return;
-    if (!c->periodic && hipMalloc((void **)&c->periodic, 3 * c->n_words_alloc * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
+    const size_t words = 3 * c->n_words_alloc + 2;  // the three masks, then the two "any" flags
+    if (!c->periodic && hipMalloc((void **)&c->periodic, words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
     TpcLaunch a = make_launch(c);
-    if (hipMemsetAsync(c->periodic, 0, 3 * c->n_words_alloc * sizeof(uint32_t), c->stream) != hipSuccess) return;
+    if (hipMemsetAsync(c->periodic, 0, words * sizeof(uint32_t), c->stream) != hipSuccess) return;
     const uint64_t w0 = c->text_windowed ? c->text_w0 : 0, w1 = c->text_windowed ? std::min(c->text_w1, c->n_words) : c->n_words;
-    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, w0, w1, w0 << 5, c->text_windowed ? c->text_w1 << 5 : ~0ull);
+    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, w0, w1, w0 << 5, c->text_windowed ? c->text_w1 << 5 : ~0ull,
+                              c->periodic + 3 * c->n_words_alloc);
+    uint32_t any[2] = {0, 0};
+    if (hipMemcpyAsync(any, c->periodic + 3 * c->n_words_alloc, sizeof any, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return;  // (a sharded hash may run on the second stream)
+    c->periodic_any_q = any[0] != 0; c->periodic_any_i = any[1] != 0;
     c->periodic_valid = true;
 }
 
@@ -985,7 +994,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     if (surv > 0) pl.group_survivors = batch_marks * 4 >= surv;
                 }
             }
-            if (c->periodic_valid) tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);  // positions that sent no probes take their twin's verdict
+            if (c->periodic_valid && c->periodic_any_q) tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);  // positions that sent no probes take their twin's verdict
             tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
         }
         HIPCHK(c, hipGetLastError());
@@ -1831,7 +1840,7 @@ int tpc_shard_periodic_copy(tpc_ctx *c)
 {
     if (!c || !c->rmask) return fail(c, -1, "no text");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->opt_shard_periodic && c->periodic_valid) {
+    if (c->opt_shard_periodic && c->periodic_valid && c->periodic_any_q) {
         tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));

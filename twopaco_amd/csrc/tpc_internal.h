@@ -49,7 +49,7 @@ struct TpcLaunch {
     // equal those around i - 1 (per_q1) or i - 2 -- its candidate verdict is that position's, copied after the verification
     const uint32_t *per_i = nullptr, *per_qs = nullptr, *per_q1 = nullptr;
 };
-int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi);
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi, uint32_t *any);
 int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *q1, uint64_t n_words);
 
 // pass 1 (tpc_pass1.hip)

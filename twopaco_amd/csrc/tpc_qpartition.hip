@@ -1539,8 +1539,10 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 // verification is done (k_periodic_copy).  The masks depend on the text and k alone: built once per upload.
 // Thread = one word of 32 positions.  c_p(j) = length of the run of j' <= j with T[j'] == T[j' - p], both definite; window ending at j = i + k.
 __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
-                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo, uint64_t pos_hi)
+                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo, uint64_t pos_hi,
+                                                        uint32_t *__restrict__ any)
 {   // words [w_begin, n_words); characters outside [pos_lo, pos_hi) -- a context that holds only its window of the text -- count as N
+    // any[0] / any[1]: set when some position copies its verdict / drops its insert (a text without tracts never reads the masks again)
     const uint64_t w = w_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
     uint32_t oqs = 0, oq1 = 0, oin = 0;
@@ -1567,6 +1569,8 @@ __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restri
         }
     }
     qs[w] = oqs; q1[w] = oq1; ins[w] = oin;
+    if (oqs) any[0] = 1u;
+    if (oin) any[1] = 1u;
 }
 
 // mark(i) = mark(i - 1) where q1 is set, mark(i - 2) where only qs is.  A segment = a maximal stretch of positions in which no two
@@ -2120,11 +2124,11 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
 __global__ void k_warm_qpartition() {}
 int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }
 
-int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi)
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi, uint32_t *any)
 {
     if (w_end > w_begin)
         hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, q1, ins, w_begin, w_end,
-                           pos_lo, pos_hi);
+                           pos_lo, pos_hi, any);
     return 0;
 }
 
