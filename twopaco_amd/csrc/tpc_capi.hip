@@ -629,7 +629,7 @@ int tpc_seq_upload(tpc_ctx *c, const uint64_t *bases, const uint32_t *nmask, uin
     HIPCHK(c, dev_malloc(c, (void **)&c->nmask_alloc, wn * sizeof(uint32_t)));
     HIPCHK(c, dev_malloc(c, (void **)&c->rmask, alloc * sizeof(uint32_t)));
     HIPCHK(c, dev_malloc(c, (void **)&c->mask, alloc * sizeof(uint32_t)));
-    HIPCHK(c, dev_malloc(c, (void **)&c->block_sums, (alloc / 256 + 2) * sizeof(uint64_t)));
+    HIPCHK(c, dev_malloc(c, (void **)&c->block_sums, (alloc / 256 + 2 + 64) * sizeof(uint64_t)));  // (+ 64: tpc_launch_mask_count's scratch behind the sums)
     HIPCHK(c, hipMemsetAsync(c->bases_alloc, 0, wn * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->nmask_alloc, 0xFF, wn * sizeof(uint32_t), c->stream));  // padding = N
     HIPCHK(c, hipMemsetAsync(c->rmask, 0, alloc * sizeof(uint32_t), c->stream));
