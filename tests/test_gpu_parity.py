@@ -404,8 +404,8 @@ def _tract_records(rng, n_bases, k):
     """Random sequence with homopolymer / dinucleotide / trinucleotide tracts -- also across the 16384-position tile boundaries, with an N
     inside some, at the very start and end of records -- plus short records."""
     a = rng.integers(0, 4, n_bases).astype(np.uint8)
-    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [2]]
-    for t in range(60):
+    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [2], [3, 3, 0, 2, 2, 2], [0, 1, 2, 3], [1, 1, 0, 3, 2], [0, 1, 2, 3, 0, 2, 1]]  # periods 1..6 copy, 7 does not
+    for t in range(90):
         unit = units[t % len(units)]
         ln = int(rng.integers(k + 3, 900))
         at = int(rng.integers(0, n_bases - ln))
@@ -416,13 +416,14 @@ def _tract_records(rng, n_bases, k):
             a[at + ln // 2] = 4  # an N inside the tract
     a[:300] = 0          # the record begins inside a tract
     a[-200:] = np.resize(np.array([1, 0], dtype=np.uint8), 200)  # and ends inside one
-    recs = [a, np.zeros(k + 1, dtype=np.uint8), np.zeros(k - 1, dtype=np.uint8), np.resize(np.array([1, 0], dtype=np.uint8), 5000), np.zeros(40000, dtype=np.uint8)]
+    recs = [a, np.zeros(k + 1, dtype=np.uint8), np.zeros(k - 1, dtype=np.uint8), np.resize(np.array([1, 0], dtype=np.uint8), 5000), np.zeros(40000, dtype=np.uint8),
+            np.resize(np.array([3, 3, 0, 2, 2, 2], dtype=np.uint8), 20000)]  # (a telomere: the hexamer over 20 kbp, across a tile boundary)
     return recs
 
 
 @pytest.mark.parametrize("k,L,q,budget", [(25, 28, 5, 0), (5, 22, 3, 0), (51, 28, 2, 0), (25, 28, 5, 2 << 20), (31, 34, 5, 0)])
 def test_periodic_windows_are_skipped_and_copied(capi, k, L, q, budget):
-    """Positions whose window repeats the one 1 or 2 positions earlier (poly-A, (CA)n) send nothing in the partitioned passes: the insert
+    """Positions whose window repeats the one 1 .. 6 positions earlier (poly-A, (CA)n, microsatellites, the telomere hexamer) send nothing in the partitioned passes: the insert
     drops their out-edge (per_i), the query drops their probes and k_periodic_copy gives them the twin's verdict (tpc_qpartition.hip:
     k_periodic_build).  Filter bitmap, candidate mask and count equal the oracle's -- whole range and two gated half ranges -- and equal the
     run with option periodic_skip = 0; tracts across tile boundaries, with N inside, at record ends, records shorter than k, in batches."""

@@ -187,31 +187,37 @@ TpcLaunch make_launch_periodic(const tpc_ctx *c)
 {
     TpcLaunch a = make_launch(c);
     if (c->periodic && c->periodic_valid) {
-        if (c->periodic_any_q) { a.per_qs = c->periodic; a.per_q1 = c->periodic + c->n_words_alloc; }
-        if (c->periodic_any_i) a.per_i = c->periodic + 2 * c->n_words_alloc;
+        if (c->periodic_any_q) a.per_qs = c->periodic;
+        if (c->periodic_any_i) a.per_i = c->periodic + 4 * c->n_words_alloc;
     }
     return a;
 }
 
-// The periodic-window masks of this text and k, built once (0.6 ms on the 62-genome text).  The one-GPU passes use them by default; a sharded
-// context only when its host opted in (option shard_periodic_skip: that host calls tpc_shard_periodic_copy after a round's last batch).  A
-// context that holds a window of the text builds the masks of its window (characters outside count as N: no skipping across its edges).
-// A failed allocation just leaves the feature off.
+// The periodic-window masks of this text and k, built once: a detection launch first (0.6 ms on the 62-genome text, which has none: nothing
+// is allocated then), the masks themselves only for a text that has such windows: [5][n_words_alloc] = per_qs, the three planes of the
+// copy distance, per_i.  The one-GPU passes use them by default; a sharded context only when its host opted in (option shard_periodic_skip:
+// that host calls tpc_shard_periodic_copy after a round's last batch).  A context that holds a window of the text builds the masks of its
+// window (characters outside count as N: no skipping across its edges).  A failed allocation just leaves the feature off.
 void ensure_periodic(tpc_ctx *c)
 {
     if (c->periodic_valid || !c->opt_periodic || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
     if ((c->sh_world > 1 || c->text_windowed) && !c->opt_shard_periodic) return;
-    const size_t words = 3 * c->n_words_alloc + 2;  // the three masks, then the two "any" flags
-    if (!c->periodic && hipMalloc((void **)&c->periodic, words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
     TpcLaunch a = make_launch(c);
-    if (hipMemsetAsync(c->periodic, 0, words * sizeof(uint32_t), c->stream) != hipSuccess) return;
     const uint64_t w0 = c->text_windowed ? c->text_w0 : 0, w1 = c->text_windowed ? std::min(c->text_w1, c->n_words) : c->n_words;
-    tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->periodic + 2 * c->n_words_alloc, w0, w1, w0 << 5, c->text_windowed ? c->text_w1 << 5 : ~0ull,
-                              c->periodic + 3 * c->n_words_alloc);
+    const uint64_t pos_hi = c->text_windowed ? c->text_w1 << 5 : ~0ull;
     uint32_t any[2] = {0, 0};
-    if (hipMemcpyAsync(any, c->periodic + 3 * c->n_words_alloc, sizeof any, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return;  // (a sharded hash may run on the second stream)
+    uint32_t *flags = reinterpret_cast<uint32_t *>(c->counters + 6);  // (two words of the context's counter block)
+    if (hipMemsetAsync(flags, 0, sizeof any, c->stream) != hipSuccess) return;
+    tpc_launch_periodic_build(a, nullptr, nullptr, 0, nullptr, w0, w1, w0 << 5, pos_hi, flags);
+    if (hipMemcpyAsync(any, flags, sizeof any, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
     c->periodic_any_q = any[0] != 0; c->periodic_any_i = any[1] != 0;
+    if (any[0] || any[1]) {
+        const size_t words = 5 * c->n_words_alloc;
+        if (!c->periodic && hipMalloc((void **)&c->periodic, words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
+        if (hipMemsetAsync(c->periodic, 0, words * sizeof(uint32_t), c->stream) != hipSuccess) return;
+        tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->n_words_alloc, c->periodic + 4 * c->n_words_alloc, w0, w1, w0 << 5, pos_hi, flags);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return;  // (a sharded hash may run on the second stream)
+    }
     c->periodic_valid = true;
 }
 
@@ -994,7 +1000,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     if (surv > 0) pl.group_survivors = batch_marks * 4 >= surv;
                 }
             }
-            if (c->periodic_valid && c->periodic_any_q) tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);  // positions that sent no probes take their twin's verdict
+            if (c->periodic_valid && c->periodic_any_q && c->periodic) tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words_alloc, c->n_words);  // positions that sent no probes take their twin's verdict
             tpc_launch_mask_count(c->stream, c->rmask, c->n_words, c->block_sums, c->counters + 1);
         }
         HIPCHK(c, hipGetLastError());
@@ -1840,8 +1846,8 @@ int tpc_shard_periodic_copy(tpc_ctx *c)
 {
     if (!c || !c->rmask) return fail(c, -1, "no text");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->opt_shard_periodic && c->periodic_valid && c->periodic_any_q) {
-        tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words);
+    if (c->opt_shard_periodic && c->periodic_valid && c->periodic_any_q && c->periodic) {
+        tpc_launch_periodic_copy(c->stream, c->rmask, c->periodic, c->periodic + c->n_words_alloc, c->n_words_alloc, c->n_words);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->marks_valid = false; c->rmask_sums_valid = false;

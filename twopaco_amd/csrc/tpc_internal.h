@@ -45,12 +45,13 @@ struct TpcLaunch {
     uint32_t *filter;       // device: Bloom filter words
     hipStream_t stream;
     // periodic windows (tpc_qpartition.hip:k_periodic_build; nullptr: off): one bit per position, laid out like nmask.  per_i: the
-    // (k+1)-mer at i equals the one at i - 1 or i - 2 -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
-    // equal those around i - 1 (per_q1) or i - 2 -- its candidate verdict is that position's, copied after the verification
-    const uint32_t *per_i = nullptr, *per_qs = nullptr, *per_q1 = nullptr;
+    // (k+1)-mer at i equals the one 1..6 positions earlier -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
+    // equal those around i - p -- its candidate verdict is that position's, copied after the verification (p: three bit planes, the copy's business)
+    const uint32_t *per_i = nullptr, *per_qs = nullptr;
 };
-int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi, uint32_t *any);
-int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *q1, uint64_t n_words);
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *qd, uint64_t stride, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi,
+                              uint32_t *any);
+int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *qd, uint64_t stride, uint64_t n_words);
 
 // pass 1 (tpc_pass1.hip)
 int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);

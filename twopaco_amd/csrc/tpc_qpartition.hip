@@ -1529,89 +1529,111 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 }
 
 // ------------------------------------------------------------------------------------------ periodic windows
-// A homopolymer or dinucleotide tract sends the SAME six probes (and the same q insert addresses) from hundreds of consecutive positions:
-// bursts of identical entries for one ring of one level-2 workgroup, in every such tract of the input -- m2r's tracts, 0.13 % of its text,
-// cost the two split kernels 2.4 ms (DESIGN_HISTORY.md, round 5; four attempts to make the overflow path cheap enough failed).  They are
-// removed at the source instead.  Both passes are functions of a window of the text: the first-pass verdict of the vertex at i of the
+// A homopolymer, a dinucleotide tract, a telomere sends the SAME six probes (and the same q insert addresses) from hundreds of positions in a
+// row: bursts of identical entries for one ring of one level-2 workgroup, in every such tract of the input -- m2r's tracts, 0.13 % of its
+// text, cost the two split kernels 2.4 ms (DESIGN_HISTORY.md, round 5; four attempts to make the overflow path cheap enough failed).  They
+// are removed at the source instead.  Both passes are functions of a window of the text: the first-pass verdict of the vertex at i of the
 // k + 2 characters T[i - 1 .. i + k] (VE.h:633-674), the insert of its out-edge of T[i .. i + k] (VE.h:1035-1092).  When such a window
-// equals the one p = 1 or 2 positions earlier, character for character and all of them definite, the position repeats that one's work:
-// its insert is dropped (per_i; OR is idempotent), and its probes are dropped (per_qs) and its mark copied from position i - p once the
-// verification is done (k_periodic_copy).  The masks depend on the text and k alone: built once per upload.
+// equals the one p positions earlier (p = 1 .. 6: every microsatellite unit, the telomere hexamer), character for character and all of them
+// definite, the position repeats that one's work: its insert is dropped (per_i; OR is idempotent), and its probes are dropped (per_qs) and
+// its mark copied from position i - p once the verification is done (k_periodic_copy; p in three bit planes).  The masks depend on the text
+// and k alone: built once per upload -- a first launch without outputs only says whether there is anything to skip at all.
 // Thread = one word of 32 positions.  c_p(j) = length of the run of j' <= j with T[j'] == T[j' - p], both definite; window ending at j = i + k.
+constexpr int PER_MAXP = 6;
 __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
-                                                        uint32_t *__restrict__ q1, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo, uint64_t pos_hi,
-                                                        uint32_t *__restrict__ any)
+                                                        uint32_t *__restrict__ qd, uint64_t stride, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo,
+                                                        uint64_t pos_hi, uint32_t *__restrict__ any)
 {   // words [w_begin, n_words); characters outside [pos_lo, pos_hi) -- a context that holds only its window of the text -- count as N
-    // any[0] / any[1]: set when some position copies its verdict / drops its insert (a text without tracts never reads the masks again)
+    // qs == nullptr: detection only.  any[0] / any[1]: set when some position copies its verdict / drops its insert
+    // qd: the distance p of a copying position in three bit planes (qd, qd + stride, qd + 2 stride)
     const uint64_t w = w_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
-    uint32_t oqs = 0, oq1 = 0, oin = 0;
+    uint32_t oqs = 0, od0 = 0, od1 = 0, od2 = 0, oin = 0;
     const int64_t first = (int64_t)(w << 5);
     if ((uint64_t)first < n_text) {
         auto ch_at = [&](int64_t j) { return j >= (int64_t)pos_lo && (uint64_t)j < pos_hi && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
         const int64_t j0 = first - 2;  // (run lengths only matter up to k + 2: starting k + 2 characters before the first window's end is exact)
-        int prev1 = ch_at(j0 - 1), prev2 = ch_at(j0 - 2), c1 = 0, c2 = 0;
+        int hist[PER_MAXP], c[PER_MAXP];
+#pragma unroll
+        for (int p = 0; p < PER_MAXP; p++) { hist[p] = ch_at(j0 - 1 - p); c[p] = 0; }
         for (int64_t j = j0; j <= first + 31 + k; j++) {
             const int ch = ch_at(j);
-            c1 = ch < 4 && ch == prev1 ? c1 + 1 : 0;
-            c2 = ch < 4 && ch == prev2 ? c2 + 1 : 0;
-            prev2 = prev1; prev1 = ch;
+#pragma unroll
+            for (int p = 0; p < PER_MAXP; p++) c[p] = ch < 4 && ch == hist[p] ? c[p] + 1 : 0;
+#pragma unroll
+            for (int p = PER_MAXP - 1; p > 0; p--) hist[p] = hist[p - 1];
+            hist[0] = ch;
             const int64_t i = j - k;
             if (i < first) continue;
             const uint32_t bit = 1u << (uint32_t)(i - first);
-            if (c1 >= k + 1 || c2 >= k + 1) oin |= bit;
-            // the position it copies from lies in the same 512-word tile, and the first two positions of a tile always probe: a run of
+            int d = 0;
+            bool in = false;
+#pragma unroll
+            for (int p = PER_MAXP - 1; p >= 0; p--) {
+                if (c[p] >= k + 2) d = p + 1;  // (the smallest period wins)
+                in = in || c[p] >= k + 1;
+            }
+            if (in) oin |= bit;
+            // the position it copies from lies in the same 512-word tile, and the first PER_MAXP positions of a tile always probe: a run of
             // copying positions never crosses a tile (batches and ranks are made of tiles) and k_periodic_copy's walks end there
-            if (((uint32_t)i & (uint32_t)(PT_THREADS * TPC_RUN - 1)) >= 2u) {
-                if (c1 >= k + 2) { oqs |= bit; oq1 |= bit; }
-                else if (c2 >= k + 2) oqs |= bit;
+            if (d && ((uint32_t)i & (uint32_t)(PT_THREADS * TPC_RUN - 1)) >= (uint32_t)PER_MAXP) {
+                oqs |= bit;
+                if (d & 1) od0 |= bit;
+                if (d & 2) od1 |= bit;
+                if (d & 4) od2 |= bit;
             }
         }
     }
-    qs[w] = oqs; q1[w] = oq1; ins[w] = oin;
+    if (qs) { qs[w] = oqs; qd[w] = od0; qd[w + stride] = od1; qd[w + 2 * stride] = od2; ins[w] = oin; }
     if (oqs) any[0] = 1u;
     if (oin) any[1] = 1u;
 }
 
-// mark(i) = mark(i - 1) where q1 is set, mark(i - 2) where only qs is.  A segment = a maximal stretch of positions in which no two
-// consecutive ones probe themselves; it starts at a copying position whose two predecessors probed (their marks are final) and is
-// walked by one thread, so every position's source -- inside the segment or one of those two -- is known when it is needed.
-__global__ void __launch_bounds__(256) k_periodic_copy(uint32_t *__restrict__ rmask, const uint32_t *__restrict__ qs, const uint32_t *__restrict__ q1, uint64_t n_words)
+// mark(i) = mark(i - p(i)) at every copying position.  A segment = a maximal stretch of positions in which no PER_MAXP consecutive ones
+// probe for themselves; it starts at a copying position whose PER_MAXP predecessors all probed (their marks are final) and is walked by one
+// thread, so every position's source -- inside the segment or one of those predecessors -- is known when it is needed.
+__global__ void __launch_bounds__(256) k_periodic_copy(uint32_t *__restrict__ rmask, const uint32_t *__restrict__ qs, const uint32_t *__restrict__ qd, uint64_t stride, uint64_t n_words)
 {
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
     const uint32_t S = qs[w];
     if (S == 0u) return;
     const uint32_t Sp = w ? qs[w - 1] : 0u;
-    uint32_t starts = S & ~((S << 1) | (Sp >> 31)) & ~((S << 2) | (Sp >> 30));
-    auto bit_of = [](const uint32_t *m, uint64_t i) { return (m[i >> 5] >> (i & 31u)) & 1u; };
+    uint32_t before = 0;
+#pragma unroll
+    for (int t = 1; t <= PER_MAXP; t++) before |= (S << t) | (Sp >> (32 - t));
+    uint32_t starts = S & ~before;
     while (starts) {
         const uint32_t b = (uint32_t)__ffs((int)starts) - 1u;
         starts &= starts - 1u;
-        uint64_t i = (w << 5) + b;  // (>= 2: the first two positions of a tile never copy)
-        uint32_t m1 = bit_of(rmask, i - 1), m2 = bit_of(rmask, i - 2);
-        // the walk keeps the three words of the 32 positions at hand in registers (a 500-position tract is 16 word fetches, not 1500 loads
-        // one after the other: the kernel lasts as long as its longest walk)
+        uint64_t i = (w << 5) + b;  // (>= PER_MAXP: the first positions of a tile never copy)
+        uint32_t mh = 0;            // bit t - 1 = mark(i - t)
+#pragma unroll
+        for (int t = 1; t <= PER_MAXP; t++) mh |= ((rmask[(i - t) >> 5] >> ((i - t) & 31u)) & 1u) << (t - 1);
+        // the walk keeps the words of the 32 positions at hand in registers (a 500-position tract is 16 word fetches, not 2500 loads one
+        // after the other: the kernel lasts as long as its longest walk)
         uint64_t cw = i >> 5;
-        uint32_t sw = S, qw = q1[cw], rw = rmask[cw], add = 0;
+        uint32_t sw = S, d0 = qd[cw], d1 = qd[cw + stride], d2 = qd[cw + 2 * stride], rw = rmask[cw], add = 0;
         for (int zeros = 0;; i++) {
             if ((i >> 5) != cw) {
                 if (add) atomicOr(&rmask[cw], add);
                 cw = i >> 5;
-                if (cw >= n_words) { add = 0; break; }
-                sw = qs[cw]; qw = q1[cw]; rw = rmask[cw]; add = 0;
+                add = 0;
+                if (cw >= n_words) break;
+                sw = qs[cw]; d0 = qd[cw]; d1 = qd[cw + stride]; d2 = qd[cw + 2 * stride]; rw = rmask[cw];
             }
             const uint32_t bi = (uint32_t)i & 31u;
             uint32_t m;
             if ((sw >> bi) & 1u) {
                 zeros = 0;
-                m = (qw >> bi) & 1u ? m1 : m2;
+                const uint32_t d = ((d0 >> bi) & 1u) | (((d1 >> bi) & 1u) << 1) | (((d2 >> bi) & 1u) << 2);
+                m = (mh >> (d - 1u)) & 1u;
                 add |= m << bi;
             } else {
-                if (++zeros == 2) break;
+                if (++zeros == PER_MAXP) break;
                 m = (rw >> bi) & 1u;  // (a probing position: its mark is final, and no walk ever sets it)
             }
-            m2 = m1; m1 = m;
+            mh = ((mh << 1) | m) & ((1u << PER_MAXP) - 1u);
         }
         if (add) atomicOr(&rmask[cw], add);
     }
@@ -2124,16 +2146,17 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
 __global__ void k_warm_qpartition() {}
 int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }
 
-int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *q1, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi, uint32_t *any)
-{
+int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *qd, uint64_t stride, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi,
+                              uint32_t *any)
+{   // qs == nullptr: detection only (any[0], any[1])
     if (w_end > w_begin)
-        hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, q1, ins, w_begin, w_end,
-                           pos_lo, pos_hi, any);
+        hipLaunchKernelGGL(k_periodic_build, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, a.stream, a.bases, a.nmask, a.n_text, a.P.k, qs, qd, stride, ins, w_begin,
+                           w_end, pos_lo, pos_hi, any);
     return 0;
 }
 
-int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *q1, uint64_t n_words)
+int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *qd, uint64_t stride, uint64_t n_words)
 {
-    if (n_words) hipLaunchKernelGGL(k_periodic_copy, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, rmask, qs, q1, n_words);
+    if (n_words) hipLaunchKernelGGL(k_periodic_copy, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, rmask, qs, qd, stride, n_words);
     return 0;
 }
