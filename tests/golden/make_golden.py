@@ -97,6 +97,32 @@ def write_longk_fa(path, seed=13):
     synth.write_fasta(path, [base, c1, c2, c3, c4], width=70)
 
 
+def write_tracts_fa(path, seed=17):
+    """Low-complexity input (round 5: positions whose window repeats the one 1 .. 6 before them send nothing in the partitioned passes,
+    tpc_qpartition.hip:k_periodic_build): chr0 random with homopolymer / dinucleotide / tri- ... hepta-nucleotide tracts of 30 .. 700 bases,
+    some with an N inside, one across the 16384-position tile boundary of the packed text; chr1 = chr0 with 1 % substitutions (the tracts are
+    junction-rich where the copies differ); chr2 a telomere: (TTAGGG)n over 6 kbp between random flanks; chr3 poly-A only; chr4 = (CA)n only."""
+    n = 40000
+    base = synth.random_genome(n, seed).copy()
+    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [0, 1, 2, 3], [1, 1, 0, 3, 2], [3, 3, 0, 2, 2, 2], [0, 1, 2, 3, 0, 2, 1]]
+    at = synth._stream(seed, 40, 21) % np.uint64(n - 800)
+    ln = synth._stream(seed, 40, 22) % np.uint64(671) + np.uint64(30)
+    for t in range(40):
+        a, l = int(at[t]), int(ln[t])
+        if t == 7:
+            a = 16384 - 1 - 300  # (record 0 starts at text position 1: the tract straddles the first tile boundary)
+        base[a:a + l] = np.resize(np.array(units[t % len(units)], dtype=np.uint8), l)
+        if t % 6 == 0:
+            base[a + l // 2] = 4
+    c1 = synth.substitute(base, 0.01, seed + 1)
+    c1 = np.where(base == 4, 4, c1).astype(np.uint8)
+    flank = synth.random_genome(600, seed + 2)
+    c2 = np.concatenate([flank[:300], np.resize(np.array([3, 3, 0, 2, 2, 2], dtype=np.uint8), 6000), flank[300:]])
+    c3 = np.zeros(900, dtype=np.uint8)
+    c4 = np.resize(np.array([1, 0], dtype=np.uint8), 1100)
+    synth.write_fasta(path, [base, c1, c2, c3, c4], width=80)
+
+
 def parse_log(log):
     rounds = []
     for m in re.finditer(r"Round (\d+), (\d+):(\d+)", log):
@@ -124,6 +150,8 @@ def main():
         write_rand_fa(os.path.join(HERE, "c2.fa"), 2500, 3, 12, n_rate=1 / 900.0, change=0.03)
     if only is None or any(n.startswith("lk_") for n in only):
         write_longk_fa(os.path.join(HERE, "lk.fa"))
+    if only is None or any(n.startswith("tr_") for n in only):
+        write_tracts_fa(os.path.join(HERE, "tracts.fa"))
 
     cases = []
 
@@ -198,6 +226,11 @@ def main():
     # so the round ranges (VE.h:206-254) below are what ANY correct implementation must print
     case("rand6_k9_L24_r4", "rand6.fa", 9, 24, rounds=4)
     case("c2_k29_L26_r3", "c2.fa", 29, 26, rounds=3)
+
+    # low-complexity tracts (periodic windows) at filter sizes that take the partitioned passes (L >= 28); _r2: gated rounds, collision free
+    case("tr_k25_L28", "tracts.fa", 25, 28)
+    case("tr_k11_L28_r2", "tracts.fa", 11, 28, rounds=2)
+    case("tr_k31_L30_q3", "tracts.fa", 31, 30, q=3)
 
     # synthetic workloads of BASELINE.json's configs (FASTA regenerated from twopaco_amd/synth.py)
     # m2_full = the bench workload (BASELINE configs[2]); m2_s05_f38 = the f = 38 geometry (512 bins per level) on a text the

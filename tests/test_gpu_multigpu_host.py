@@ -32,7 +32,7 @@ def _check(case, e, out):
 
 
 @pytest.mark.parametrize("name,ranks", [("rand6_k9_fp", 2), ("rand6_k9_L33", 4), ("c2_k51_r2", 2), ("edge_k5", 2), ("rand6_k25_q3", 8),
-                                        ("rand6_k9_a3", 4), ("c2_k125", 2), ("m1_small", 4), ("m2_small", 8), ("rand6_k9_q12", 2), ("m2r_small", 4)])
+                                        ("rand6_k9_a3", 4), ("c2_k125", 2), ("m1_small", 4), ("m2_small", 8), ("rand6_k9_q12", 2), ("m2r_small", 4), ("tr_k25_L28", 2), ("tr_k31_L30_q3", 4)])
 def test_emulated_ranks_write_reference_bytes(capi, tmp_path, name, ranks):
     case = CASES[name]
     out = str(tmp_path / "mg.bin")
