@@ -788,6 +788,12 @@ class AddressSharded:
         self.comm.phase = "second pass: marked positions to the key owners"
         zeros = [0] * W
         none = {"true": 0, "false": 0, "table": 0}
+        if W == 1 and not os.environ.get("TPC_PASS2_ROUTED"):  # one rank owns every key and holds the whole text: nothing to route (as _verify does for the probes)
+            st = self._try(ctx.pass2_filter, abundance, default=dict(none))
+            st["marks"] = self._try(ctx.stat, "round_marks")
+            self.stats["pass2_positions_received"] = st["marks"]
+            self._tick("pass2_sharded", t0)
+            return st
         n = self._try(ctx.pass2_marks)
         if records:
             rw = ctx.key_words() + 1
