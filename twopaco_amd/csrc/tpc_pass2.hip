@@ -126,17 +126,22 @@ __global__ void __launch_bounds__(256) k_scan_sums(uint64_t *block_sums, uint64_
 __global__ void __launch_bounds__(256) k_mask_scatter(const uint32_t *__restrict__ mask, uint64_t n_words,
                                                       const uint64_t *__restrict__ block_sums, uint64_t *__restrict__ list)
 {
+    // the block's marks are gathered in LDS (13-bit local positions) and leave as one contiguous, coalesced run: a lane storing its own
+    // 4-5 positions one after the other wrote 8 bytes at a stride of ~36 (172 us for the 44 M marks of the 62-genome workload)
     __shared__ uint32_t s_w[4];
+    __shared__ uint16_t s_loc[256 * 32];
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t m = w < n_words ? mask[w] : 0;
     uint32_t total;
-    const uint32_t ex = block_excl_scan256(__popc(m), s_w, total);
-    uint64_t o = block_sums[blockIdx.x] + ex;
+    uint32_t o = block_excl_scan256(__popc(m), s_w, total);
     while (m) {
         const int b = __ffs(m) - 1;
-        list[o++] = w * 32 + b;
+        s_loc[o++] = (uint16_t)(threadIdx.x * 32u + (uint32_t)b);
         m &= m - 1;
     }
+    __syncthreads();
+    const uint64_t base = block_sums[blockIdx.x], pos0 = (uint64_t)blockIdx.x * (256u * 32u);
+    for (uint32_t i = threadIdx.x; i < total; i += 256) list[base + i] = pos0 + s_loc[i];
 }
 
 __global__ void k_mask_or(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n_words)
