@@ -319,7 +319,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step(ctx)
-    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "fused"]
+    names = ["filter_reset", "insert", "query", "compact", "filter2", "scan2", "sort", "emit", "fused", "lookup"]
     kms = {n: 0.0 for n in names}
     fused0 = ctx.stat("fused_lookups")
     torch.cuda.synchronize()
@@ -358,12 +358,14 @@ def main():
     ins_addr, qry_addr = q * n_kmers, 6 * n_kmers
     design_ins = 0.375 * n_kmers + ins_addr * (4 + 4 + 2 * i_l2_bytes) + filter_bytes          # W l1, R+W l2, R apply; filter written once
     design_qry = 0.375 * n_kmers + qry_addr * (8 + 8 + 2 * q_l2_bytes) + (0 if fused else filter_bytes)  # 8-byte level-1 entries; filter read once unless fused
-    # With the apply deferred into the query's lookup kernel ("fused" = k_q_split + k_apply_lookup, timed inside "query"),
-    # the insert's share of that group is what its apply has to move: its level-2 entries in, the filter out.
+    # With the apply deferred into the query's lookup kernel, ONE kernel is shared by the two groups: k_apply_lookup ("lookup": its own
+    # event pair inside "fused" = k_q_split + k_apply_lookup, itself inside "query").  The insert's share of THAT KERNEL's time is its
+    # share of that kernel's bytes -- the insert's level-2 entries in and the filter out, against the query's level-2 entries in --
+    # exactly as tools/pmc_traffic.py splits the kernel's counter bytes (fused_share_insert); k_q_split is the query's alone.
     ins_ms, qry_ms = kms["insert"], kms["query"]
+    share = None
     if fused:
-        share = (ins_addr * i_l2_bytes + filter_bytes) / (ins_addr * i_l2_bytes + filter_bytes + qry_addr * (8 + 2 * q_l2_bytes))
-        ins_ms, qry_ms = kms["insert"] + share * kms["fused"], kms["query"] - share * kms["fused"]
+        share = (ins_addr * i_l2_bytes + filter_bytes) / (ins_addr * i_l2_bytes + filter_bytes + qry_addr * q_l2_bytes)
     traffic_ins = traffic_qry = None
     pmc_tag = None
     pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
@@ -373,8 +375,13 @@ def main():
         if t.get("csrc_signature") == csrc_signature():
             traffic_ins, traffic_qry = t["groups"]["insert"], t["groups"]["query"]
             pmc_tag = PMC_PROFILE
+            if fused and t.get("fused_share_insert"):
+                share = t["fused_share_insert"]  # the counters' own split of the shared kernel's bytes
         else:
             pmc_tag = "stale: %s was collected on other kernel sources" % PMC_PROFILE
+
+    if fused:
+        ins_ms, qry_ms = kms["insert"] + share * kms["lookup"], kms["query"] - share * kms["lookup"]
 
     def roof(kernel, ms, design, traffic, survey_bytes, floor_per_kmer):
         # `achieved` / `frac`: the HBM bytes the rocprofv3 counters saw per launch of this kernel group (profiles/<PMC_PROFILE>, same
@@ -416,6 +423,8 @@ def main():
         "paths": paths,  # 2 = partitioned with two levels, +10 = completed by the direct kernel; entries that went the overflow lists' way (last step)
         "ps_per_kmer": dt / args.steps / n_kmers * 1e12,
         "insert_ms_with_its_share_of_fused": ins_ms, "query_ms_without_it": qry_ms,
+        "shared_kernel": {"kernel": "k_apply_lookup", "ms": kms["lookup"], "insert_share_of_its_bytes": share,
+                          "what": "insert group = k_part_hash + k_part_split (kernel_ms.insert) + this share of the shared kernel's own time; k_q_split (kernel_ms.fused - this kernel) is the query's"} if fused else None,
         "result": result,
         "result_equals_reference_golden": result_ok,
         "upload_s_pcie": upload_s,

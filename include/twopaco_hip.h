@@ -53,7 +53,8 @@ enum {
     TPC_K_SHARD_APPLY = 10, /* tpc_shard_apply: levels 2-3 of a sharded pass                   */
     TPC_K_STREAM = 11,      /* tpc_emit_stream: FlushEdgeResults + JunctionPositionWriter bytes  */
     TPC_K_FUSED = 12,       /* deferred apply: k_q_split + k_apply_lookup (inside TPC_K_QUERY), or the apply alone when it was flushed */
-    TPC_K_COUNT = 13
+    TPC_K_LOOKUP = 13,      /* the k_apply_lookup launch of TPC_K_FUSED alone (the one kernel insert and query share: its time is split by bytes) */
+    TPC_K_COUNT = 14
 };
 
 /* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:

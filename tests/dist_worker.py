@@ -113,6 +113,8 @@ def addr_worker(rank, world, port, spec, result_path):
         if windowed:
             if world > 1 and len(text.bases) > 8 * 512 * world:  # (a window is whole 512-word tiles + a halo: only meaningful on texts of many tiles)
                 assert ctx.stat("text_words") < len(text.bases) * (1.0 / world + 0.25) + 600, (ctx.stat("text_words"), len(text.bases))
+        if "periodic" in sp:  # (read by AddressSharded: positions inside periodic windows send nothing)
+            os.environ["TPC_SHARD_PERIODIC"] = str(int(sp["periodic"]))
         sh = tdist.AddressSharded(ctx, dist, torch.device("cuda", 0), compact=sp.get("compact_exchange", True), configure=not windowed, fused=sp.get("fused_verify", True))
         out = {"rounds": []}
         for lo, hi in sp["ranges"]:
@@ -123,7 +125,7 @@ def addr_worker(rank, world, port, spec, result_path):
                                   "survivors": sh.stats["survivors"]})
         st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True, sharded_pass2=sp.get("sharded_pass2", False))
         out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], step_marks=st["marks"], moved=sh.comm.bytes_moved, region_bytes_sent=sh.stats.get("region_bytes_sent", 0),
-                   relaxed_regions=sh.stats.get("relaxed_regions", 0), overflow_entries=sh.stats.get("overflow_entries", 0))
+                   relaxed_regions=sh.stats.get("relaxed_regions", 0), overflow_entries=sh.stats.get("overflow_entries", 0), periodic_skip=ctx.stat("periodic_skip"))
         gathered = [None] * world
         dist.all_gather_object(gathered, out)
         results.append(gathered)

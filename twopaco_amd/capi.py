@@ -10,7 +10,7 @@ from .build import lib_dir
 
 INVALID_VERTEX = (1 << 63) - 1
 KERNELS = {"fused": 12, "filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8,
-           "shard_hash": 9, "shard_apply": 10, "stream": 11}
+           "shard_hash": 9, "shard_apply": 10, "stream": 11, "lookup": 13}
 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",

@@ -28,7 +28,7 @@ struct tpc_ctx {
     uint64_t *bases = nullptr;
     uint32_t *nmask = nullptr;
     uint64_t n_text = 0, n_words = 0, n_words_alloc = 0, n_tiles = 0;
-    // periodic-window masks of the text (tpc_internal.h:TpcLaunch): [3][n_words_alloc] = per_qs, per_q1, per_i; built at the first
+    // periodic-window masks of the text (tpc_internal.h:TpcLaunch): [5][n_words_alloc] = per_qs, the three bit planes of the copy distance, per_i (at 4 * n_words_alloc); built at the first
     // partitioned pass after an upload / a change of k (ensure_periodic), option "periodic_skip" (default on)
     uint32_t *periodic = nullptr;
     bool periodic_valid = false;
@@ -974,7 +974,9 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                     if (tpc_launch_query_part_hash(make_launch_periodic(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                     {
                         Timed tf(c, TPC_K_FUSED);
-                        if (tpc_launch_query_part_fused_lookup(make_launch(c), p1, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
+                        TpcLaunch af = make_launch(c);
+                        af.ev_lookup0 = c->ev0[TPC_K_LOOKUP]; af.ev_lookup1 = c->ev1[TPC_K_LOOKUP]; c->ev_used[TPC_K_LOOKUP] = true;
+                        if (tpc_launch_query_part_fused_lookup(af, p1, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
                                                                c->pending_novf ? c->iovf_off : nullptr)) return fail(c, -1, "fused lookup launch failed");
                     }
                     if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");

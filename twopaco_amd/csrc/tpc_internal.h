@@ -48,6 +48,8 @@ struct TpcLaunch {
     // (k+1)-mer at i equals the one 1..6 positions earlier -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
     // equal those around i - p -- its candidate verdict is that position's, copied after the verification (p: three bit planes, the copy's business)
     const uint32_t *per_i = nullptr, *per_qs = nullptr;
+    // measurement: recorded around the k_apply_lookup launch of tpc_launch_query_part_fused_lookup when set (TPC_K_LOOKUP)
+    hipEvent_t ev_lookup0 = nullptr, ev_lookup1 = nullptr;
 };
 int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *qd, uint64_t stride, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi,
                               uint32_t *any);
@@ -72,9 +74,9 @@ struct TpcPartPlan {
     uint64_t tile0, n_tiles;  // 512-word tiles of the text handled by this batch
     uint32_t nwg1, wpb;   // level-1 workgroups; level-2 workgroups per level-1 bucket
     uint32_t wpb3 = 1;    // level-3 workgroups per (b1, b2) bucket
-    uint64_t cap1, cap2;  // entries per private region (multiples of 32; cap2 a multiple of 42 when fmt2 == 3)
+    uint64_t cap1, cap2;  // entries per private region (multiples of 32; cap2 a multiple of 40 = PFmt3::GROUP when fmt2 == 3)
     uint64_t cap3 = 0;
-    int fmt2 = 0;         // level-2 regions: 0 = 32-bit entries, 3 = planar lines of 42 x 24-bit entries (tpc_binsp.h:PFmt3)
+    int fmt2 = 0;         // level-2 regions: 0 = 32-bit entries, 3 = blocked lines of 40 x 24-bit entries (tpc_binsp.h:PFmt3)
     uint64_t ovf_cap;
     uint32_t *buf1, *cnt1, *buf2, *cnt2;
     uint32_t *buf3 = nullptr, *cnt3 = nullptr;

@@ -188,7 +188,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
              const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
              uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows,
              const uint32_t *__restrict__ skip32)
-{   // skip32 (tpc_qpartition.hip:k_periodic_build's per_i, or nullptr): positions whose out-edge repeats the one of the position one or two
+{   // skip32 (tpc_qpartition.hip:k_periodic_build's per_i, or nullptr): positions whose out-edge repeats the one of the position 1 .. 6
     // before them insert nothing.
     // LHI: L > 32.  Every L-bit value lives in two separate 32-bit registers (LeanV, tpc_lean.h: round 4); for L <= 32 the high
     // halves do not exist.
@@ -408,9 +408,9 @@ __global__ void __launch_bounds__(256) k_count_kmers(const uint32_t *__restrict_
 #if TPC_PARTITION_PART == 0
 // ------------------------------------------------------------------------------------------ level 2
 constexpr int PS_THREADS = 1024;  // 16 waves hide the LDS atomic round trips better than 8
-// P3: the output regions are planar lines of 42 x 24-bit entries (tpc_binsp.h:PFmt3, round 5) instead of 32-bit entries -- the
+// P3: the output regions are blocked lines of 40 x 24-bit entries (tpc_binsp.h:PFmt3, round 5) instead of 32-bit entries -- the
 // last level's entries are slice offsets of at most 20 bits; 3.05 bytes each instead of 4 on this kernel's writes and the apply's reads.
-// cap2 is then a multiple of 42 and the buffer is addressed in 128-byte lines.
+// cap2 is then a multiple of 40 and the buffer is addressed in 128-byte lines.
 template <bool SHARDED, bool P3>
 __global__ void __launch_bounds__(PS_THREADS)
 k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uint32_t wpb, const uint32_t *__restrict__ buf1, const uint32_t *__restrict__ cnt1,
@@ -528,7 +528,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
 
 // ------------------------------------------------------------------------------------------ level 3
 // One workgroup per 2^slice_bits-bit slice of the filter.
-template <bool P3>  // the regions are planar lines of 42 x 24-bit entries (see k_part_split)
+template <bool P3>  // the regions are blocked lines of 40 x 24-bit entries (see k_part_split)
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
              uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm, PtShard sh)
@@ -595,7 +595,7 @@ int launch_hash_q(const TpcLaunch &a, const TpcPartPlan &pl, bool gated, uint64_
         (void)hipFuncSetAttribute((const void *)k_part_hash2<Q, G, S, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         hipLaunchKernelGGL((k_part_hash2<Q, G, S, H>), dim3(pl.nwg1), dim3(PH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh, n_kmers, seed_rows,   \
-                           pl.world == 1 ? a.per_i : (const uint32_t *)nullptr);                                                          \
+                           a.per_i);  /* (global word index: the sharded variants skip too) */                                    \
     } while (0)
 #define TPC_HASH2_GS(H)                                                                                                                     \
     do {                                                                                                                                    \

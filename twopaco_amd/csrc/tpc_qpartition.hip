@@ -254,7 +254,7 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
           uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
           uint64_t gbase, uint32_t *__restrict__ rmask, uint32_t tiles_per_wg, const uint16_t *__restrict__ skip16)
 {   // LHI: L > 32; L-bit values on two separate 32-bit registers (LeanV, tpc_lean.h: round 4)
-    // skip16 (k_periodic_build's per_qs, or nullptr): positions whose k + 2 characters repeat those of the position one or two before
+    // skip16 (k_periodic_build's per_qs, or nullptr): positions whose k + 2 characters repeat those of the position 1 .. 6 before
     // them send no probes -- k_periodic_copy gives them that position's verdict after the verification
     // tiles_per_wg > 0: workgroup w takes the tiles [w T, (w + 1) T) of the batch instead of w, w + nwg, ...: its regions then hold
     // ascending positions, which the 6-byte level-2 entries rely on (k_q_split<.., P6>)
@@ -1496,7 +1496,7 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
         hipLaunchKernelGGL((k_q_hash2<G, S, H, X>), dim3(pl.nwg1), dim3(QH_THREADS), lds, a.stream, pl.b1, a.P, a.tab, a.bases, a.nmask, a.n_text, \
                            pl.tile0, pl.n_tiles, pl.pos_per_round, lo, hi, pl.buf1, pl.cnt1, pl.cap1, ovf, perm, sh,                          \
                            pl.tile0_global * (uint64_t)(PT_THREADS * TPC_RUN), rmask, pl.fmt == 6 ? pl.tiles_per_wg : 0u,                  \
-                           pl.world == 1 ? reinterpret_cast<const uint16_t *>(a.per_qs) : (const uint16_t *)nullptr);                       \
+                           reinterpret_cast<const uint16_t *>(a.per_qs));  /* (global word index: the sharded variants skip too) */          \
     } while (0)
 #define TPC_QHASH2_GS(H, X)                                                                                                                 \
     do {                                                                                                                                    \
@@ -1848,7 +1848,13 @@ static bool qpart_plan_compute(int L, int slice_bits, uint64_t n_tiles, double f
     //  the 62-genome text at f = 38 measured 40.6 ms per step against 39.6; TPC_P6_MAXB2=9 lifts the gate for measurements)
     static const int max_b2 = [] { const char *e = getenv("TPC_P6_MAXB2"); return e ? atoi(e) : 8; }();
     if (packed && !legacy_fmt && !no_lean && world == 1 && !three && pl.b2 >= 4 && pl.b2 <= max_b2 && pl.b1 <= 9 && pl.sub_rounds <= 2 && F <= 24 && PB2 >= 14 &&
-        tpw * (uint64_t)(PT_THREADS * TPC_RUN) <= (1ull << PB2) && groups >= 1 && groups <= 64) {
+        tpw * (uint64_t)(PT_THREADS * TPC_RUN) <= (1ull << PB2) && groups >= 1 && groups <= 64 && [&] {
+            // Q6Res::raw keeps a survivor's index in its level-2 region above 4 + PB2 bits of a 54-bit staged id (SurvStage::ID_BITS): the
+            // largest region, in padded lines x 20 entries, must stay below 2^(50 - PB2) or the index would spill into the bucket bits
+            uint64_t most = 0;
+            for (uint64_t r = 0; r < nreg2; r++) most = std::max(most, pl.off2_host[r + 1] - pl.off2_host[r]);
+            return ((most + PFmt6::GROUP - 1) / PFmt6::GROUP + 1) * PFmt6::GROUP < (1ull << (50 - PB2));
+        }()) {
         pl.fmt = 6;
         pl.tiles_per_wg = (uint32_t)tpw;
         pl.n_groups = (uint32_t)groups;
@@ -1962,7 +1968,9 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
                            ipl.cnt2, (uint64_t)(I3 ? ipl.cap2 / PFmt3::GROUP : ipl.cap2 / 32), fresh ? 1 : 0, iovf, iovf_off, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2, \
                            pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);       \
     } while (0)
+        if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
         if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
+        if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
 #undef TPC_AL6_GO
         hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
         return 0;
@@ -1976,8 +1984,10 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
         hipLaunchKernelGGL(k_apply_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
                            ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh);
+        if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
     return 0;

@@ -559,9 +559,24 @@ class AddressSharded:
 
     def _apply(self, which, b, x):
         recv_r, recv_c, send_r, send_c = x
-        if self.compact:
-            return self._try(self.ctx.shard_apply_packed, which, b, recv_r.data_ptr(), recv_c.data_ptr())
-        return self._try(self.ctx.shard_apply_inplace, which, b, recv_r.data_ptr() if recv_r is not None else 0, recv_c.data_ptr(), send_r.data_ptr(), send_c.data_ptr())
+        # The apply side extends the gathered overflow list with its own level-2 losses (repeat-rich input): when THAT overflows
+        # (the library's -20) the pass is re-planned once like a hash-side overflow -- the ranks agree on it in one tiny all-reduce,
+        # any other failure goes the usual way (comm.fail -> DistAbort at the next collective)
+        n, lost = 0, 0
+        if not self.comm.rc:
+            try:
+                if self.compact:
+                    n = self.ctx.shard_apply_packed(which, b, recv_r.data_ptr(), recv_c.data_ptr())
+                else:
+                    n = self.ctx.shard_apply_inplace(which, b, recv_r.data_ptr() if recv_r is not None else 0, recv_c.data_ptr(), send_r.data_ptr(), send_c.data_ptr())
+            except Exception as e:  # noqa: BLE001
+                if "list overflowed" in str(e):
+                    lost = 1
+                else:
+                    self.comm.fail(e)
+        if self.comm.max_ints([lost])[0]:
+            raise _ListOverflow("address-sharded pass: an overflow list overflowed on the apply side (address skew); use the vertex-hash-range decomposition")
+        return n
 
     def _relax(self, exc):
         """An overflow list overflowed on some rank (every rank sees it in the same all-reduce).  Once per object: the level-1 regions go
@@ -571,11 +586,17 @@ class AddressSharded:
         if getattr(self, "_relaxed", False):
             raise RuntimeError(str(exc))
         self._relaxed = True
+        for key, val in getattr(self, "_stats_at_pass", {}).items():  # the failed attempt's share of the per-pass counters
+            self.stats[key] = val
         self.stats["relaxed_regions"] = 1
         self._try(self.ctx.set_option, "shard_tight_regions", 0)
         self._bufs.clear()  # the block sizes of the exchange buffers change with the plan
 
+    def _pass_begins(self):
+        self._stats_at_pass = {key: self.stats.get(key, 0) for key in ("overflow_entries", "region_bytes_sent")}
+
     def insert(self, lo=0, hi=None):
+        self._pass_begins()
         try:
             return self._insert(lo, hi)
         except _ListOverflow as e:
@@ -718,6 +739,7 @@ class AddressSharded:
 
     def query(self, lo=0, hi=None, union=True):
         """union = False: every rank keeps only the marks of the positions it hashed (for the key-sharded second pass)."""
+        self._pass_begins()
         try:
             return self._query(lo, hi, union)
         except _ListOverflow as e:
