@@ -54,7 +54,8 @@ enum {
     TPC_K_STREAM = 11,      /* tpc_emit_stream: FlushEdgeResults + JunctionPositionWriter bytes  */
     TPC_K_FUSED = 12,       /* deferred apply: k_q_split + k_apply_lookup (inside TPC_K_QUERY), or the apply alone when it was flushed */
     TPC_K_LOOKUP = 13,      /* the k_apply_lookup launch of TPC_K_FUSED alone (the one kernel insert and query share: its time is split by bytes) */
-    TPC_K_COUNT = 14
+    TPC_K_COMBINE = 14,     /* tpc_combine_export / tpc_combine_merge: k_slice_combine                                        */
+    TPC_K_COUNT = 15
 };
 
 /* Context on HIP device `device`.  Fails (non-zero) when no GPU / device is present:
@@ -343,6 +344,51 @@ int tpc_mask_export_padded(tpc_ctx *ctx, uint32_t *dst_dev, uint64_t total_words
 int tpc_mask_or_blocks(tpc_ctx *ctx, const uint32_t *blocks_dev, uint32_t count, uint64_t words, uint32_t *out_dev);
 int tpc_mask_import(tpc_ctx *ctx, const uint32_t *src_dev);
 
+/* ---- combined exchange: the filter REPLICATED through set-bit lists (multi-GPU, round 6) --------------------------------------
+ * The reference's threads share one ConcurrentBitVector for free (fetch_or, concurrentbitvector.cpp:31-45; MergeOr :115-122).  Routing
+ * every hash hit to the rank that owns its slice (tpc_shard_* above) moves 4 bytes per insert address and 8 per query probe; but an
+ * insert matters only the first time a bit is set, and a rank's write-combining passes OR its inserts into LDS slices anyway.  Here
+ * every rank keeps the WHOLE filter (option "replicate_filter" = 1 before tpc_shard_config / tpc_set_params; sensible while 2^L / 8
+ * bytes fit one GPU beside the partition buffers) and hashes only its chunk of the text:
+ *   tpc_filter_reset, tpc_pass1_insert   the one-GPU insert over this rank's chunk of the tiles (tpc_shard_chunk); with one tile
+ *                          batch its apply is deferred: the entries wait in their level-2 regions
+ *   tpc_combine_info       info[0] = 1: they do, lists can be exported ([1] slices, [2] 2^16-bit windows per slice, [3] upper bound of
+ *                          a destination block in 16-byte units for `n_dest` destinations, [4] slice_bits, [5] b1, [6] b2, [7] directory
+ *                          entries per destination block); info[0] = 0: the insert was applied to this rank's dense filter (several
+ *                          batches, three levels, no memory): OR-reduce the filters instead (tpc_filter_copy_out / tpc_mask_or_blocks /
+ *                          tpc_filter_copy_in: an all_to_all of word ranges, a fold, an all_gather)
+ *   tpc_combine_export     every slice built in LDS from the rank's own entries; its SET BITS leave as ascending 16-bit offsets per
+ *                          2^16-bit window (csrc/tpc_lists.h): block d of payload_dev (cap_units 16-byte units each) = the slices of
+ *                          the level-1 buckets b1 % n_dest == d in the order [b1 / n_dest][b2]; dir_dev[d][slice][window] =
+ *                          first unit << 24 | entries; units_host[d] = units used.  2 bytes per DISTINCT set bit of the chunk
+ *   (exchange, the host's: an all-gather of the exports, blocks and directories; or a reduce-scatter -- block d and its directory to rank d)
+ *   tpc_combine_merge      reduce-scatter only: the owner ORs the n_src = world received blocks (source s at unit src_base_host[s], its
+ *                          directory at dir_dev + s * stride, stride = info[7]) slice by slice and emits the merged lists of ITS slices
+ *                          (one block, directory [slice][window]); the sum of the received units always suffices as capacity
+ *   (all-gather of the merged blocks and their directories)
+ *   tpc_combine_import     the lists every slice is to be built from: n_src blocks (block s at unit src_base_host[s], its directory at
+ *                          dir_dev + s * dir_stride).  n_owner = W > 0 (all-gathered blocks): block s lists only the slices of the
+ *                          level-1 buckets b1 % W == s % W, keyed [b1 / W][b2] -- the W merged blocks of tpc_combine_merge (n_src = W),
+ *                          or all W x W blocks of the ranks' exports, rank-major (n_src = W * W, no reduce-scatter); n_owner = 0: every
+ *                          block lists every slice (exports with n_dest = 1).  The insert is then pending again: the buffers must stay
+ *                          untouched until the query ran
+ *   tpc_pass1_query        the one-GPU query over this rank's chunk; its first lookup builds every slice from the lists, writes it to
+ *                          the rank's filter and tests the chunk's probes in LDS: no probe, no survivor, no answer crosses a link.
+ *                          The round mask then holds the marks of this rank's positions (as after tpc_shard_finish: second pass sharded
+ *                          by key hash, tpc_pass2_marks ...)
+ *   tpc_combine_choose     the bytes model both hosts print and follow: bytes a rank receives per round for (1) all-gather of exports,
+ *                          (2) reduce-scatter + all-gather of merged lists, (3) dense OR all-reduce, from the mean export size; returns
+ *                          the cheapest.  No context: pure arithmetic. */
+int tpc_combine_info(tpc_ctx *ctx, uint32_t n_dest, uint64_t *info /* [8] */);
+int tpc_combine_export(tpc_ctx *ctx, uint32_t n_dest, uint16_t *payload_dev, uint64_t cap_units, uint64_t *dir_dev, uint64_t *units_host);
+int tpc_combine_merge(tpc_ctx *ctx, uint32_t n_src, const uint16_t *payload_dev, const uint64_t *src_base_host, const uint64_t *dir_dev, uint16_t *out_payload_dev,
+                      uint64_t out_cap_units, uint64_t *out_dir_dev, uint64_t *units_host);
+int tpc_combine_import(tpc_ctx *ctx, uint32_t n_src, uint32_t n_owner, const uint16_t *payload_dev, const uint64_t *src_base_host, const uint64_t *dir_dev, uint64_t dir_stride);
+int tpc_combine_choose(uint32_t world, int L, uint64_t mean_export_units, double *bytes /* [3] */);
+/* Words [word0, word0 + n_words) of the filter to / from a device buffer (the dense form of the exchange; a pending insert is applied first). */
+int tpc_filter_copy_out(tpc_ctx *ctx, uint64_t word0, uint64_t n_words, uint32_t *dst_dev);
+int tpc_filter_copy_in(tpc_ctx *ctx, uint64_t word0, uint64_t n_words, const uint32_t *src_dev);
+
 /* ---- parity taps (debug; used by tests/) ---------------------------------------------- */
 uint64_t tpc_filter_words(const tpc_ctx *ctx);               /* 2^L/32 + 1, concurrentbitvector.cpp:12 (sharded: 2^L/32/world) */
 int tpc_filter_download(tpc_ctx *ctx, uint32_t *words_host); /* tpc_filter_words words       */
@@ -377,6 +423,8 @@ double tpc_kernel_ms(const tpc_ctx *ctx, int which);
  *                      (csrc/tpc_pass1_anyq.hip) for every q, so that they can be checked on the goldens with q <= 16
  *   part_budget_bytes  partition buffers per tile batch (0 = automatic: 40 GiB, or 60 % of the free device
  *                      memory when that is more; any number of batches, not only powers of two); part_min_tiles  smallest batch */
+/*   replicate_filter   1 (before tpc_shard_config / tpc_set_params): a sharded context keeps the whole filter; tpc_pass1_insert / tpc_pass1_query
+ *                      run over this rank's chunk of the tiles and the tpc_combine_* calls exchange set-bit lists (see there) */
 int tpc_set_option(tpc_ctx *ctx, const char *name, int64_t value);
 /* What the last first-pass calls ran: "insert_path" / "query_path" = 1 direct kernel, 2 or 3 = LDS
  * write-combining with that many levels (+10: it overflowed and the direct kernel completed the pass);

@@ -137,6 +137,69 @@ def addr_worker(rank, world, port, spec, result_path):
     dist.destroy_process_group()
 
 
+def combined_worker(rank, world, port, spec, result_path):
+    """The combined exchange (twopaco_amd/dist.py:Combined; include/twopaco_hip.h tpc_combine_*): `world` ranks over gloo, every context
+    on GPU 0 with option replicate_filter.  Each rank reports its WHOLE filter and its round mask after every round's query, and the
+    final (position, id) list.  spec["peek"]: the filter is also downloaded between insert and query (the imported lists are then
+    applied without a lookup riding along, and the query reads the dense filter)."""
+    import pickle
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from twopaco_amd import capi, synth
+    from twopaco_amd import dist as tdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    code_of = np.zeros(256, dtype=np.uint8)
+    code_of[letters] = np.arange(5, dtype=np.uint8)
+    results = []
+    for sp in (spec if isinstance(spec, list) else [spec]):
+        if sp.get("files"):
+            text = capi.PackedText.from_fasta(sp["files"])
+        elif sp.get("records"):
+            text = capi.PackedText.from_codes([code_of[np.frombuffer(r, dtype=np.uint8)] for r in sp["records"]])
+        else:
+            recs, _ = synth.workload(sp["workload"], scale=sp["scale"])
+            text = capi.PackedText.from_codes(recs)
+        ctx = capi.Context(0)
+        for opt, val in sp.get("options", {}).items():
+            ctx.set_option(opt, val)
+        ctx.set_option("replicate_filter", 1)
+        windowed = bool(sp.get("text_window"))
+        if windowed:
+            ctx.set_option("text_window", 1)
+        ctx.shard_config(rank, world)  # before the upload (the window) and the parameters (the filter stays whole)
+        ctx.set_params(sp["k"], sp["L"], sp["q"], capi.seed_table(sp["q"], sp["L"], seed=sp["seed"]))
+        ctx.seq_upload(text)
+        sh = tdist.Combined(ctx, dist, torch.device("cuda", 0), configure=False, mode=sp.get("mode"))
+        out = {"rounds": []}
+        for lo, hi in sp["ranges"]:
+            sh.insert(lo, hi)
+            peek = ctx.filter_download() if sp.get("peek") else None
+            sh.query(lo, hi, union=not sp.get("sharded_pass2"))
+            out["rounds"].append({"filter": ctx.filter_download(), "peek": peek, "mask": ctx.mask_download(False), "combine": dict(sh.stats["combine"]),
+                                  "fused": ctx.stat("fused_lookups"), "query_batches": ctx.stat("query_batches"), "insert_batches": ctx.stat("insert_batches")})
+        st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True, sharded_pass2=sp.get("sharded_pass2", False))
+        lo_hi = ctx.shard_chunk() if hasattr(ctx, "shard_chunk") else None
+        out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], step_marks=st["marks"], moved=sh.comm.bytes_moved, chunk=lo_hi,
+                   combine=dict(sh.stats["combine"]))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        results.append(gathered)
+        ctx.close()
+    if rank == 0:
+        with open(result_path, "wb") as f:
+            pickle.dump(results if isinstance(spec, list) else results[0], f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def comm_worker(rank, world, port, result_path, p2p=False):
     """The collectives of the address-sharded driver (twopaco_amd/dist.py:_Comm) over gloo on host tensors."""
     import pickle

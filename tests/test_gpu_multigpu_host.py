@@ -14,6 +14,14 @@ CASES = {c["name"]: c for c in golden_cases()}
 MAXU = (1 << 64) - 1
 
 
+@pytest.fixture(autouse=True)
+def _entry_routing(monkeypatch):
+    """This module pins the ENTRY-ROUTING form of the multi-GPU first pass (the filter cut over the ranks, every hash hit of both
+    passes routed to the owner of its slice: what filters beyond one GPU need).  The default of `twopaco --gpus N` while the filter
+    fits a GPU is the combined exchange: tests/test_gpu_multigpu_combined.py."""
+    monkeypatch.setenv("TWOPACO_MULTIGPU", "entries")
+
+
 @pytest.fixture(scope="module")
 def capi():
     from twopaco_amd import capi as m

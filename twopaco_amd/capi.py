@@ -10,7 +10,7 @@ from .build import lib_dir
 
 INVALID_VERTEX = (1 << 63) - 1
 KERNELS = {"fused": 12, "filter_reset": 0, "insert": 1, "query": 2, "compact": 3, "filter2": 4, "scan2": 5, "sort": 6, "emit": 7, "split": 8,
-           "shard_hash": 9, "shard_apply": 10, "stream": 11, "lookup": 13}
+           "shard_hash": 9, "shard_apply": 10, "stream": 11, "lookup": 13, "combine": 14}
 
 # every symbol include/twopaco_hip.h declares
 HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_params", "tpc_seq_upload",
@@ -25,10 +25,18 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part",
-               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish", "tpc_shard_verify_local", "tpc_shard_periodic_copy"]
+               "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish", "tpc_shard_verify_local", "tpc_shard_periodic_copy",
+               "tpc_combine_info", "tpc_combine_export", "tpc_combine_merge", "tpc_combine_import", "tpc_combine_choose", "tpc_filter_copy_out", "tpc_filter_copy_in"]
 
 _hip = None
 _host = None
+
+
+def combine_choose(world, L, mean_export_units):
+    """(mode, bytes received per rank for [all-gather of exports, reduce-scatter + all-gather, dense OR all-reduce]); mode 1..3 = the cheapest."""
+    b = (ctypes.c_double * 3)()
+    mode = hip().tpc_combine_choose(world, L, int(mean_export_units), b)
+    return mode, [float(x) for x in b]
 
 
 def _load(name):
@@ -104,6 +112,13 @@ def hip():
         L.tpc_shard_finish.argtypes = [p, p, u64, ci, p, p, p]
         L.tpc_shard_verify_local.argtypes = [p]
         L.tpc_shard_periodic_copy.argtypes = [p]
+        L.tpc_combine_info.argtypes = [p, u32, p]
+        L.tpc_combine_export.argtypes = [p, u32, p, u64, p, p]
+        L.tpc_combine_merge.argtypes = [p, u32, p, p, p, p, u64, p, p]
+        L.tpc_combine_import.argtypes = [p, u32, u32, p, p, p, u64]
+        L.tpc_combine_choose.argtypes = [u32, ci, u64, p]
+        L.tpc_filter_copy_out.argtypes = [p, u64, u64, p]
+        L.tpc_filter_copy_in.argtypes = [p, u64, u64, p]
         L.tpc_shard_survivors.argtypes = [p, p]
         L.tpc_shard_verify_addrs.argtypes = [p, ci, ci, p, u64, p, p]
         L.tpc_shard_survivor_sources.argtypes = [p, p, u64, p]
@@ -388,6 +403,9 @@ class Context:
             raise RuntimeError("tpc_emit_stream_fetch failed")
         return buf.tobytes(), nr.value
 
+    def filter_words(self):
+        return int(hip().tpc_filter_words(self._h))
+
     def filter_download(self):
         w = np.zeros(hip().tpc_filter_words(self._h), dtype=np.uint32)
         self._ck(hip().tpc_filter_download(self._h, w.ctypes.data))
@@ -526,6 +544,34 @@ class Context:
 
     def mask_import(self, src_ptr):
         self._ck(hip().tpc_mask_import(self._h, src_ptr))
+
+    # ---- combined exchange: the filter replicated through set-bit lists (include/twopaco_hip.h: tpc_combine_*)
+    def combine_info(self, n_dest):
+        g = np.zeros(8, dtype=np.uint64)
+        self._ck(hip().tpc_combine_info(self._h, n_dest, g.ctypes.data))
+        names = ["sparse", "slices", "windows", "cap_units", "slice_bits", "b1", "b2", "dir_entries_per_dest"]
+        return {n: int(g[i]) for i, n in enumerate(names)}
+
+    def combine_export(self, n_dest, payload_ptr, cap_units, dir_ptr):
+        out = (ctypes.c_uint64 * n_dest)()
+        self._ck(hip().tpc_combine_export(self._h, n_dest, payload_ptr, cap_units, dir_ptr, out))
+        return [int(x) for x in out]
+
+    def combine_merge(self, n_src, payload_ptr, src_base, dir_ptr, out_payload_ptr, out_cap_units, out_dir_ptr):
+        base = (ctypes.c_uint64 * n_src)(*[int(x) for x in src_base])
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_combine_merge(self._h, n_src, payload_ptr, base, dir_ptr, out_payload_ptr, out_cap_units, out_dir_ptr, ctypes.byref(n)))
+        return n.value
+
+    def combine_import(self, n_src, n_owner, payload_ptr, src_base, dir_ptr, dir_stride):
+        base = (ctypes.c_uint64 * n_src)(*[int(x) for x in src_base])
+        self._ck(hip().tpc_combine_import(self._h, n_src, n_owner, payload_ptr, base, dir_ptr, dir_stride))
+
+    def filter_copy_out(self, word0, n_words, dst_ptr):
+        self._ck(hip().tpc_filter_copy_out(self._h, word0, n_words, dst_ptr))
+
+    def filter_copy_in(self, word0, n_words, src_ptr):
+        self._ck(hip().tpc_filter_copy_in(self._h, word0, n_words, src_ptr))
 
 
 class Enumerator:

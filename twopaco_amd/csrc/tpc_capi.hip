@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -139,6 +140,15 @@ struct tpc_ctx {
     hipStream_t stream2 = nullptr;         // tpc_shard_hash_begin: the hash of a pass beside the main stream's work
     bool sh_async[2] = {false, false};     // a hash of the pass is in flight on stream2
     unsigned long long sh_ov_host[2][2] = {{0, 0}, {0, 0}};
+    // combined exchange (tpc_combine_*, tpc_combine.hip): option replicate_filter keeps the WHOLE filter on every rank of a sharded
+    // context (sh_world > 1); tpc_pass1_insert / tpc_pass1_query then run the one-GPU passes over this rank's chunk of the tiles
+    int opt_replicate = 0;
+    bool pending_lists = false;          // the pending (deferred) insert lives in imported set-bit lists (cmb_ls), not in level-2 regions
+    TpcListSrc cmb_ls;                   // ... these (payload and directories are the caller's device buffers)
+    TpcPartPlan cmb_geo;                 // slice geometry of the last deferred insert (tpc_combine_export / _merge / _import agree on it)
+    bool cmb_have_geo = false;
+    uint64_t *cmb_base = nullptr;        // device, [64]: first unit of every source block
+    unsigned long long *cmb_cur = nullptr;  // device, [65]: units claimed per destination block, overflow flag
     // timing
     hipEvent_t ev0[TPC_K_COUNT]{}, ev1[TPC_K_COUNT]{};
     bool ev_used[TPC_K_COUNT]{};
@@ -148,6 +158,8 @@ struct tpc_ctx {
 };
 
 namespace {
+
+bool replicated(const tpc_ctx *c);
 
 int fail(tpc_ctx *c, int code, const char *fmt, ...)
 {
@@ -201,7 +213,7 @@ TpcLaunch make_launch_periodic(const tpc_ctx *c)
 void ensure_periodic(tpc_ctx *c)
 {
     if (c->periodic_valid || !c->opt_periodic || !c->bases || !c->have_params || c->n_words_alloc == 0) return;
-    if ((c->sh_world > 1 || c->text_windowed) && !c->opt_shard_periodic) return;
+    if ((c->sh_world > 1 || c->text_windowed) && !c->opt_shard_periodic && !replicated(c)) return;  // (a replicated pass copies the verdicts itself: tpc_pass1_query)
     TpcLaunch a = make_launch(c);
     const uint64_t w0 = c->text_windowed ? c->text_w0 : 0, w1 = c->text_windowed ? std::min(c->text_w1, c->n_words) : c->n_words;
     const uint64_t pos_hi = c->text_windowed ? c->text_w1 << 5 : ~0ull;
@@ -285,6 +297,15 @@ int flush_pending_apply(tpc_ctx *c)
 {   // the deferred apply of the last insert, for anything that reads or extends the filter other than the fused lookup
     if (!c->pending_apply) return 0;
     c->pending_apply = false;
+    if (c->pending_lists) {  // the combined exchange's imported lists: every slice built from them and written out (no lookup rides along)
+        c->pending_lists = false;
+        Timed t(c, TPC_K_FUSED);
+        const TpcPartPlan &g = c->pending_pl;
+        if (tpc_launch_slice_combine(make_launch(c), g.slice_bits, g.b1, g.b2, g.perm_mult, g.perm_inv, nullptr, nullptr, nullptr, c->cmb_ls, true, c->pending_fresh, nullptr, 0, 1))
+            return fail(c, -1, "apply launch failed");
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     if (c->pending_shard) {  // the sharded insert: level-2 regions kept aside, the overflow entries still in the apply-side list the plan points at
         c->pending_shard = false;
         Timed t(c, TPC_K_SHARD_APPLY);
@@ -379,6 +400,21 @@ uint64_t next_batches(uint64_t b) { return b + std::max<uint64_t>(1, b / 8); }
 
 uint64_t text_tiles512(const tpc_ctx *c) { return (c->n_text / TPC_RUN + 512) / 512; }
 
+// The 512-word tiles tpc_pass1_insert / tpc_pass1_query hash: all of them, or -- option replicate_filter on a rank of a sharded
+// context -- this rank's chunk (the split of tpc_shard_hash and tpc_shard_chunk; possibly empty on a tiny text)
+bool replicated(const tpc_ctx *c) { return c->opt_replicate && c->sh_world > 1; }
+void pass_tiles(const tpc_ctx *c, uint64_t &t_begin, uint64_t &t_end)
+{
+    const uint64_t tiles = text_tiles512(c);
+    t_begin = 0; t_end = tiles;
+    if (replicated(c)) {
+        const uint64_t chunk = (tiles + c->sh_world - 1) / c->sh_world;
+        t_begin = std::min<uint64_t>(tiles, (uint64_t)c->sh_rank * chunk);
+        t_end = std::min<uint64_t>(tiles, t_begin + chunk);
+    }
+}
+uint64_t pass_tile_count(const tpc_ctx *c) { uint64_t a, b; pass_tiles(c, a, b); return std::max<uint64_t>(1, b - a); }
+
 // Bytes of the single-GPU query's buffer i: with three levels the level-3 regions take the place of the level-1 buffer (dead once
 // level 2 has split it), as in the insert -- a batch holds two of the three large buffers, not three.
 size_t qpart_need(const TpcQPlan &pl, int i)
@@ -402,9 +438,9 @@ bool part_hash_supported(const tpc_ctx *c)
 // Tile batching of the partitioned query under the buffer budget; false: use the direct kernel.
 bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan &pl)
 {
-    const uint64_t tiles = text_tiles512(c);
+    const uint64_t tiles = pass_tile_count(c);
     if (c->P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return false;  // the verification kernels are the rolling ones
-    if (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28)) return false;  // small filters are cache resident: direct loads win
+    if (!replicated(c) && (c->opt_query_mode == 1 || (c->opt_query_mode == 0 && c->P.L < 28))) return false;  // small filters are cache resident: direct loads win
     const int64_t budget = part_budget(c);
     for (uint64_t batches = 1;; batches = next_batches(batches)) {
         const uint64_t per = (tiles + batches - 1) / batches;
@@ -415,7 +451,7 @@ bool plan_query(const tpc_ctx *c, uint64_t lo, uint64_t hi, bool gated, TpcQPlan
             // batch; below that (sparse huge filters: f >= 39 on the 62-genome input) the direct loads are cheaper.
             // tools/large_filter_bench.py: f=38 3.5 k probes per slice and batch 52 vs 61 ms, f=39 1.8 k 64 vs 61, f=40 0.9 k 99 vs 63.
             const double per_slice = 6.0 * (gated ? range_mass(c, lo, hi) : 1.0) * (double)per * 512 * TPC_RUN / (double)(1ull << (c->P.L - pl.slice_bits));
-            if (c->opt_query_mode == 0 && batches > 1 && per_slice < 2500.0) return false;
+            if (c->opt_query_mode == 0 && batches > 1 && per_slice < 2500.0 && !replicated(c)) return false;
             return true;
         }
         if (per <= 1) return false;
@@ -480,6 +516,8 @@ void tpc_ctx_destroy(tpc_ctx *c)
     for (void *p : c->pbuf) if (p) (void)hipFree(p);
     for (void *p : c->ikeep) if (p) (void)hipFree(p);
     if (c->periodic) (void)hipFree(c->periodic);
+    if (c->cmb_base) (void)hipFree(c->cmb_base);
+    if (c->cmb_cur) (void)hipFree(c->cmb_cur);
     if (c->ikeep_ovf) (void)hipFree(c->ikeep_ovf);
     if (c->iovf_cnt) (void)hipFree(c->iovf_cnt);
     if (c->iovf_off) (void)hipFree(c->iovf_off);
@@ -510,6 +548,7 @@ int tpc_set_option(tpc_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "test_tight_pinch")) { tpc_test_tight_pinch = (int)value; c->sh_have[0] = c->sh_have[1] = false; return 0; }  // process-wide, tests only
     if (!strcmp(name, "test_sched_cap")) { tpc_test_sched_cap = value > 0 ? (uint32_t)value : 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "text_window")) { c->opt_text_window = value != 0; return 0; }
+    if (!strcmp(name, "replicate_filter")) { c->opt_replicate = value != 0; return 0; }  // before tpc_shard_config / tpc_set_params
     if (!strcmp(name, "test_force_anyq")) { tpc_test_force_anyq = value != 0; return 0; }  // process-wide, tests only
     if (!strcmp(name, "test_fail_mallocs")) { tpc_test_fail_mallocs.store(value > 0 ? (int)value : 0); return 0; }  // process-wide, tests only
     return fail(c, -1, "unknown option %s", name);
@@ -586,8 +625,9 @@ int tpc_set_params(tpc_ctx *c, int k, int L, int q, const uint64_t *seed_table)
             c->tab_host[TPC_TAB_HK + i * 5 + ch] = rotln_host(h, L, c->P.rk);
         }
     HIPCHK(c, hipMemcpy(c->tab, c->tab_host, sizeof c->tab_host, hipMemcpyHostToDevice));
-    const uint64_t fw = filter_words_for(L, c->sh_world);
+    const uint64_t fw = filter_words_for(L, c->opt_replicate ? 1 : c->sh_world);
     c->sh_have[0] = c->sh_have[1] = false;
+    c->pending_lists = false; c->cmb_have_geo = false;
     if (fw != c->filter_words) {
         if (c->filter) (void)hipFree(c->filter);
         c->filter = nullptr;
@@ -681,6 +721,7 @@ int tpc_filter_reset(tpc_ctx *c)
     c->filter_zero_pending = true;
     c->pending_apply = false;  // an insert nobody looked at is forgotten with the filter
     c->pending_shard = false;
+    c->pending_lists = false;
     c->ev_used[TPC_K_FILTER_RESET] = false;
     return 0;
 }
@@ -688,19 +729,22 @@ int tpc_filter_reset(tpc_ctx *c)
 int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
-    if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
+    if (c->sh_world > 1 && !c->opt_replicate) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }
     ensure_periodic(c);
     if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
+    uint64_t t_begin, t_end;
+    pass_tiles(c, t_begin, t_end);  // every tile, or this rank's chunk (option replicate_filter on a sharded context)
     TpcPartPlan pl;
     const double m_ins = gated ? range_mass(c, lo, hi) : 1.0;
     const double ins_frac = gated ? std::min(1.0, (1.0 - (1.0 - m_ins) * (1.0 - m_ins)) * 1.15) : 1.0;  // either endpoint in range
-    const uint64_t tiles = text_tiles512(c);
+    const uint64_t tiles = pass_tile_count(c);
     uint64_t batches = 1;
     bool defer = false;
-    bool part = c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28) && part_hash_supported(c);  // small filters: the direct kernel is as fast
+    bool part = ((c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28)) || replicated(c)) && part_hash_supported(c);  // small filters: the direct kernel is as fast
+    if (replicated(c) && !part) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned hash kernels (q=%d, L=%d, slice_bits=%d are outside what they cover)", c->P.q, c->P.L, c->opt_slice_bits);
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);
@@ -711,7 +755,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         }
         // A batch after the first loads and stores every filter slice (2 x 2^L/8 bytes at ~5 TB/s) to save ~40 ps per address
         // against the direct atomics: worth it only above ~2^slice_bits/800 addresses per slice and batch.
-        if (part && c->opt_insert_mode == 0 && batches > 1) {
+        if (part && c->opt_insert_mode == 0 && batches > 1 && !replicated(c)) {
             const double per_slice = (double)c->P.q * ins_frac * (double)pl.n_tiles * 512 * TPC_RUN / (double)(1ull << (c->P.L - pl.slice_bits));
             if (per_slice < (double)(1ull << pl.slice_bits) / 800.0) part = false;
         }
@@ -755,9 +799,9 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
             if (fresh) HIPCHK(c, hipMemsetAsync(c->filter + (c->filter_words - 1), 0, sizeof(uint32_t), c->stream));
             const uint64_t per = pl.n_tiles;
             per_batch = per;
-            for (uint64_t t0 = 0; t0 < tiles; t0 += per) {
+            for (uint64_t t0 = t_begin; t0 < t_end || t0 == t_begin; t0 += per) {  // (an empty chunk still runs one batch of no tiles: the slices must be written)
                 pl.tile0 = t0;
-                pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
+                pl.n_tiles = t0 < t_end ? std::min<uint64_t>(per, t_end - t0) : 0;
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 2 * sizeof(unsigned long long), c->stream));
                 if (defer) {  // levels 1 and 2 only; whether the apply can wait is known once the overflow count is back
                     TpcPartPlan p1 = pl;
@@ -789,7 +833,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                                                         c->ikeep_ovf + c->ikeep_ovf_cap)) return fail(c, -1, "overflow grouping launch failed");
                         }
                     }
-                    if (keep) { c->pending_apply = true; c->pending_shard = false; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = ov[0]; }
+                    if (keep) { c->pending_apply = true; c->pending_shard = false; c->pending_lists = false; c->pending_fresh = fresh; c->pending_pl = p1; c->pending_novf = ov[0]; }
                     else if (tpc_launch_insert_part_apply_only(make_launch(c), p1, fresh)) return fail(c, -1, "apply launch failed");
                     break;
                 }
@@ -797,7 +841,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
                     return fail(c, -1, "partitioned insert launch failed");
                 fresh = false;  // later batches OR into the slices
                 HIPCHK(c, hipMemcpyAsync(ov, pl.ovf_cur, sizeof ov, hipMemcpyDeviceToHost, c->stream));
-                if (t0 + per < tiles) { HIPCHK(c, hipStreamSynchronize(c->stream)); overflowed = overflowed || ov[1] != 0; }
+                if (t0 + per < t_end) { HIPCHK(c, hipStreamSynchronize(c->stream)); overflowed = overflowed || ov[1] != 0; }
             }
         }
         c->filter_zero_pending = false;
@@ -817,6 +861,7 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
         }
         // the overflow list itself overflowed (pathological skew): OR is idempotent, so running the
         // direct kernel on top completes the filter
+        if (replicated(c)) return fail(c, -20, "overflow list overflowed (address skew beyond what the sharded path handles)");  // (the direct kernel scans the whole text)
         if (n_kmers) HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream));
     }
     int rc = materialize_reset(c);
@@ -924,14 +969,19 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
 int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
-    if (c->sh_world > 1) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
+    if (c->sh_world > 1 && !c->opt_replicate) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
     c->marks_valid = false; c->rmask_sums_valid = false;
     ensure_periodic(c);
     TpcQPlan pl;
-    const uint64_t tiles = text_tiles512(c);
+    uint64_t t_begin, t_end;
+    pass_tiles(c, t_begin, t_end);  // every tile, or this rank's chunk (option replicate_filter on a sharded context: the marks of the chunk only)
     bool part = plan_query(c, lo, hi, gated, pl);
+    if (replicated(c)) {
+        if (!part) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned query (q=%d, L=%d, slice_bits=%d)", c->P.q, c->P.L, c->opt_slice_bits);
+        HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));  // the hash kernel rewrites the words of this rank's tiles only
+    }
     if (part)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (qpart_need(pl, i)) part = ensure_pbuf(c, i, qpart_need(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
@@ -960,13 +1010,13 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             Timed t(c, TPC_K_QUERY);
             const uint64_t per = pl.n_tiles;
             per_batch = per;
-            for (uint64_t t0 = 0; t0 < tiles && !overflowed; t0 += per) {
+            for (uint64_t t0 = t_begin; (t0 < t_end || t0 == t_begin) && !overflowed; t0 += per) {  // (an empty chunk: one batch of no tiles -- a pending apply is still carried out)
                 pl.tile0 = t0;
                 pl.tile0_global = t0;
-                pl.n_tiles = std::min<uint64_t>(per, tiles - t0);
+                pl.n_tiles = t0 < t_end ? std::min<uint64_t>(per, t_end - t0) : 0;
                 HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
                 HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
-                if (fused && t0 == 0) {  // the first batch's lookup kernel also builds and writes the filter slices; later batches read them
+                if (fused && t0 == t_begin) {  // the first batch's lookup kernel also builds and writes the filter slices; later batches read them
                     TpcQPlan p1 = pl;
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
                     c->pending_apply = false;
@@ -976,15 +1026,17 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                         Timed tf(c, TPC_K_FUSED);
                         TpcLaunch af = make_launch(c);
                         af.ev_lookup0 = c->ev0[TPC_K_LOOKUP]; af.ev_lookup1 = c->ev1[TPC_K_LOOKUP]; c->ev_used[TPC_K_LOOKUP] = true;
-                        if (tpc_launch_query_part_fused_lookup(af, p1, c->pending_pl, c->pending_fresh, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
-                                                               c->pending_novf ? c->iovf_off : nullptr)) return fail(c, -1, "fused lookup launch failed");
+                        const bool lists = c->pending_lists;  // the combined exchange: the slices are built from the imported set-bit lists
+                        c->pending_lists = false;
+                        if (tpc_launch_query_part_fused_lookup(af, p1, c->pending_pl, c->pending_fresh, c->pending_novf && !lists ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
+                                                               c->pending_novf && !lists ? c->iovf_off : nullptr, lists ? &c->cmb_ls : nullptr)) return fail(c, -1, "fused lookup launch failed");
                     }
                     if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");
                 } else
                 if (tpc_launch_query_partitioned(make_launch_periodic(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                 HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipMemcpyAsync(&f2, pl.surv_cur + 64, sizeof f2, hipMemcpyDeviceToHost, c->stream));
-                if (t0 + per < tiles) {
+                if (t0 + per < t_end) {
                     // Grouping the survivors by address pays when they are true second edges (every genome's occurrence of an edge probes
                     // the same words); a batch whose first-probe survivors were mostly Bloom false positives -- a well-filled filter: full
                     // configs[3] marks 2 % of them -- has nothing to bring together, and the next batch's lookup skips the sort.  The
@@ -1013,7 +1065,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
         c->stat_query_overflow = (int64_t)f1[0];
         c->stat_path[1] = (pl.b3 ? 3 : 2) + (overflowed ? 10 : 0);
         c->stat_fmt[1] = pl.fmt;
-        c->stat_batches[1] = (int64_t)((tiles + per_batch - 1) / per_batch);
+        c->stat_batches[1] = (int64_t)((pass_tile_count(c) + per_batch - 1) / per_batch);
         if (c->dbg_ovf) {
             unsigned long long sc[65];
             (void)hipMemcpy(sc, pl.surv_cur, sizeof sc, hipMemcpyDeviceToHost);
@@ -1082,6 +1134,7 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
             return 0;
         }
         // an overflow list overflowed (pathological skew): the direct kernel below rewrites the whole mask
+        if (replicated(c)) return fail(c, -20, "overflow or survivor list overflowed (address skew beyond what the sharded path handles)");  // (the direct kernel scans the whole text)
     }
     if (!part) { c->stat_path[1] = 1; c->stat_batches[1] = 1; }
     HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
@@ -1635,7 +1688,7 @@ int tpc_shard_config(tpc_ctx *c, uint32_t rank, uint32_t world)
     c->sh_have[0] = c->sh_have[1] = false;
     c->pending_apply = false;  // the filter is about to be re-cut
     if (c->have_params) {
-        const uint64_t fw = filter_words_for(c->P.L, world);
+        const uint64_t fw = filter_words_for(c->P.L, c->opt_replicate ? 1 : world);
         if (fw != c->filter_words) {
             if (c->filter) (void)hipFree(c->filter);
             c->filter = nullptr; c->filter_words = 0;
@@ -2057,6 +2110,165 @@ int shard_apply_impl(tpc_ctx *c, int pass, uint64_t batch, const void *recv_regi
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------ combined exchange (tpc_combine.hip)
+namespace {
+
+// slices / windows / directory entries of the geometry the combined calls agree on
+uint32_t cmb_slices(const TpcPartPlan &g) { return 1u << (g.b1 + g.b2); }
+
+int cmb_sources(tpc_ctx *c, uint32_t n_src, const uint16_t *payload, const uint64_t *base_host, const uint64_t *dir, uint64_t dir_stride, uint32_t n_owner, TpcListSrc &ls)
+{
+    if (n_src == 0 || n_src > 4096 || !payload || !base_host || !dir) return fail(c, -1, "bad arguments");
+    if (n_owner && ((n_owner & (n_owner - 1)) || n_src % n_owner)) return fail(c, -1, "bad arguments: n_owner must be a power of two dividing n_src");
+    if (!c->cmb_base) HIPCHK(c, hipMalloc((void **)&c->cmb_base, 4096 * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpy(c->cmb_base, base_host, n_src * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ls.payload = payload; ls.base = c->cmb_base; ls.dir = dir; ls.dir_stride = dir_stride; ls.n_src = n_src; ls.n_owner = n_owner;
+    return 0;
+}
+
+}  // namespace
+
+int tpc_combine_info(tpc_ctx *c, uint32_t n_dest, uint64_t *info)
+{
+    if (!c || !info || !c->have_params || n_dest == 0 || (n_dest & (n_dest - 1))) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    // sparse lists need the insert still in its level-2 regions (32-bit entries, two levels, one batch: the deferred apply)
+    if (!(c->pending_apply && !c->pending_shard && !c->pending_lists && c->pending_pl.b3 == 0 && c->pending_pl.fmt2 == 0 && n_dest <= (1u << c->pending_pl.b1))) return 0;
+    const TpcPartPlan &g = c->pending_pl;
+    const uint32_t n_slices = cmb_slices(g), n_win = tpc_list_windows(g.slice_bits), nb2 = 1u << g.b2;
+    // upper bound of a destination block: the entries (duplicates included) of its slices, every window's list rounded up to a unit
+    std::vector<uint32_t> cnt((size_t)n_slices * g.wpb);
+    std::vector<uint64_t> ovf_off;
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), g.cnt2, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->pending_novf) {
+        ovf_off.resize((size_t)n_slices + 1);
+        HIPCHK(c, hipMemcpyAsync(ovf_off.data(), c->iovf_off, ovf_off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> units(n_dest, 0);
+    for (uint32_t b1 = 0; b1 < (1u << g.b1); b1++)
+        for (uint32_t b2 = 0; b2 < nb2; b2++) {
+            uint64_t e = 0;
+            for (uint32_t j = 0; j < g.wpb; j++) e += cnt[((size_t)b1 * g.wpb + j) * nb2 + b2];
+            const uint32_t sp = (b1 << g.b2) | b2;
+            if (c->pending_novf) e += ovf_off[sp + 1] - ovf_off[sp];
+            e = std::min<uint64_t>(e, (uint64_t)1 << g.slice_bits);
+            units[b1 & (n_dest - 1)] += (e + 7) / 8 + n_win;
+        }
+    info[0] = 1; info[1] = n_slices; info[2] = n_win; info[3] = *std::max_element(units.begin(), units.end());
+    info[4] = (uint64_t)g.slice_bits; info[5] = (uint64_t)g.b1; info[6] = (uint64_t)g.b2; info[7] = (uint64_t)(n_slices / n_dest) * n_win;
+    return 0;
+}
+
+int tpc_combine_export(tpc_ctx *c, uint32_t n_dest, uint16_t *payload_dev, uint64_t cap_units, uint64_t *dir_dev, uint64_t *units_host)
+{
+    if (!c || !payload_dev || !dir_dev || !units_host || n_dest == 0 || n_dest > 64 || (n_dest & (n_dest - 1))) return fail(c, -1, "bad arguments");
+    if (!(c->pending_apply && !c->pending_shard && !c->pending_lists && c->pending_pl.b3 == 0 && c->pending_pl.fmt2 == 0 && n_dest <= (1u << c->pending_pl.b1)))
+        return fail(c, -1, "tpc_combine_export needs the insert of this round still in its level-2 regions (tpc_combine_info says when)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->cmb_cur) HIPCHK(c, hipMalloc((void **)&c->cmb_cur, 65 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->cmb_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+    const TpcPartPlan g = c->pending_pl;
+    const TpcCombineOut out{payload_dev, cap_units, c->cmb_cur, dir_dev, n_dest};
+    {
+        Timed t(c, TPC_K_COMBINE);
+        if (tpc_launch_slice_combine(make_launch(c), g.slice_bits, g.b1, g.b2, g.perm_mult, g.perm_inv, &g, c->pending_novf ? c->ikeep_ovf + c->ikeep_ovf_cap : nullptr,
+                                     c->pending_novf ? c->iovf_off : nullptr, TpcListSrc(), false, true, &out, 0, 1)) return fail(c, -1, "combine launch failed");
+    }
+    unsigned long long cur[65];
+    HIPCHK(c, hipMemcpyAsync(cur, c->cmb_cur, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (cur[n_dest]) return fail(c, -1, "tpc_combine_export: a destination block of %llu units is too small (size it with tpc_combine_info)", (unsigned long long)cap_units);
+    for (uint32_t d = 0; d < n_dest; d++) units_host[d] = cur[d];
+    // the lists now hold what the regions held: the insert is no longer pending here -- it comes back, merged with the other ranks',
+    // through tpc_combine_import.  The geometry stays for tpc_combine_merge / tpc_combine_import.
+    c->cmb_geo = g; c->cmb_geo.wpb = 0; c->cmb_geo.buf2 = nullptr; c->cmb_geo.cnt2 = nullptr; c->cmb_have_geo = true;
+    c->pending_apply = false; c->pending_novf = 0;
+    c->filter_zero_pending = c->pending_fresh;  // (what the filter held before this insert still counts when it was not reset)
+    return 0;
+}
+
+int tpc_combine_merge(tpc_ctx *c, uint32_t n_src, const uint16_t *payload_dev, const uint64_t *src_base_host, const uint64_t *dir_dev, uint16_t *out_payload_dev,
+                      uint64_t out_cap_units, uint64_t *out_dir_dev, uint64_t *units_host)
+{
+    if (!c || !out_payload_dev || !out_dir_dev || !units_host) return fail(c, -1, "bad arguments");
+    if (!c->cmb_have_geo) return fail(c, -1, "tpc_combine_export first");
+    if (!replicated(c) || n_src != c->sh_world) return fail(c, -1, "tpc_combine_merge: one source block per rank of a replicated sharded context");
+    HIPCHK(c, hipSetDevice(c->device));
+    const TpcPartPlan &g = c->cmb_geo;
+    const uint64_t stride = (uint64_t)(cmb_slices(g) / c->sh_world) * tpc_list_windows(g.slice_bits);
+    TpcListSrc ls;
+    { int rc = cmb_sources(c, n_src, payload_dev, src_base_host, dir_dev, stride, 0, ls); if (rc) return rc; }
+    HIPCHK(c, hipMemsetAsync(c->cmb_cur, 0, 65 * sizeof(unsigned long long), c->stream));
+    const TpcCombineOut out{out_payload_dev, out_cap_units, c->cmb_cur, out_dir_dev, 1};
+    {
+        Timed t(c, TPC_K_COMBINE);
+        if (tpc_launch_slice_combine(make_launch(c), g.slice_bits, g.b1, g.b2, g.perm_mult, g.perm_inv, nullptr, nullptr, nullptr, ls, false, true, &out, c->sh_rank, c->sh_world))
+            return fail(c, -1, "combine launch failed");
+    }
+    unsigned long long cur[2];
+    HIPCHK(c, hipMemcpyAsync(cur, c->cmb_cur, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (cur[1]) return fail(c, -1, "tpc_combine_merge: the output block of %llu units is too small (the sum of the received blocks always suffices)", (unsigned long long)out_cap_units);
+    *units_host = cur[0];
+    return 0;
+}
+
+int tpc_combine_import(tpc_ctx *c, uint32_t n_src, uint32_t n_owner, const uint16_t *payload_dev, const uint64_t *src_base_host, const uint64_t *dir_dev, uint64_t dir_stride)
+{
+    if (!c) return -1;
+    if (!c->cmb_have_geo) return fail(c, -1, "tpc_combine_export first");
+    if (n_owner > (1u << c->cmb_geo.b1)) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = flush_pending_apply(c); if (rc0) return rc0; }
+    { int rc = cmb_sources(c, n_src, payload_dev, src_base_host, dir_dev, dir_stride, n_owner, c->cmb_ls); if (rc) return rc; }
+    // from here on the round's insert is pending again: the next tpc_pass1_query's first lookup builds every slice from these lists
+    // (or whatever reads the filter first: flush_pending_apply)
+    c->pending_apply = true; c->pending_shard = false; c->pending_lists = true; c->pending_fresh = c->filter_zero_pending; c->pending_pl = c->cmb_geo; c->pending_novf = 0;
+    c->filter_zero_pending = false;
+    return 0;
+}
+
+int tpc_filter_copy_out(tpc_ctx *c, uint64_t word0, uint64_t n_words, uint32_t *dst_dev)
+{
+    if (!c || !c->filter || (n_words && !dst_dev) || word0 + n_words > c->filter_words) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    if (n_words) HIPCHK(c, hipMemcpyAsync(dst_dev, c->filter + word0, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_filter_copy_in(tpc_ctx *c, uint64_t word0, uint64_t n_words, const uint32_t *src_dev)
+{
+    if (!c || !c->filter || (n_words && !src_dev) || word0 + n_words > c->filter_words) return fail(c, -1, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    if (n_words) HIPCHK(c, hipMemcpyAsync(c->filter + word0, src_dev, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_combine_choose(uint32_t world, int L, uint64_t mean_export_units, double *bytes /* [3] */)
+{   // bytes a rank RECEIVES per round under each form of the exchange (the directories are small beside the payload and left out):
+    //   [0] all-gather of the ranks' exports                      (W - 1) D
+    //   [1] reduce-scatter by owner, all-gather of the merged     (W - 1) / W (D + U),  U = all merged lists ~ D W^0.3 (measured on the
+    //       lists                                                 62-genome text: 1.33 / 1.62 / 1.84 D at 2 / 4 / 8 ranks; U <= W D always)
+    //   [2] the dense filters: OR all-reduce by word ranges       2 (W - 1) / W 2^L / 8
+    // D = a rank's export in bytes.  Returns the cheapest: 1, 2 or 3.
+    if (world < 2 || !bytes) return 1;
+    const double W = (double)world, D = 16.0 * (double)mean_export_units, U = D * std::min(W, std::pow(W, 0.3));
+    bytes[0] = (W - 1.0) * D;
+    bytes[1] = (W - 1.0) / W * (D + U);
+    bytes[2] = 2.0 * (W - 1.0) / W * std::ldexp(1.0, L - 3);
+    int best = 0;
+    for (int i = 1; i < 3; i++) if (bytes[i] < bytes[best]) best = i;
+    return best + 1;
+}
 
 int tpc_shard_verify_local(tpc_ctx *c)
 {   // One rank: every survivor of the last tpc_shard_apply was hashed here and every probe address of functions 1..q-1 is owned

@@ -156,7 +156,9 @@ int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl, uint32_
 int tpc_launch_insert_part_split(const TpcLaunch &a, const TpcPartPlan &pl);   // level 2 (and 3) only
 int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl, bool fresh);  // k_part_apply + k_part_ovf
 // iovf_sorted / iovf_off: the insert's overflow entries grouped by slice (tpc_launch_ovf_by_slice), or nullptr when there are none
-int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf_sorted, const uint64_t *iovf_off);  // k_q_split + k_apply_lookup + k_q_ovf
+struct TpcListSrc;
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf_sorted, const uint64_t *iovf_off,
+                                       const TpcListSrc *lists = nullptr);  // k_q_split + k_apply_lookup + k_q_ovf
 int tpc_launch_ovf_by_slice(const TpcLaunch &a, const uint64_t *list, uint64_t n, int slice_bits, uint32_t n_slices, uint32_t *cnt, uint32_t *cursor,
                             uint64_t *off, uint64_t *sorted, uint32_t rank = 0, uint32_t world = 1, int log_nb2 = 0);  // world > 1: local slices of this rank's shard
 #define TPC_FUSE_MAX_OVF (16ull << 20)  // insert overflow entries (ring or region full) up to which the apply is still deferred
@@ -192,6 +194,34 @@ int tpc_launch_survivor_sources(hipStream_t s, const uint64_t *sid, uint64_t n, 
 int tpc_launch_route(hipStream_t s, const int32_t *owner, uint64_t n, unsigned long long *counts, unsigned long long *cursor, uint32_t *perm, int phase);
 int tpc_launch_permute64(hipStream_t s, const uint64_t *src, const uint32_t *perm, uint64_t n, uint64_t *dst);
 int tpc_launch_select(hipStream_t s, const uint64_t *sid, uint64_t n, int fn_count, const uint8_t *hit, const uint32_t *perm, uint64_t *out, unsigned long long *n_out);
+
+// ---- combined multi-GPU exchange: set-bit lists of filter slices (tpc_lists.h, tpc_combine.hip)
+constexpr int TPC_LIST_WINDOW_BITS = 16;                           // bits of a slice behind one list
+constexpr int TPC_LIST_WINDOW_WORDS = 1 << (TPC_LIST_WINDOW_BITS - 5);
+
+// Where the lists to apply are (POD, passed to kernels by value).  Source s has its block at 16-byte unit base[s] of payload and its
+// directory at dir + s * dir_stride.  A workgroup that builds the slice with directory key `key` reads entries
+// dir[s * dir_stride + key * n_windows + w].
+struct TpcListSrc {
+    const uint16_t *payload = nullptr;  // device
+    const uint64_t *base = nullptr;     // device, [n_src]: first unit of every source's block
+    const uint64_t *dir = nullptr;      // device, [n_src][dir_stride]
+    uint64_t dir_stride = 0;
+    uint32_t n_src = 0;
+    // n_owner == 0: every block lists every slice the reading grid builds, keyed by that grid's workgroup index (the blocks a
+    // reduce-scatter delivered to the owner of those slices).  n_owner = W > 0 (all-gathered blocks): block s lists only the slices
+    // of the level-1 buckets b1 with b1 % W == s % W, keyed by their local index [b1 / W][b2] -- a slice reads the n_src / W blocks
+    // s = b1 % W, b1 % W + W, ... (one per rank that exported, or the one merged block of the bucket's owner).
+    uint32_t n_owner = 0;
+};
+
+__host__ __device__ __forceinline__ uint32_t tpc_list_windows(int slice_bits) { return slice_bits > TPC_LIST_WINDOW_BITS ? 1u << (slice_bits - TPC_LIST_WINDOW_BITS) : 1u; }
+
+// what a pass of k_slice_combine produces: n_dest blocks of `cap` 16-byte units each in payload, cur[d] = units used of block d
+// (cur[n_dest] != 0: a block was too small), dir = [n_dest][slices per destination][windows] (tpc_lists.h)
+struct TpcCombineOut { uint16_t *payload; uint64_t cap; unsigned long long *cur; uint64_t *dir; uint32_t n_dest; };
+int tpc_launch_slice_combine(const TpcLaunch &a, int slice_bits, int b1, int b2, uint32_t perm_mult, uint32_t perm_inv, const TpcPartPlan *ipl, const uint64_t *iovf,
+                             const uint64_t *iovf_off, const TpcListSrc &ls, bool dense, bool fresh, const TpcCombineOut *out, uint32_t rank, uint32_t world);
 
 // pass 2 / output (tpc_pass2.hip)
 // Ordered compaction of a bit mask into the list of set positions.  block_sums: scratch of

@@ -870,7 +870,12 @@ static bool part_plan_compute(int L, int q, int slice_bits, uint64_t n_tiles, do
     // the 1.5 x slack; a sharded filter has no direct-kernel fallback behind its overflow list.)
     const bool gated_plan = frac < 1.0;
     const double a_l2 = !gated_plan ? a_exp : q <= 2 ? a_max : std::min(a_max, a_exp * (1.0 + 1.5 / q));
-    const double avg2 = a_l2 * world / ((double)(1 << pl.b1) * pl.wpb * (1 << pl.b2));
+    // a bucket's nwg1 x world level-1 regions are dealt to its wpb level-2 workgroups whole: with fewer regions than workgroups (a few
+    // tiles per rank: small inputs, many ranks) some workgroups take one region each and the others none, so a level-2 region holds
+    // up to ceil(regions / wpb) / regions of the bucket's entries of its slice, not 1 / wpb
+    const uint64_t nvw = (uint64_t)pl.nwg1 * world;
+    const double deal = (double)((nvw + pl.wpb - 1) / pl.wpb) / (double)nvw;
+    const double avg2 = a_l2 * world * deal / ((double)(1 << pl.b1) * (1 << pl.b2));
     pl.cap2 = ((uint64_t)(avg2 * 1.5 + 8 * std::sqrt(avg2) + 128) + 31) & ~31ull;
     // the last level's entries as planar 24-bit lines (tpc_binsp.h): one rank, two levels, slice offsets of at most 20 bits, bins that
     // do not span waves.  TPC_ENTRY_FMT=legacy (read once per process) keeps the 32-bit entries for A/B measurements.

@@ -93,8 +93,8 @@ __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2_lines, int fresh,
                 const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const unsigned char *__restrict__ qbuf2,
                 const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2, const uint32_t *__restrict__ bnd, uint32_t n_groups, uint32_t pb2,
-                uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group)
-{
+                uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, TpcListSrc ls)
+{   // ls (ls.n_src > 0: the combined multi-GPU exchange, tpc_lists.h): set-bit lists of the slice, from this and the other ranks' inserts
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
@@ -133,6 +133,9 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
             const uint64_t a = iovf[i];
             atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
         }
+    }
+    if (ls.n_src) {
+        tpc_lists_apply<PT_APPLY_THREADS>(ls, b1, b2, log_nb2, blockIdx.x, slice, slice_bits);
     }
     const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
     if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];

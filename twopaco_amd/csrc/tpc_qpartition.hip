@@ -26,6 +26,7 @@
 #include "tpc_binsp.h"
 #include "tpc_lean.h"
 #include "tpc_internal.h"
+#include "tpc_lists.h"
 #include <algorithm>
 #include <type_traits>
 #include <cstdio>
@@ -787,8 +788,9 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
                const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
-               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, PtShard sh)
-{   // sh.world > 1 (round 5): the owned slices of a sharded filter, compact layout [local bucket][b2] as k_part_apply / k_q_lookup write and read it
+               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, PtShard sh, TpcListSrc ls)
+{   // ls (ls.n_src > 0, sh.world == 1: the combined multi-GPU exchange, tpc_lists.h): set-bit lists of the slice, from this and the other ranks' inserts
+    // sh.world > 1 (round 5): the owned slices of a sharded filter, compact layout [local bucket][b2] as k_part_apply / k_q_lookup write and read it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
@@ -822,6 +824,9 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
             const uint64_t a = iovf[i];
             atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
         }
+    }
+    if (ls.n_src) {
+        tpc_lists_apply<PT_APPLY_THREADS>(ls, b1, b2, log_nb2, blockIdx.x, slice, slice_bits);
     }
     __syncthreads();
     // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
@@ -1817,7 +1822,11 @@ static bool qpart_plan_compute(int L, int slice_bits, uint64_t n_tiles, double f
     // ... but only at level 1, whose buckets mix the slices evenly: the slice regions of a gated round are sized for ALL the
     // entries, because the round's hot slices (see pl.loads above) take ~2.5 x their share of what is there (sized for the share alone,
     // the regions of one range of eight lost 25 M of 232 M entries to the overflow list)
-    const double avg2 = a_max * world / ((double)nreg2 * world);  // entries of all ranks over all regions
+    // entries of all ranks over all regions -- dealt to the wpb level-2 workgroups of a bucket as whole level-1 regions, so with fewer
+    // regions than workgroups a region holds up to ceil(regions / wpb) / regions of its slice's entries (as tpc_part_plan_sharded)
+    const uint64_t nvw = (uint64_t)pl.nwg1 * world;
+    const double deal = (double)((nvw + pl.wpb - 1) / pl.wpb) / (double)nvw * (double)pl.wpb;
+    const double avg2 = a_max * world * deal / ((double)nreg2 * world);
     pl.wpb3 = 1;
     pl.loads3 = pl.loads;
     if (pl.b3) {
@@ -1950,8 +1959,10 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 
 // Fused tail of the query when the insert's apply was deferred (see tpc_capi.hip:flush_pending_apply): level-2 binning of
 // the query, then k_apply_lookup over the insert's and the query's level-2 regions, then the overflow probes.
-int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, const uint64_t *iovf_off)
-{
+int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, const uint64_t *iovf_off, const TpcListSrc *lists)
+{   // lists: set-bit lists to OR into every slice as well (the combined exchange; ipl.wpb may then be 0: no regions of its own)
+    const TpcListSrc ls = lists ? *lists : TpcListSrc();
+    if (ls.n_src && pl.world != 1) return -1;
     if (pl.b3 || ipl.b3 || pl.world != ipl.world || pl.rank != ipl.rank || pl.slice_bits != ipl.slice_bits || pl.b1 != ipl.b1 || pl.b2 != ipl.b2) return -1;
     if (pl.world > 1 && (pl.fmt == 6 || ipl.fmt2 == 3)) return -1;  // (the sharded passes keep the power-of-two entries)
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2, pl.perm_mult, pl.perm_inv};
@@ -1966,7 +1977,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         (void)hipFuncSetAttribute((const void *)k_apply_lookup6<I3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
         hipLaunchKernelGGL(k_apply_lookup6<I3>, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, (const unsigned char *)ipl.buf2, \
                            ipl.cnt2, (uint64_t)(I3 ? ipl.cap2 / PFmt3::GROUP : ipl.cap2 / 32), fresh ? 1 : 0, iovf, iovf_off, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2, \
-                           pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);       \
+                           pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls);   \
     } while (0)
         if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
         if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
@@ -1986,7 +1997,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
         hipLaunchKernelGGL(k_apply_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
-                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh);
+                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh, ls);
         if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);

@@ -230,6 +230,8 @@ class _Comm:
         """A local failure of this rank: remembered, and agreed upon by every rank at the next collective."""
         if not self.rc:
             self.rc, self.err = 1, "%s: %s" % (type(exc).__name__, exc)
+            sys.stderr.write("twopaco_amd.dist: rank %d: local failure in phase '%s': %s\n" % (self.rank, self.phase, self.err))
+            sys.stderr.flush()
 
     def _agreed(self, flags, op):
         """flags[r] != 0: rank r failed before this collective.  Every rank sees the same flags and raises the same DistAbort."""
@@ -849,6 +851,173 @@ class AddressSharded:
         self.stats["pass2_positions_received"] = recv.numel()
         self._tick("pass2_sharded", t0)
         return st
+
+
+class Combined(AddressSharded):
+    """The first pass with the filter REPLICATED through set-bit lists ("combine before routing"; include/twopaco_hip.h: tpc_combine_*,
+    csrc/tpc_combine.hip).  The reference's threads share one ConcurrentBitVector for free (concurrentbitvector.cpp:31-45, MergeOr
+    :115-122); AddressSharded pays 4 bytes per insert address and 8 per query probe to imitate that over links.  Here every rank
+      insert   runs the one-GPU insert over ITS chunk of the text up to the level-2 regions (tpc_pass1_insert on a context with option
+               replicate_filter), builds every filter slice in LDS and exports only the slice's SET BITS (tpc_combine_export: 2 bytes per
+               distinct bit, owner-major blocks)
+      move     the bytes model (tpc_combine_choose, the same arithmetic in both hosts) picks: an all-gather of the exports (two ranks),
+               or a reduce-scatter by owner -- the north star's "route hits to owning shards", now deduplicated -- a merge on the owner
+               (tpc_combine_merge) and an all-gather of the merged lists; or, when the insert could not stay in its regions (several
+               batches, three levels) or the lists would be larger, an OR all-reduce of the dense filters by word ranges
+      query    imports the lists (tpc_combine_import) and runs the one-GPU query over its chunk: the first lookup builds every slice
+               from the lists, writes the whole filter locally and tests the chunk's probes -- no probe, survivor or answer crosses a link.
+    The marks stay on the rank that hashed them (second pass sharded by key hash as in AddressSharded) or are OR-reduced (union = True).
+    The context must have been configured with option replicate_filter = 1 before tpc_shard_config / tpc_set_params."""
+
+    def __init__(self, ctx, dist, device, configure=True, mode=None):
+        ctx.set_option("replicate_filter", 1)
+        super().__init__(ctx, dist, device, compact=False, configure=configure)
+        # "auto" (the bytes model), "gather" (all-gather of exports), "scatter" (reduce-scatter + all-gather), "dense"
+        self.mode = mode or os.environ.get("TPC_COMBINE", "auto")
+        self.stats["combine"] = {}
+
+    # ---- insert: local insert, export, exchange, import
+    def insert(self, lo=0, hi=None):
+        torch, ctx, W, comm = self.torch, self.ctx, self.world, self.comm
+        comm.phase = "combined insert"
+        t0 = time.perf_counter()
+        self._try(ctx.filter_reset)
+        self._try(ctx.pass1_insert, lo, hi, False)
+        t0 = self._tick("insert_local", t0)
+        info = self._try(ctx.combine_info, W, default=None) or {"sparse": 0}
+        # every rank must take the same road: sparse lists only if every rank's insert stayed in its regions
+        dense = comm.max_ints([0 if info["sparse"] else 1])[0] == 1 or self.mode == "dense"
+        st = self.stats["combine"]
+        if not dense:
+            n_win, spd = info["windows"], info["slices"] // W  # windows per slice, slices per destination
+            cap = info["cap_units"]
+            payload = self._buf("c_payload", W * cap * 16)
+            cdir = self._buf("c_dir", info["slices"] * n_win * 8)
+            units = self._try(ctx.combine_export, W, payload.data_ptr(), cap, cdir.data_ptr(), default=[0] * W)
+            t0 = self._tick("insert_export", t0)
+            # everybody's block sizes: [source][destination] units
+            comm.agree()
+            allu = comm.all_gather(torch.tensor(units, dtype=torch.int64, device=self.device)).cpu().tolist()
+            mean_units = sum(sum(r) for r in allu) // W
+            from . import capi
+            mode, model = capi.combine_choose(W, ctx.L, mean_units)  # (pure arithmetic in the library: both hosts take the same road)
+            if self.mode == "gather":
+                mode = 1
+            elif self.mode == "scatter":
+                mode = 2
+            if W == 1:
+                mode = 1
+            st.update(mode={1: "all-gather of the exports", 2: "reduce-scatter by owner + all-gather of the merged lists", 3: "dense OR all-reduce"}[mode],
+                      model_bytes_received={"gather": model[0], "scatter": model[1], "dense": model[2]}, export_units=units, export_bytes=16 * sum(units))
+            dense = mode == 3
+            if dense:  # the export took the insert out of its regions: this rank's own lists bring it back, to be applied to its dense filter
+                self._try(ctx.combine_import, W, W, payload.data_ptr(), [d * cap for d in range(W)], cdir.data_ptr(), spd * n_win)
+        if dense:
+            st.setdefault("mode", "dense OR all-reduce")
+            self._dense_reduce()
+            self._tick("insert_exchange", t0)
+            return {"mode": st["mode"]}
+        pay64 = payload.view(torch.int64)  # (2 x int64 per unit)
+        dir64 = cdir.view(torch.int64)
+        if mode == 1:
+            # all-gather of every rank's W blocks (used prefixes back to back) and of the directories
+            comm.phase = "combined insert: all-gather of the exports"
+            mine = torch.cat([pay64[2 * d * cap:2 * (d * cap + units[d])] for d in range(W)]) if sum(units) else pay64[:0]
+            most = max(sum(r) for r in allu)
+            pad = self._buf("c_send", max(most, 1) * 16).view(torch.int64)
+            pad[:mine.numel()] = mine
+            allp = comm.all_gather(pad[:2 * most]) if W > 1 else pad[:2 * most].unsqueeze(0)
+            alld = comm.all_gather(dir64) if W > 1 else dir64.unsqueeze(0)
+            self._keep = (allp, alld)  # the query's lookup reads them
+            base = []
+            for r in range(W):
+                o = r * most
+                for d in range(W):
+                    base.append(o)
+                    o += allu[r][d]
+            comm.sync()
+            self._try(ctx.combine_import, W * W, W, allp.data_ptr(), base, alld.data_ptr(), spd * n_win)
+            st["exchange_bytes_received"] = 16 * (sum(sum(r) for r in allu) - sum(units)) + 8 * (W - 1) * dir64.numel()
+        else:
+            # reduce-scatter: block d and its directory to rank d; the owner merges; all-gather of the merged lists
+            comm.phase = "combined insert: reduce-scatter of the exports"
+            send = torch.cat([pay64[2 * d * cap:2 * (d * cap + units[d])] for d in range(W)]) if sum(units) else pay64[:0]
+            recv, rc = comm.a2a_var(send.contiguous(), [2 * u for u in units], out=self._out_buf("c_recv"))
+            rdir = comm.a2a_equal(dir64.contiguous())
+            base, o = [], 0
+            for s in range(W):
+                base.append(o)
+                o += rc[s] // 2
+            comm.sync()
+            t0 = self._tick("insert_exchange", t0)
+            merged = self._buf("c_merged", max(o, 1) * 16)
+            mdir = self._buf("c_mdir", spd * n_win * 8)
+            recv_ptr = recv.data_ptr() if recv.numel() else merged.data_ptr()
+            mu = self._try(ctx.combine_merge, W, recv_ptr, base, rdir.data_ptr(), merged.data_ptr(), max(o, 1), mdir.data_ptr())
+            t0 = self._tick("insert_merge", t0)
+            comm.phase = "combined insert: all-gather of the merged lists"
+            comm.agree()
+            allm = comm.all_gather(torch.tensor([mu], dtype=torch.int64, device=self.device)).cpu().view(-1).tolist()
+            most = max(max(allm), 1)
+            padm = self._buf("c_mpad", most * 16).view(torch.int64)  # (the largest merged block sets the all-gather's block size)
+            padm[:2 * mu] = merged.view(torch.int64)[:2 * mu]
+            allp = comm.all_gather(padm)
+            alld = comm.all_gather(mdir.view(torch.int64))
+            self._keep = (allp, alld)
+            comm.sync()
+            self._try(ctx.combine_import, W, W, allp.data_ptr(), [r * most for r in range(W)], alld.data_ptr(), spd * n_win)
+            st["merged_units"] = allm
+            st["exchange_bytes_received"] = 16 * (o - units[self.rank]) + 16 * (sum(allm) - mu) + 8 * (W - 1) * (rdir.numel() // W + mdir.numel() // 8)
+        self._tick("insert_exchange", t0)
+        return {"mode": st["mode"]}
+
+    def _dense_reduce(self):
+        """OR all-reduce of the ranks' dense filters by word ranges (the mask union's scheme on 2^L / 8 bytes)."""
+        torch, ctx, W, comm = self.torch, self.ctx, self.world, self.comm
+        if W == 1:
+            return
+        comm.phase = "combined insert: dense OR all-reduce"
+        words = ctx.filter_words() - 1  # 2^L / 32: a multiple of W (the last word is the reference's spare)
+        chunk = words // W
+        mine = self._buf("c_dense", words * 4).view(torch.int32)
+        self._try(ctx.filter_copy_out, 0, words, mine.data_ptr())
+        comm.agree()
+        parts = comm.a2a_equal(mine).contiguous()
+        folded = self._buf("c_fold", chunk * 4).view(torch.int32)
+        comm.sync()
+        self._try(ctx.mask_or_blocks, parts.data_ptr(), W, chunk, folded.data_ptr())
+        allm = comm.all_gather(folded).contiguous()
+        comm.sync()
+        self._try(ctx.filter_copy_in, 0, words, allm.data_ptr())
+        self.stats["combine"]["exchange_bytes_received"] = 2 * (W - 1) * chunk * 4
+
+    # ---- query: entirely local
+    def query(self, lo=0, hi=None, union=True):
+        torch, ctx, W = self.torch, self.ctx, self.world
+        self.comm.phase = "combined query"
+        t0 = time.perf_counter()
+        n = self._try(ctx.pass1_query, lo, hi)
+        self.comm.agree()
+        self._keep = None
+        self.stats["local_marks"] = n
+        self.stats["survivors"] = []
+        t0 = self._tick("query_local", t0)
+        if union and W > 1:
+            words = ctx.mask_words()
+            chunk = (words + W - 1) // W
+            self.comm.phase = "mask union"
+            mine = torch.empty(W * chunk, dtype=torch.int32, device=self.device)
+            self._try(ctx.mask_export_padded, mine.data_ptr(), W * chunk)
+            self.comm.agree()
+            parts = self.comm.a2a_equal(mine).contiguous()
+            folded = torch.empty(chunk, dtype=torch.int32, device=self.device)
+            self.comm.sync()
+            self._try(ctx.mask_or_blocks, parts.data_ptr(), W, chunk, folded.data_ptr())
+            allm = self.comm.all_gather(folded).contiguous()
+            self.comm.sync()
+            self._try(ctx.mask_import, allm.data_ptr())
+            self._tick("mask_union", t0)
+        return {"batches": ctx.stat("query_batches")}
 
 
 def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False, sharded_pass2=False):

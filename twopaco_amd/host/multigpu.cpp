@@ -363,7 +363,8 @@ namespace TwoPaCo
 	// ------------------------------------------------------------------------------------------ the pass
 	namespace
 	{
-		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED, REC, REC2, GATHER, SEND_R2, SEND_C2 };
+		enum { SEND_R, SEND_C, RECV_R, RECV_C, OVF_MINE, OVF_ALL, SID, SID2, ADDR, OWNER, MISC_A, MISC_B, PACKED, REC, REC2, GATHER, SEND_R2, SEND_C2,
+		       CMB_PAYLOAD, CMB_DIR, CMB_SEND, CMB_RECV, CMB_DIRS, CMB_MERGED };
 
 		void Exchange(ShardedRank & r, Transport & net, int pass, const uint64_t * geom, void * sendR, void * sendC, uint64_t overflow, bool overflowFetched);
 
@@ -646,8 +647,184 @@ namespace TwoPaCo
 		}
 	}
 
+	namespace
+	{
+		// The first pass with the filter replicated through set-bit lists (multigpu.h: ShardedRank::combined; the same protocol and the
+		// same arithmetic -- tpc_combine_choose -- as twopaco_amd/dist.py:Combined).  The shared ConcurrentBitVector of the reference's
+		// threads (concurrentbitvector.cpp:31-45, MergeOr :115-122) becomes: local insert -> export of every slice's set bits -> all-gather,
+		// or reduce-scatter by owner + merge + all-gather (or the dense filters OR-reduced by word ranges) -> import -> local query.
+		void DenseReduce(ShardedRank & r, Transport & net)
+		{
+			const int W = net.Ranks();
+			if (W == 1) return;
+			const uint64_t words = tpc_filter_words(r.ctx) - 1;  // 2^L / 32: a multiple of the number of ranks
+			const uint64_t chunk = words / uint64_t(W);
+			uint32_t * mine = static_cast<uint32_t*>(r.Ensure(CMB_SEND, words * 4));
+			uint32_t * parts = static_cast<uint32_t*>(r.Ensure(CMB_RECV, words * 4));
+			uint32_t * folded = static_cast<uint32_t*>(r.Ensure(CMB_MERGED, chunk * 4));
+			LibCheck(r.ctx, tpc_filter_copy_out(r.ctx, 0, words, mine), "filter_copy_out");
+			net.AllToAll(r.rank, mine, parts, chunk * 4);
+			LibCheck(r.ctx, tpc_mask_or_blocks(r.ctx, parts, uint32_t(W), chunk, folded), "mask_or_blocks");
+			net.AllGather(r.rank, folded, mine, chunk * 4);
+			LibCheck(r.ctx, tpc_filter_copy_in(r.ctx, 0, words, mine), "filter_copy_in");
+			r.combineBytesReceived = 2 * uint64_t(W - 1) * chunk * 4;
+			r.combineMode = "dense";
+		}
+
+		void CombinedInsert(ShardedRank & r, Transport & net, uint64_t lo, uint64_t hi)
+		{
+			const int W = net.Ranks();
+			LibCheck(r.ctx, tpc_filter_reset(r.ctx), "filter_reset");
+			LibCheck(r.ctx, tpc_pass1_insert(r.ctx, lo, hi, 0), "pass1_insert");
+			r.Phase("insert (local)");
+			uint64_t info[8];
+			LibCheck(r.ctx, tpc_combine_info(r.ctx, uint32_t(W), info), "combine_info");
+			// every rank takes the same road: lists only if every rank's insert stayed in its level-2 regions
+			std::vector<uint64_t> all;
+			const char * pin = std::getenv("TWOPACO_COMBINE");  // gather | scatter | dense (measurements, tests)
+			uint64_t sparse = info[0] && !(pin && std::string(pin) == "dense") ? 1 : 0;
+			net.ExchangeHost(r.rank, &sparse, 1, all);
+			for (int s = 0; s < W; s++) sparse = std::min<uint64_t>(sparse, all[size_t(s)]);
+			if (!sparse)
+			{
+				DenseReduce(r, net);
+				r.Phase("insert exchange (dense)");
+				return;
+			}
+
+			const uint64_t nWin = info[2], slices = info[1], spd = slices / uint64_t(W), cap = info[3];
+			uint16_t * payload = static_cast<uint16_t*>(r.Ensure(CMB_PAYLOAD, size_t(W) * cap * 16));
+			uint64_t * dir = static_cast<uint64_t*>(r.Ensure(CMB_DIR, size_t(slices) * nWin * 8));
+			std::vector<uint64_t> units(W);
+			LibCheck(r.ctx, tpc_combine_export(r.ctx, uint32_t(W), payload, cap, dir, units.data()), "combine_export");
+			r.Phase("insert export");
+			net.ExchangeHost(r.rank, units.data(), W, all);  // all[s * W + d]: units of rank s for destination d
+			uint64_t total = 0, most = 0, mine = 0;
+			for (int s = 0; s < W; s++)
+			{
+				uint64_t sum = 0;
+				for (int d = 0; d < W; d++) sum += all[size_t(s) * W + d];
+				total += sum;
+				most = std::max(most, sum);
+				if (s == r.rank) mine = sum;
+			}
+
+			double model[3] = { 0, 0, 0 };
+			int mode = tpc_combine_choose(uint32_t(W), r.filterBits, total / uint64_t(W), model);
+			if (pin && std::string(pin) == "gather") mode = 1;
+			if (pin && std::string(pin) == "scatter") mode = 2;
+			if (W == 1) mode = 1;
+			if (r.rank == 0 && std::getenv("TWOPACO_TIMING"))
+			{
+				std::fprintf(stderr, "[timing]     combined exchange: export %.1f MB of set-bit lists per rank; bytes a rank receives by the model: all-gather %.1f MB, "
+					"reduce-scatter + all-gather %.1f MB, dense %.1f MB -> %s\n", 16.0 * double(total) / W / 1e6, model[0] / 1e6, model[1] / 1e6, model[2] / 1e6,
+					mode == 1 ? "all-gather" : mode == 2 ? "reduce-scatter + all-gather" : "dense");
+			}
+
+			// the used prefixes of this rank's W blocks, back to back
+			char * send = static_cast<char*>(r.Ensure(CMB_SEND, std::max<uint64_t>(most, 1) * 16));
+			{
+				uint64_t o = 0;
+				for (int d = 0; d < W; d++)
+				{
+					if (units[d]) HipCheck(hipMemcpy(send + o * 16, reinterpret_cast<const char*>(payload) + size_t(d) * cap * 16, units[d] * 16, hipMemcpyDeviceToDevice), "pack the export");
+					o += units[d];
+				}
+			}
+
+			if (mode == 3)
+			{
+				// the export took the insert out of its regions: this rank's own lists bring it back, to be applied to its dense filter
+				std::vector<uint64_t> base(W);
+				for (int d = 0; d < W; d++) base[d] = uint64_t(d) * cap;
+				LibCheck(r.ctx, tpc_combine_import(r.ctx, uint32_t(W), uint32_t(W), payload, base.data(), dir, spd * nWin), "combine_import");
+				DenseReduce(r, net);
+				r.Phase("insert exchange (dense)");
+				return;
+			}
+
+			if (mode == 1)
+			{
+				// all-gather of every rank's blocks and directories: W x W blocks, rank-major
+				char * allp = static_cast<char*>(r.Ensure(CMB_RECV, size_t(W) * std::max<uint64_t>(most, 1) * 16));
+				uint64_t * alld = static_cast<uint64_t*>(r.Ensure(CMB_DIRS, size_t(W) * slices * nWin * 8));
+				net.AllGather(r.rank, send, allp, std::max<uint64_t>(most, 1) * 16);
+				net.AllGather(r.rank, dir, alld, slices * nWin * 8);
+				std::vector<uint64_t> base;
+				for (int s = 0; s < W; s++)
+				{
+					uint64_t o = uint64_t(s) * std::max<uint64_t>(most, 1);
+					for (int d = 0; d < W; d++) { base.push_back(o); o += all[size_t(s) * W + d]; }
+				}
+
+				LibCheck(r.ctx, tpc_combine_import(r.ctx, uint32_t(W * W), uint32_t(W), reinterpret_cast<const uint16_t*>(allp), base.data(), alld, spd * nWin), "combine_import");
+				r.combineBytesReceived = 16 * (total - mine) + uint64_t(W - 1) * slices * nWin * 8;
+				r.combineMode = "gather";
+				r.Phase("insert exchange (all-gather)");
+				return;
+			}
+
+			// reduce-scatter: block d and its directory to rank d, merged there, the merged lists all-gathered
+			std::vector<uint64_t> recvUnits(W), base(W);
+			uint64_t arriving = 0;
+			for (int s = 0; s < W; s++)
+			{
+				recvUnits[s] = all[size_t(s) * W + r.rank];
+				base[s] = arriving;
+				arriving += recvUnits[s];
+			}
+
+			char * recv = static_cast<char*>(r.Ensure(CMB_RECV, std::max<uint64_t>(arriving, 1) * 16));
+			uint64_t * rdir = static_cast<uint64_t*>(r.Ensure(CMB_DIRS, size_t(W) * slices * nWin * 8));  // (room for the all-gathered merged directories below)
+			net.AllToAllV(r.rank, send, units.data(), recv, recvUnits.data(), 16);
+			net.AllToAll(r.rank, dir, rdir, spd * nWin * 8);
+			r.Phase("insert exchange (reduce-scatter)");
+			uint16_t * merged = static_cast<uint16_t*>(r.Ensure(CMB_MERGED, std::max<uint64_t>(arriving, 1) * 16));
+			uint64_t mergedUnits = 0;
+			LibCheck(r.ctx, tpc_combine_merge(r.ctx, uint32_t(W), reinterpret_cast<const uint16_t*>(recv), base.data(), rdir, merged, std::max<uint64_t>(arriving, 1), dir, &mergedUnits), "combine_merge");
+			r.Phase("insert merge");
+			net.ExchangeHost(r.rank, &mergedUnits, 1, all);
+			uint64_t mostMerged = 1, totalMerged = 0;
+			for (int s = 0; s < W; s++) { mostMerged = std::max(mostMerged, all[size_t(s)]); totalMerged += all[size_t(s)]; }
+			// (the largest merged block sets the all-gather's block size: this rank's block padded in a buffer of that size)
+			char * padded = static_cast<char*>(r.Ensure(CMB_SEND, mostMerged * 16));
+			if (mergedUnits) HipCheck(hipMemcpy(padded, merged, mergedUnits * 16, hipMemcpyDeviceToDevice), "pad the merged block");
+			char * allp = static_cast<char*>(r.Ensure(CMB_PAYLOAD, size_t(W) * mostMerged * 16));
+			net.AllGather(r.rank, padded, allp, mostMerged * 16);
+			net.AllGather(r.rank, dir, rdir, spd * nWin * 8);  // (dir now holds the merged lists' directory, [slice][window] of this rank's slices)
+			for (int s = 0; s < W; s++) base[s] = uint64_t(s) * mostMerged;
+			LibCheck(r.ctx, tpc_combine_import(r.ctx, uint32_t(W), uint32_t(W), reinterpret_cast<const uint16_t*>(allp), base.data(), rdir, spd * nWin), "combine_import");
+			r.combineBytesReceived = 16 * (arriving - recvUnits[r.rank]) + 16 * (totalMerged - mergedUnits) + uint64_t(W - 1) * 2 * spd * nWin * 8;
+			r.combineMode = "scatter";
+			r.Phase("insert exchange (all-gather of the merged lists)");
+		}
+
+		void CombinedFirstPass(ShardedRank & r, Transport & net, uint64_t lo, uint64_t hi)
+		{
+			r.PhaseBegin();
+			if (!r.filterLoaded) CombinedInsert(r, net, lo, hi);
+			uint64_t marks = 0;
+			LibCheck(r.ctx, tpc_pass1_query(r.ctx, lo, hi, &marks), "pass1_query");
+			r.Phase("query (local)");
+			if (r.phaseOn) std::fprintf(stderr, "[timing]     combined exchange: %s, %.1f MB received by rank 0\n", r.combineMode.c_str(), double(r.combineBytesReceived) / 1e6);
+			r.PhasePrint("combined first pass");
+		}
+	}
+
+	namespace
+	{
+		void MaskUnion(ShardedRank & r, Transport & net);
+	}
+
 	void ShardedFirstPass(ShardedRank & r, Transport & net, int hashFunctions, uint64_t lo, uint64_t hi)
 	{
+		if (r.combined)
+		{
+			CombinedFirstPass(r, net, lo, hi);
+			if (!r.shardedSecondPass) MaskUnion(r, net);  // (every rank marked only the positions it hashed)
+			return;
+		}
+
 		uint64_t geom[16];
 		const bool overlapped = std::getenv("TWOPACO_OVERLAP") != 0 && !r.filterLoaded;
 		if (overlapped) OverlappedFirstPass(r, net, hashFunctions, lo, hi);

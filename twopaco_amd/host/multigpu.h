@@ -85,7 +85,7 @@ namespace TwoPaCo
 		int device;
 		tpc_ctx * ctx;
 		// device scratch owned by the rank (grown on demand, freed by Release)
-		enum { BUFFERS = 18 };
+		enum { BUFFERS = 24 };
 		void * buf[BUFFERS];
 		size_t cap[BUFFERS];
 		// exact-size exchange of the level-1 regions (tpc_shard_pack / tpc_shard_apply_packed); false: equal blocks
@@ -96,6 +96,13 @@ namespace TwoPaCo
 		uint64_t regionBytesSent;
 		bool filterLoaded;  // this round's filter shard was restored from a checkpoint (tpc_filter_upload): ShardedFirstPass skips the insert
 		int verifyEager;  // survivor verification: -1 not decided yet, 0 lazy (function 1 alone, then the rest), 1 all q - 1 functions in one round trip
+		// The combined exchange (include/twopaco_hip.h: tpc_combine_*): the context keeps the WHOLE filter (option replicate_filter), the rank
+		// inserts its chunk locally, only the set bits of every slice travel (2 bytes per distinct bit), the query is local.  false: the
+		// level-1 entries of both passes are routed to the owners of their slices (tpc_shard_*: filters no single GPU holds)
+		bool combined;
+		int filterBits;                 // L (the bytes model of the combined exchange)
+		std::string combineMode;        // what the last combined round did: "gather", "scatter" or "dense"
+		uint64_t combineBytesReceived;  // ... and the bytes this rank received for it
 		// TWOPACO_TIMING=1: host-clock milliseconds per phase of the first pass (every phase ends synchronised), printed by rank 0
 		std::vector<std::pair<std::string, double> > phaseMs;
 		std::chrono::steady_clock::time_point phaseT0;
@@ -103,7 +110,7 @@ namespace TwoPaCo
 		void PhaseBegin();
 		void Phase(const char * name);  // time since the previous Phase / PhaseBegin goes to `name`
 		void PhasePrint(const char * title);
-		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), filterLoaded(false), verifyEager(-1), phaseOn(false) { for (int i = 0; i < BUFFERS; i++) { buf[i] = 0; cap[i] = 0; } }
+		ShardedRank() : rank(0), device(0), ctx(0), compactExchange(true), shardedSecondPass(true), regionBytesSent(0), filterLoaded(false), verifyEager(-1), combined(false), filterBits(0), combineBytesReceived(0), phaseOn(false) { for (int i = 0; i < BUFFERS; i++) { buf[i] = 0; cap[i] = 0; } }
 		void * Ensure(int which, size_t bytes);
 		void Release();
 	};

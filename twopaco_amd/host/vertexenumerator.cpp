@@ -219,6 +219,12 @@ namespace TwoPaCo
 				// ShardedSecondPass / ShardedFinish); TWOPACO_REPLICATED_PASS2=1: union of the candidate masks, then the single-GPU
 				// second pass on rank 0, which then keeps the whole text
 				const bool shardedPass2 = sharded && std::getenv("TWOPACO_REPLICATED_PASS2") == 0;
+				// How the ranks share the filter.  Combined (default while 2^L / 8 bytes fit a GPU with room to spare and the passes have two
+				// levels: L <= 38): every rank keeps the whole filter, inserts its chunk of the text locally and only the SET BITS of every
+				// slice travel, once (multigpu.cpp:CombinedFirstPass); the query is local.  Entries (larger filters; TWOPACO_MULTIGPU=entries):
+				// the filter is cut over the ranks and every hash hit of both passes is routed to the owner of its slice.
+				const char * multiGpuEnv = std::getenv("TWOPACO_MULTIGPU");
+				const bool combined = sharded && filterSize <= 38 && !(multiGpuEnv && std::string(multiGpuEnv) == "entries");
 				// filter slices of 2^20 bits (128 KiB of LDS) unless the filter is too small to give every rank its level-1 buckets:
 				// the fan-out 2^(L - slice_bits) is split over two levels and the first must have at least `gpus` buckets
 				int logGpus = 0;
@@ -253,7 +259,7 @@ namespace TwoPaCo
 				std::vector<uint64_t> table;
 				// (a sharded run checkpoints every rank's shard in its own file, <name>[.<round>].shard<r>of<W>: the shard layout depends on
 				//  the number of ranks, so such a checkpoint reloads into a run with the same --gpus only)
-				const size_t ckptShards = sharded ? size_t(gpus) : 1;
+				const size_t ckptShards = sharded && !combined ? size_t(gpus) : 1;  // (combined: every rank holds the whole filter -- rank 0 writes it, every rank reads it)
 				if (!options.loadFilter.empty())
 				{
 					// the filter's bits mean something only under the hash tables they were set with: those come from the file
@@ -316,6 +322,7 @@ namespace TwoPaCo
 							if (shardedPass2) Check(tpc_set_option(ctx_, "text_window", 1), "set_option");
 							// tracts send nothing (multigpu.cpp:ShardedFirstPass copies their verdicts); TWOPACO_SHARD_PERIODIC=0: every position probes
 							Check(tpc_set_option(ctx_, "shard_periodic_skip", shardPeriodic ? 1 : 0), "set_option");
+							if (combined) Check(tpc_set_option(ctx_, "replicate_filter", 1), "set_option");
 							Check(tpc_shard_config(ctx_, 0, uint32_t(gpus)), "shard_config");
 						}
 
@@ -394,7 +401,8 @@ namespace TwoPaCo
 					std::vector<int> devices(gpus);
 					for (int r = 0; r < gpus; r++) devices[r] = options.emulateRanks ? options.device : options.device + r;
 					net = MakeTransport(devices, options.rccl && !options.emulateRanks);
-					logStream << "GPUs = " << gpus << " (Bloom filter sharded by bit address; transport: " << net->Name() << ")" << std::endl;
+					logStream << "GPUs = " << gpus << (combined ? " (Bloom filter replicated through set-bit lists, combined by bit-address owner; transport: " : " (Bloom filter sharded by bit address; transport: ")
+						<< net->Name() << ")" << std::endl;
 					peers_.resize(gpus);
 					peers_[0].rank = 0; peers_[0].device = devices[0]; peers_[0].ctx = ctx_;
 					// The level-1 regions travel as equal blocks (sized tightly: tpc_shard_plan; the own block is read in place) up to four
@@ -408,6 +416,8 @@ namespace TwoPaCo
 					{
 						peers_[r].compactExchange = compact;
 						peers_[r].shardedSecondPass = shardedPass2;
+						peers_[r].combined = combined;
+						peers_[r].filterBits = int(filterSize);
 					}
 					std::vector<std::string> errors(gpus);
 					std::vector<std::thread> pool;
@@ -426,6 +436,7 @@ namespace TwoPaCo
 								check(tpc_set_option(me.ctx, "part_budget_bytes", partBudget), "set_option");
 								check(tpc_set_option(me.ctx, "text_window", 1), "set_option");  // ranks other than 0 keep only their chunk of the text (rank 0 runs the second pass)
 								check(tpc_set_option(me.ctx, "shard_periodic_skip", shardPeriodic ? 1 : 0), "set_option");
+								if (combined) check(tpc_set_option(me.ctx, "replicate_filter", 1), "set_option");
 								check(tpc_shard_config(me.ctx, uint32_t(r), uint32_t(gpus)), "shard_config");
 								check(tpc_set_params(me.ctx, int(vertexLength), int(filterSize), int(hashFunctions), table.data()), "set_params");
 								check(tpc_seq_upload(me.ctx, text.bases.data(), text.nmask.data(), text.length), "seq_upload");
@@ -569,15 +580,15 @@ namespace TwoPaCo
 									peers_[r].filterLoaded = !options.loadFilter.empty();
 									if (peers_[r].filterLoaded)
 									{
-										LoadFilter(FilterFileName(options.loadFilter, round, size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
-											peers_[r].ctx, uint32_t(r), uint32_t(ckptShards));
+										LoadFilter(FilterFileName(options.loadFilter, round, combined ? 0 : size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
+											peers_[r].ctx, combined ? 0u : uint32_t(r), uint32_t(ckptShards));
 									}
 
 									ShardedFirstPass(peers_[r], *net, int(hashFunctions), low, high);
-									if (!options.saveFilter.empty())
+									if (!options.saveFilter.empty() && (!combined || r == 0))
 									{
-										SaveFilter(FilterFileName(options.saveFilter, round, size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
-											peers_[r].ctx, uint32_t(r), uint32_t(ckptShards));
+										SaveFilter(FilterFileName(options.saveFilter, round, combined ? 0 : size_t(r), ckptShards), vertexLength, filterSize, hashFunctions, round, rounds, low, high, table,
+											peers_[r].ctx, combined ? 0u : uint32_t(r), uint32_t(ckptShards));
 									}
 
 									if (shardedPass2) ShardedSecondPass(peers_[r], *net, abundance, &roundCounters[size_t(r) * 4]);
