@@ -142,11 +142,14 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
         ph = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[timing\]\s+(.*): ([0-9.eE+-]+) ms", err)}
         # the C++ multi-GPU host's own phases of the sharded first pass (rank 0, summed over the rounds): "name ms;" pairs on one line
         sharded = {}
-        for m in re.finditer(r"\[timing\]\s+sharded first pass[^:]*\(rank 0, ms\):(.*)", err):
+        for m in re.finditer(r"\[timing\]\s+(?:sharded|combined) first pass[^:]*\(rank 0, ms\):(.*)", err):
             for name, val in re.findall(r"\s*([^;]*?) ([0-9.eE+-]+);", m.group(1)):
                 sharded[name.strip()] = sharded.get(name.strip(), 0.0) + float(val)
         if sharded:
             ph["__sharded__"] = sharded
+        m = re.search(r"\[timing\]\s+combined exchange: (\S.*?), ([0-9.eE+-]+) MB received by rank 0", err)
+        if m:
+            ph["__combined__"] = {"mode": m.group(1), "bytes_received_rank0": int(float(m.group(2)) * 1e6)}
         m = re.search(r"\[timing\] device memory in use after the rounds: ([0-9.eE+-]+) GB", err)
         if m:
             ph["__device_GB__"] = float(m.group(1))
@@ -178,6 +181,7 @@ def e2e_cli(files, p, golden, runs, tmp, gpus=1, settle_s=0.0):
             "output_sha256_equals_reference": sha_ok,
             "sharded_first_pass_ms_rank0": {k: v for k, v in sharded.items() if k != "region bytes sent"} if sharded else None,
             "region_bytes_sent_rank0": int(sharded["region bytes sent"]) if sharded and "region bytes sent" in sharded else None,
+            "combined_exchange_rank0": median_ph.get("__combined__"),
             "what": "twopaco CLI child process%s, process start -> exit (output file closed), %d FASTA files in the page cache, median of %d runs" % (
                 " --gpus %d (C++ host, RCCL transport)" % gpus if gpus > 1 else "", len(files), runs)}
 

@@ -357,7 +357,7 @@ int tpc_mask_import(tpc_ctx *ctx, const uint32_t *src_dev);
  *                          entries per destination block); info[0] = 0: the insert was applied to this rank's dense filter (several
  *                          batches, three levels, no memory): OR-reduce the filters instead (tpc_filter_copy_out / tpc_mask_or_blocks /
  *                          tpc_filter_copy_in: an all_to_all of word ranges, a fold, an all_gather)
- *   tpc_combine_export     every slice built in LDS from the rank's own entries; its SET BITS leave as ascending 16-bit offsets per
+ *   tpc_combine_export     every slice built in LDS from the rank's own entries; its SET BITS leave as 16-bit offsets per
  *                          2^16-bit window (csrc/tpc_lists.h): block d of payload_dev (cap_units 16-byte units each) = the slices of
  *                          the level-1 buckets b1 % n_dest == d in the order [b1 / n_dest][b2]; dir_dev[d][slice][window] =
  *                          first unit << 24 | entries; units_host[d] = units used.  2 bytes per DISTINCT set bit of the chunk

@@ -52,7 +52,7 @@ def test_bench_auto_value_is_the_address_sharded_filter_and_ranges_keep_their_re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", TPC_MULTIGPU="entries")
     env.pop("TPC_DIST_BACKEND", None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
                           "--no-cpu-baseline", "--e2e-runs", "0"], env=env, capture_output=True, text=True, timeout=600)
@@ -76,6 +76,7 @@ def test_bench_two_ranks_on_one_gpu_whole_line():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPC_FORCE_DIST")}
     env["TPC_DIST_BACKEND"] = "gloo"
+    env["TPC_MULTIGPU"] = env["TWOPACO_MULTIGPU"] = "entries"  # this test pins the entry-routing exchange (filters beyond one GPU); the default is below
     env["TPC_E2E_EMULATE_RANKS"] = "1"  # the end-to-end leg: `twopaco --gpus 2 --emulate-ranks` (both ranks of the C++ host on this one device)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
                           "--no-cpu-baseline", "--e2e-runs", "1", "--e2e-settle", "0.5"], env=env, capture_output=True, text=True, timeout=900)
@@ -96,6 +97,40 @@ def test_bench_two_ranks_on_one_gpu_whole_line():
     assert cx["all_to_all_GBs_rank0"] is None or cx["all_to_all_GBs_rank0"] > 0  # (None: the loopback copies of this small input took no measurable time)
 
 
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_combined_exchange_whole_line(ranks, tmp_path):
+    """`bench.py --gpus N` with its default exchange while the filter fits a GPU -- the filter replicated through set-bit lists
+    (twopaco_amd/dist.py:Combined) -- gloo standing in for RCCL, the ranks taking turns on GPU 0 (TPC_DIST_SERIALIZE) so that the
+    library-call times the link model is built from are those of a rank alone on its device: counters equal to the ranges', the
+    model's inputs and prediction in the line, the C++ host's end-to-end leg through the same exchange."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPC_FORCE_DIST", "TPC_MULTIGPU", "TWOPACO_MULTIGPU")}
+    env["TPC_DIST_BACKEND"] = "gloo"
+    env["TPC_DIST_SERIALIZE"] = str(tmp_path / "device.lock")
+    env["TPC_E2E_EMULATE_RANKS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
+                          "--no-cpu-baseline", "--e2e-runs", "1", "--e2e-settle", "0.5"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["backend"] == "gloo" and line["headline_decomposition"] == "address"
+    assert line["result"] == line["ranges"]["result"] and line["result"]["junctions"] > 0
+    assert ("all-gather of the exports" if ranks == 2 else "reduce-scatter") in line["multi_gpu_exchange"]
+    assert line["exchange_bytes_rank0_per_step"] > 0 and line["combine_rank0"]["export_bytes"] > 0
+    m = line["model"]
+    assert m["compute_ms"] > 0 and m["wire_ms_total"] > 0 and abs(m["predicted_ms"] - m["compute_ms"] - m["wire_ms_total"]) < 1e-6
+    assert {"pass1_insert", "combine_export", "pass1_query"} <= set(line["call_ms_rank0_per_step"])
+    assert line["e2e_failed"] is False, line["e2e"]
+    cx = line["cxx_host"]
+    assert cx["rounds_ms"] > 0 and {"insert (local)", "insert export", "query (local)"} <= set(cx["sharded_first_pass_ms_rank0"])
+    assert cx["combined_exchange_rank0"]["bytes_received_rank0"] > 0
+
+
 def test_bench_address_path_full_size_over_rccl():
     """The address decomposition at the bench's full size (62 x 5 Mbp, f=36) with one RCCL rank: the 8.6 GB and 19 GB exchange
     buffers cross `_Comm` in 256 MiB messages (a single multi-GiB all_to_all_single arrived truncated here), and the counters
@@ -106,7 +141,7 @@ def test_bench_address_path_full_size_over_rccl():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     case = CASES["m2_full"]
-    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", TPC_MULTIGPU="entries")
     env.pop("TPC_DIST_BACKEND", None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--decomposition", "address"],
                          env=env, capture_output=True, text=True, timeout=900)

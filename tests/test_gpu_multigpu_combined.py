@@ -123,3 +123,36 @@ def test_timing_line_names_the_exchange(tmp_path):
     assert r.returncode == 0, r.stderr
     assert sha256_file(out) == case["bin_sha256"]
     assert "combined exchange: export" in r.stderr and "reduce-scatter + all-gather" in r.stderr and "combined first pass" in r.stderr
+
+
+@pytest.mark.parametrize("ranks,mode", [(4, "scatter"), (2, "gather"), (4, "dense")])
+def test_both_hosts_move_the_same_bytes(tmp_path, ranks, mode, monkeypatch):
+    """One protocol, one implementation of its arithmetic: the C++ host (multigpu.cpp) and the torch.distributed
+    driver (dist.py:Combined) take the form of the exchange from the same library call (tpc_combine_choose) and move the same blocks --
+    on m2_small at `ranks` emulated ranks rank 0 of either host reports the same number of bytes received, to the byte."""
+    import pickle
+    import re
+    import torch.multiprocessing as mp
+    from dist_worker import combined_worker
+    from test_dist_cpu import free_port
+    case = CASES["m2_small"]
+    files = case_files(case, tmp_path)
+    env = dict(os.environ, TWOPACO_TIMING="1", TWOPACO_COMBINE=mode)
+    out = str(tmp_path / "t.bin")
+    r = subprocess.run([EXE, "-k", str(case["k"]), "-f", str(case["L"]), "-q", str(case["q"]), "--gpus", str(ranks), "--emulate-ranks", "--seed", str(case["seed"]),
+                        "--tmpdir", str(tmp_path), "-o", out] + files, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert sha256_file(out) == case["bin_sha256"]
+    m = re.search(r"combined exchange: (\w+), [0-9.]+ MB received by rank 0 \((\d+) bytes\)", r.stderr)
+    assert m and m.group(1) == mode
+    cxx_bytes = int(m.group(2))
+    from twopaco_amd import synth
+    s = case["synth"]
+    spec = {"workload": s["workload"], "scale": s["scale"], "k": case["k"], "L": case["L"], "q": case["q"], "seed": case["seed"], "ranges": [(0, 1 << case["L"])],
+            "abundance": MAXU, "options": {"slice_bits": min(20, case["L"] - max(2, 2 * (ranks.bit_length() - 1)))}, "mode": mode, "sharded_pass2": "records", "text_window": True}
+    res = str(tmp_path / "res.pkl")
+    mp.spawn(combined_worker, args=(ranks, free_port(), spec, res), nprocs=ranks, join=True)
+    with open(res, "rb") as f:
+        gathered = pickle.load(f)
+    py = gathered[0]["rounds"][0]["combine"]
+    assert py["exchange_bytes_received"] == cxx_bytes, (py, cxx_bytes)

@@ -9,7 +9,7 @@
 //
 //   k_slice_combine  one workgroup per filter slice: the zeroed slice in LDS, OR of every source -- the rank's own level-2 insert
 //                    regions and overflow entries, and / or set-bit lists received from other ranks -- then the slice's set bits
-//                    leave as ascending 16-bit offsets, one list per 2^16-bit window of the slice (tpc_lists.h), in the block of the
+//                    leave as 16-bit offsets, one list per 2^16-bit window of the slice (tpc_lists.h), in the block of the
 //                    rank that owns the slice (one atomic per workgroup claims the space; a directory entry per window says where
 //                    its list went), and / or the dense slice is written to the filter.
 //
@@ -18,80 +18,94 @@
 // lookup (tpc_qpart6.h:k_apply_lookup6) builds every slice from the imported lists, so no probe and no survivor ever crosses a link.
 #include "tpc_internal.h"
 #include "tpc_lists.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int CB_THREADS = PT_APPLY_THREADS;
 constexpr int CB_MAX_WIN = 1 << (20 - TPC_LIST_WINDOW_BITS);
 
-__global__ void __launch_bounds__(CB_THREADS)
+// THREADS = 1024 / parts: a workgroup builds 1 / parts of a slice (whole 2^16-bit windows; a part reads all the entries of its slice's
+// regions and keeps its own, and only its own windows' received lists).  The kernel waits for memory most of its time -- region counts,
+// entries, the claim of its output space, one after the other: ~10 us per workgroup, 2.7 ms for the 65536 slices of a 2^36-bit filter
+// whatever the number of entries.  Parts were built to let two to four workgroups share a CU (a whole slice's 128 KB of LDS leave room
+// for one); measured, they buy nothing (tpc_launch_slice_combine), so the launch uses whole slices.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_slice_combine(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2,
                 const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, TpcListSrc ls, uint32_t *__restrict__ filter, int fresh,
                 uint16_t *__restrict__ out_payload, uint64_t out_cap, unsigned long long *out_cur, uint64_t *__restrict__ out_dir, uint32_t n_dest, PtPerm perm, PtShard grid)
 {
+    constexpr uint32_t PARTS = 1024 / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t words = 1u << (slice_bits - 5);
+    const uint32_t words = (1u << (slice_bits - 5)) / PARTS;  // of this part
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *s_w = slice + ((words + 3u) & ~3u);   // [CB_THREADS / 64] scan scratch
-    uint32_t *s_win = s_w + CB_THREADS / 64;        // [CB_MAX_WIN + 1] entries before every window, then [CB_MAX_WIN] its first unit
+    uint32_t *s_w = slice + ((words + 3u) & ~3u);   // [THREADS / 64] scan scratch
+    uint32_t *s_win = s_w + THREADS / 64;           // [CB_MAX_WIN + 1] entries before every window of the part, then [CB_MAX_WIN] its first unit
     uint32_t *s_ctl = s_win + 2 * CB_MAX_WIN + 1;   // [4]
     const uint32_t nb2 = 1u << log_nb2;
-    // the permuted slice this workgroup builds: every slice (grid.world == 1), or the blockIdx-th slice of the level-1 buckets rank grid.rank owns
-    uint32_t b1 = blockIdx.x >> log_nb2;
-    const uint32_t b2 = blockIdx.x & (nb2 - 1u);
+    // the permuted slice this workgroup builds a part of: every slice (grid.world == 1), or the slices of the level-1 buckets rank grid.rank owns
+    const uint32_t part = blockIdx.x % PARTS, index = blockIdx.x / PARTS;
+    uint32_t b1 = index >> log_nb2;
+    const uint32_t b2 = index & (nb2 - 1u);
     if (grid.world > 1) b1 = b1 * grid.world + grid.rank;
     const uint32_t sp = (b1 << log_nb2) | b2;
-    uint32_t *out = filter ? filter + (uint64_t)perm.slice_of(sp) * words : nullptr;
+    const uint32_t word0 = part * words;  // the part's first word in the slice
+    uint32_t *out = filter ? filter + (uint64_t)perm.slice_of(sp) * (words * PARTS) + word0 : nullptr;
     const bool wide = (words & 3u) == 0;
+    const uint32_t n_win = tpc_list_windows(slice_bits), n_pwin = n_win / PARTS;  // windows of the slice, of the part (the host launches PARTS <= n_win)
+    TpcListReader<THREADS> lists;  // the received lists' first loads go out now: their round trips run under the zeroing
+    if (ls.n_src) lists.begin(ls, b1, b2, log_nb2, index, slice_bits, part * n_pwin, n_pwin);
     if (fresh || !out) {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += CB_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
-        else for (uint32_t i = threadIdx.x; i < words; i += CB_THREADS) slice[i] = 0;
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+        else for (uint32_t i = threadIdx.x; i < words; i += THREADS) slice[i] = 0;
     } else {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += CB_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
-        else for (uint32_t i = threadIdx.x; i < words; i += CB_THREADS) slice[i] = out[i];
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += THREADS) slice[i] = out[i];
     }
     __syncthreads();
-    auto set = [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); };
+    auto set = [slice, word0, words](uint32_t v) {
+        const uint32_t w = (v >> 5) - word0;  // (unsigned: entries of the parts before this one wrap around and fail the test too)
+        if (PARTS == 1 || w < words) atomicOr(&slice[w], 1u << (v & 31u));
+    };
     // ---- this rank's own level-2 insert regions of the slice (32-bit slice offsets) and its overflow entries grouped by slice
     for (uint32_t j = 0; j < iwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
-        pt_stream_region<CB_THREADS, 2>(ibuf2 + r * icap2, n, set);
+        pt_stream_region<THREADS, 2>(ibuf2 + r * icap2, n, set);
     }
     if (iovf_off) {
         const uint64_t o0 = iovf_off[sp], o1 = iovf_off[sp + 1];
         const uint32_t smask = (1u << slice_bits) - 1u;
-        for (uint64_t i = o0 + threadIdx.x; i < o1; i += CB_THREADS) set((uint32_t)iovf[i] & smask);
+        for (uint64_t i = o0 + threadIdx.x; i < o1; i += THREADS) set((uint32_t)iovf[i] & smask);
     }
     // ---- set-bit lists (this kernel's own output format) received from other ranks
-    if (ls.n_src) {
-        tpc_lists_apply<CB_THREADS>(ls, b1, b2, log_nb2, blockIdx.x, slice, slice_bits);
-    }
+    if (ls.n_src) lists.finish(ls, slice);
     __syncthreads();
     if (out) {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += CB_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
-        else for (uint32_t i = threadIdx.x; i < words; i += CB_THREADS) out[i] = slice[i];
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += THREADS) out[i] = slice[i];
     }
     if (!out_payload) return;
-    // ---- the slice's set bits: thread t lists the bits of its run of words behind those of the threads before it; the threads of a
-    // window (a contiguous range of threads) write that window's list, which starts on a 16-byte unit
-    const uint32_t n_win = tpc_list_windows(slice_bits), tpw = (uint32_t)CB_THREADS / n_win;
-    const uint32_t per = (words + CB_THREADS - 1u) / CB_THREADS;
-    const uint32_t w0 = min(words, threadIdx.x * per), w1 = min(words, w0 + per);
+    // ---- the part's set bits.  The tpw threads of a window (a contiguous range of threads) list that window's bits: thread tl of the
+    // window takes its words tl, tl + tpw, tl + 2 tpw, ... -- consecutive lanes read consecutive LDS words (a run of consecutive words per
+    // thread put every lane of a wave on one bank: 16 us per slice) -- and writes its bits behind those of the threads before it: a
+    // window's list is contiguous and starts on a 16-byte unit, the order of the offsets inside it is of no consequence to a reader.
+    const uint32_t tpw = (uint32_t)THREADS / n_pwin;
+    const uint32_t win = threadIdx.x / tpw, tl = threadIdx.x % tpw;
+    const uint32_t wwords = min(words, (uint32_t)TPC_LIST_WINDOW_WORDS), wfirst = win * wwords;  // the window's words
     uint32_t cnt = 0;
-    for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(slice[w]);
+    for (uint32_t w = tl; w < wwords; w += tpw) cnt += (uint32_t)__popc(slice[wfirst + w]);
     uint32_t total;
-    const uint32_t off = pt_block_excl_scan<CB_THREADS>(cnt, s_w, total);
-    const uint32_t win = threadIdx.x / tpw;
-    if (threadIdx.x % tpw == 0) s_win[win] = off;  // entries before the window
-    if (threadIdx.x == 0) s_win[n_win] = total;
+    const uint32_t off = pt_block_excl_scan<THREADS>(cnt, s_w, total);
+    if (tl == 0) s_win[win] = off;  // entries before the window
+    if (threadIdx.x == 0) s_win[n_pwin] = total;
     __syncthreads();
     // destination block and the slice's index there: [local bucket of the destination][b2]
     const uint32_t dest = b1 & (n_dest - 1u);
-    const uint64_t key = grid.world > 1 ? (uint64_t)blockIdx.x : ((uint64_t)(b1 / n_dest) << log_nb2) | b2;
+    const uint64_t key = grid.world > 1 ? (uint64_t)index : ((uint64_t)(b1 / n_dest) << log_nb2) | b2;
     if (threadIdx.x == 0) {
         uint32_t units = 0;
-        for (uint32_t v = 0; v < n_win; v++) { s_win[CB_MAX_WIN + 1 + v] = units; units += (s_win[v + 1] - s_win[v] + 7u) >> 3; }
+        for (uint32_t v = 0; v < n_pwin; v++) { s_win[CB_MAX_WIN + 1 + v] = units; units += (s_win[v + 1] - s_win[v] + 7u) >> 3; }
         const uint64_t base = units ? (uint64_t)atomicAdd(&out_cur[dest], (unsigned long long)units) : 0ull;
         const bool ok = base + units <= out_cap;
         if (!ok) out_cur[n_dest] = 1ull;  // the block is too small (the host sizes it from the entry counts: tpc_combine_info)
@@ -101,19 +115,18 @@ k_slice_combine(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__re
     const bool ok = s_ctl[2] != 0;
     const uint64_t base = (uint64_t)s_ctl[0] | ((uint64_t)s_ctl[1] << 32);
     const uint64_t slices_per_dest = ((uint64_t)1 << (perm.F)) / (grid.world > 1 ? grid.world : n_dest);
-    uint64_t *dir = out_dir + ((uint64_t)(grid.world > 1 ? 0u : dest) * slices_per_dest + key) * n_win;
-    if (threadIdx.x < n_win) {
+    uint64_t *dir = out_dir + ((uint64_t)(grid.world > 1 ? 0u : dest) * slices_per_dest + key) * n_win + part * n_pwin;
+    if (threadIdx.x < n_pwin) {
         const uint32_t n = s_win[threadIdx.x + 1] - s_win[threadIdx.x];
         dir[threadIdx.x] = ok ? ((base + s_win[CB_MAX_WIN + 1 + threadIdx.x]) << 24) | (uint64_t)n : 0ull;
     }
     if (!ok || cnt == 0) return;
     uint16_t *dst = out_payload + (((uint64_t)dest * out_cap + base + s_win[CB_MAX_WIN + 1 + win]) << 3) + (off - s_win[win]);
-    const uint32_t wmask = TPC_LIST_WINDOW_WORDS - 1u;
-    for (uint32_t w = w0; w < w1; w++) {
-        uint32_t x = slice[w];
+    for (uint32_t w = tl; w < wwords; w += tpw) {
+        uint32_t x = slice[wfirst + w];
         while (x) {
             const uint32_t b = (uint32_t)__ffs((int)x) - 1u;
-            *dst++ = (uint16_t)(((w & wmask) << 5) | b);
+            *dst++ = (uint16_t)((w << 5) | b);
             x &= x - 1u;
         }
     }
@@ -135,11 +148,27 @@ int tpc_launch_slice_combine(const TpcLaunch &a, int slice_bits, int b1, int b2,
     if (slice_bits < 6 || slice_bits > 20) return -1;
     const PtPerm perm{slice_bits, b1 + b2, perm_mult, perm_inv};
     const PtShard grid{rank, world};
-    const size_t words = (size_t)1 << (slice_bits - 5);
-    const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (CB_THREADS / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4;
-    (void)hipFuncSetAttribute((const void *)k_slice_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_slice_combine, dim3((1u << (b1 + b2)) / world), dim3(CB_THREADS), lds, a.stream, slice_bits, b2, ipl ? ipl->wpb : 0u, ipl ? ipl->buf2 : nullptr,
-                       ipl ? ipl->cnt2 : nullptr, ipl ? ipl->cap2 : 0ull, iovf, iovf_off, ls, dense ? a.filter : nullptr, fresh ? 1 : 0, out ? out->payload : nullptr,
-                       out ? out->cap : 0ull, out ? out->cur : nullptr, out ? out->dir : nullptr, out ? out->n_dest : 1u, perm, grid);
+    // parts of a slice per workgroup (see k_slice_combine; TPC_COMBINE_PARTS = 2 / 4: measurements).  One is the default: on the 62-genome
+    // text at eight ranks the export took 2.74 ms as whole slices and 3.32 ms as quarters (profiles/r06_combine_ab.txt) -- the time is the
+    // chain of dependent memory round trips of a workgroup (count, entries, claim), which does not shrink with the part, and four times
+    // the workgroups four at a time is no gain.
+    const uint32_t n_win = tpc_list_windows(slice_bits);
+    static const int parts_env = [] { const char *e = getenv("TPC_COMBINE_PARTS"); return e ? atoi(e) : 0; }();
+    uint32_t parts = 1;
+    if (parts_env == 1 || parts_env == 2 || parts_env == 4) parts = (uint32_t)parts_env;
+    while (parts > n_win) parts >>= 1;
+    const size_t words = ((size_t)1 << (slice_bits - 5)) / parts;
+    const uint32_t threads = 1024u / parts;
+    const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (threads / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4;
+    const dim3 blocks(((1u << (b1 + b2)) / world) * parts);
+#define TPC_CB_GO(T)                                                                                                                                       \
+    do {                                                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)k_slice_combine<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+        hipLaunchKernelGGL(k_slice_combine<T>, blocks, dim3(T), lds, a.stream, slice_bits, b2, ipl ? ipl->wpb : 0u, ipl ? ipl->buf2 : nullptr,              \
+                           ipl ? ipl->cnt2 : nullptr, ipl ? ipl->cap2 : 0ull, iovf, iovf_off, ls, dense ? a.filter : nullptr, fresh ? 1 : 0,               \
+                           out ? out->payload : nullptr, out ? out->cap : 0ull, out ? out->cur : nullptr, out ? out->dir : nullptr, out ? out->n_dest : 1u, perm, grid); \
+    } while (0)
+    if (parts == 4) TPC_CB_GO(256); else if (parts == 2) TPC_CB_GO(512); else TPC_CB_GO(1024);
+#undef TPC_CB_GO
     return 0;
 }

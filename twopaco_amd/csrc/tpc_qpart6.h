@@ -105,6 +105,8 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
     const bool wide = (words & 3u) == 0;
+    TpcListReader<PT_APPLY_THREADS> lists;  // (their first loads go out before the slice is zeroed)
+    if (ls.n_src) lists.begin(ls, b1, b2, log_nb2, blockIdx.x, slice_bits);
     // ---- apply
     if (fresh) {
         if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
@@ -134,9 +136,7 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
             atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
         }
     }
-    if (ls.n_src) {
-        tpc_lists_apply<PT_APPLY_THREADS>(ls, b1, b2, log_nb2, blockIdx.x, slice, slice_bits);
-    }
+    if (ls.n_src) lists.finish(ls, slice);
     const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
     if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
     __syncthreads();

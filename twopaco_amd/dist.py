@@ -145,6 +145,31 @@ def sharded_step(backend, dist, L, abundance=(1 << 64) - 1, fetch=False):
     return st
 
 
+_SERIAL = [False, None]
+
+
+def _serial_lock():
+    """File descriptor of the lock the ranks of an emulated run take turns with (TPC_DIST_SERIALIZE), or None."""
+    if not _SERIAL[0]:
+        _SERIAL[0] = True
+        path = os.environ.get("TPC_DIST_SERIALIZE")
+        if path:
+            _SERIAL[1] = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+    return _SERIAL[1]
+
+
+LINK_GBS = 50.0  # usable GB/s per xGMI link and direction the link model assumes (7 links of 76.8 GB/s peak per direction on an MI355X; RCCL send / recv)
+
+
+def link_model(world, compute_ms, recv_bytes_per_peer_phases):
+    """Predicted milliseconds per step of a rank: its own library calls (measured: alone on a GPU) plus, for every exchange phase, the
+    bytes it receives from ONE peer over that peer's link at LINK_GBS (the W - 1 links of a fully connected node work side by side;
+    nothing is assumed to overlap with compute).  recv_bytes_per_peer_phases: {phase: bytes from the busiest peer}."""
+    wire = {k: v / (LINK_GBS * 1e9) * 1e3 for k, v in recv_bytes_per_peer_phases.items()} if world > 1 else {}
+    return {"compute_ms": compute_ms, "wire_ms": wire, "wire_ms_total": sum(wire.values()), "predicted_ms": compute_ms + sum(wire.values()),
+            "link_GBs_assumed": LINK_GBS, "what": "measured library-call time of the slowest rank (ranks taking turns on the device) + modelled wire time; no overlap assumed"}
+
+
 class _ListOverflow(RuntimeError):
     """An overflow list of a sharded pass overflowed (seen by every rank in the same all-reduce): AddressSharded re-plans once."""
 
@@ -478,6 +503,7 @@ class AddressSharded:
         self._bufs = {}
         self.stats = {}
         self.t = {}   # seconds per phase, accumulated (host clock; every phase ends synchronised)
+        self.call_ms = {}  # milliseconds per library call, accumulated (_try)
 
     def _tick(self, name, t0):
         self.t[name] = self.t.get(name, 0.0) + (time.perf_counter() - t0)
@@ -490,11 +516,29 @@ class AddressSharded:
         EVERY rank raises DistAbort there with the phase's name (multigpu.cpp does the same behind its rank barrier)."""
         if self.comm.rc:
             return default
+        # every library call's own wall time (the calls end synchronised): call_ms[name], what the link model adds the wire to.  With
+        # TPC_DIST_SERIALIZE=<lock file> the ranks of an emulated run (several ranks on ONE device) take turns on the device, so that
+        # a call's time is that of a rank alone on its GPU.
         try:
-            return fn(*args)
+            return self._timed(fn, *args)
         except Exception as e:  # noqa: BLE001 -- whatever it is, the peers must hear of it
             self.comm.fail(e)
             return default
+
+    def _timed(self, fn, *args):
+        """fn(*args) with its wall time added to call_ms[fn's name]; under TPC_DIST_SERIALIZE while holding the ranks' device lock."""
+        lock = _serial_lock()
+        if lock is not None:
+            import fcntl
+            fcntl.flock(lock, fcntl.LOCK_EX)
+        t0 = time.perf_counter()
+        try:
+            return fn(*args)
+        finally:
+            name = getattr(fn, "__name__", "call")
+            self.call_ms[name] = self.call_ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            if lock is not None:
+                fcntl.flock(lock, fcntl.LOCK_UN)
 
     def _buf(self, name, nbytes):
         b = self._bufs.get(name)
@@ -828,9 +872,10 @@ class AddressSharded:
             counts = self._try(ctx.shard_route, owner.data_ptr(), n, perm.data_ptr(), W, default=zeros)
             send = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
             self._try(ctx.shard_permute_rows, rec.data_ptr(), perm.data_ptr(), n, rw, send.data_ptr())
-            recv, _ = self.comm.a2a_var(send[:n * rw].contiguous(), [c * rw for c in counts])
+            recv, rcl = self.comm.a2a_var(send[:n * rw].contiguous(), [c * rw for c in counts])
             recv = recv.contiguous()
             self.comm.sync()
+            self.stats["pass2_recv_bytes_busiest_peer"] = 8 * max([c for r, c in enumerate(rcl) if r != self.rank] or [0])
             st = self._try(ctx.pass2_filter_records, recv.data_ptr(), recv.numel() // rw, abundance, default=dict(none))
             st["marks"] = n
             self.stats["pass2_positions_received"] = recv.numel() // rw
@@ -884,6 +929,9 @@ class Combined(AddressSharded):
         self._try(ctx.filter_reset)
         self._try(ctx.pass1_insert, lo, hi, False)
         t0 = self._tick("insert_local", t0)
+        if W == 1:  # one rank: the one-GPU pass as it is (the insert waits in its regions for the query's lookup)
+            self.stats["combine"].update(mode="one rank: nothing to exchange", exchange_bytes_received=0)
+            return {"mode": "one rank"}
         info = self._try(ctx.combine_info, W, default=None) or {"sparse": 0}
         # every rank must take the same road: sparse lists only if every rank's insert stayed in its regions
         dense = comm.max_ints([0 if info["sparse"] else 1])[0] == 1 or self.mode == "dense"
@@ -938,6 +986,7 @@ class Combined(AddressSharded):
             comm.sync()
             self._try(ctx.combine_import, W * W, W, allp.data_ptr(), base, alld.data_ptr(), spd * n_win)
             st["exchange_bytes_received"] = 16 * (sum(sum(r) for r in allu) - sum(units)) + 8 * (W - 1) * dir64.numel()
+            st["recv_bytes_busiest_peer"] = {"all-gather of the exports": 16 * max(sum(allu[r]) for r in range(W) if r != self.rank or W == 1) + 8 * dir64.numel()}
         else:
             # reduce-scatter: block d and its directory to rank d; the owner merges; all-gather of the merged lists
             comm.phase = "combined insert: reduce-scatter of the exports"
@@ -968,6 +1017,9 @@ class Combined(AddressSharded):
             self._try(ctx.combine_import, W, W, allp.data_ptr(), [r * most for r in range(W)], alld.data_ptr(), spd * n_win)
             st["merged_units"] = allm
             st["exchange_bytes_received"] = 16 * (o - units[self.rank]) + 16 * (sum(allm) - mu) + 8 * (W - 1) * (rdir.numel() // W + mdir.numel() // 8)
+            others = [r for r in range(W) if r != self.rank] or [self.rank]
+            st["recv_bytes_busiest_peer"] = {"reduce-scatter of the exports": 16 * max(allu[r][self.rank] for r in others) + 8 * (rdir.numel() // W),
+                                             "all-gather of the merged lists": 16 * max(allm[r] for r in others) + mdir.numel()}
         self._tick("insert_exchange", t0)
         return {"mode": st["mode"]}
 
@@ -990,6 +1042,7 @@ class Combined(AddressSharded):
         comm.sync()
         self._try(ctx.filter_copy_in, 0, words, allm.data_ptr())
         self.stats["combine"]["exchange_bytes_received"] = 2 * (W - 1) * chunk * 4
+        self.stats["combine"]["recv_bytes_busiest_peer"] = {"dense reduce-scatter": chunk * 4, "dense all-gather": chunk * 4}
 
     # ---- query: entirely local
     def query(self, lo=0, hi=None, union=True):
@@ -1039,8 +1092,8 @@ def address_sharded_step(sharded, abundance=(1 << 64) - 1, fetch=False, sharded_
         sharded._keys_backend.union_keys_on_device(sharded.comm.dist)
     else:
         st = sharded.round(0, None, abundance)
-    st["junctions"] = ctx.junctions_finalize()
-    st["n_marked"], st["n_valid"] = ctx.emit()
+    st["junctions"] = sharded._timed(ctx.junctions_finalize)
+    st["n_marked"], st["n_valid"] = sharded._timed(ctx.emit)
     if not sharded_pass2:
         st["marks"] = st["n_marked"]
     if fetch:
@@ -1143,6 +1196,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     also_ranges = address and getattr(args, "decomposition", "auto") == "auto"  # both are timed at every N; the line's value is the address-sharded filter's, the ranges keep their record under "ranges"
     ctx = ctx_r = None
     sharded2 = False
+    combined = False
     recs = None
     pass2 = "replicated"
     steps = {}
@@ -1173,13 +1227,19 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         if pass2 not in ("records", "positions", "replicated"):
             raise RuntimeError("TPC_PASS2 must be records, positions or replicated")
         sharded2 = pass2 != "replicated"
+        # how the ranks share the filter (the rule of host/vertexenumerator.cpp): combined while the whole filter fits a GPU with room to
+        # spare and the passes have two levels -- every rank keeps the filter, only the set bits of every slice travel (Combined) -- else
+        # (or TPC_MULTIGPU=entries) every hash hit of both passes is routed to the owner of its slice (AddressSharded)
+        combined = address and p["L"] <= 38 and os.environ.get("TPC_MULTIGPU", os.environ.get("TWOPACO_MULTIGPU", "combined")) != "entries"
+        if combined:
+            ctx.set_option("replicate_filter", 1)
         if address and pass2 == "records":
             ctx.set_option("text_window", 1)
             ctx.shard_config(rank, world)  # before the upload: the window depends on it
         ctx.set_params(p["k"], p["L"], p["q"], capi.seed_table(p["q"], p["L"], seed=20240229))
         ctx.seq_upload(text)
         if address:
-            sh = AddressSharded(ctx, dist, torch.device("cuda", device), configure=pass2 != "records")
+            sh = (Combined if combined else AddressSharded)(ctx, dist, torch.device("cuda", device), configure=pass2 != "records")
             steps["address"] = lambda: address_sharded_step(sh, sharded_pass2=pass2 if sharded2 else False)
         if not address:
             be = HipBackend(ctx)
@@ -1216,6 +1276,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         kms = {n: 0.0 for n in names}
         if which == "address":
             sh.t.clear()
+            sh.call_ms.clear()
             sh.stats["region_bytes_sent"] = 0
             sh.stats["overflow_entries"] = 0
             moved0 = sh.comm.bytes_moved
@@ -1249,6 +1310,17 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
             r["exchange"] = "packed to exact sizes (tpc_shard_pack)" if sh.compact else "equal blocks of tight regions, own block in place"
 
             r["survivors"] = sh.stats.get("survivors")
+            # the link model's inputs: this rank's library-call time (alone on its device when the ranks take turns: TPC_DIST_SERIALIZE)
+            # and, per exchange phase, the bytes from its busiest peer; the slowest rank's figures make the line
+            r["call_ms"] = {k: v / args.steps for k, v in sh.call_ms.items()}
+            r["combine"] = sh.stats.get("combine")
+            peer = dict((sh.stats.get("combine") or {}).get("recv_bytes_busiest_peer") or {})
+            if sh.stats.get("pass2_recv_bytes_busiest_peer"):
+                peer["second pass: records to the key owners"] = sh.stats["pass2_recv_bytes_busiest_peer"]
+            mine = torch.tensor([sum(r["call_ms"].values())] + [float(v) for v in peer.values()], dtype=torch.float64, device=dev)
+            guarded("bench: max of the ranks' model inputs", dist.all_reduce, mine, op=dist.ReduceOp.MAX)
+            vals = mine.cpu().tolist()
+            r["model"] = link_model(world, vals[0], dict(zip(peer.keys(), vals[1:])))
         return r
 
     head = timed("address" if address else "ranges")
@@ -1296,7 +1368,11 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
     # PMC profile exists for the sharded path, so `traffic` is null and `frac` is a DESIGN-byte fraction -- `frac_kind` says so.
     fb = (1 << p["L"]) // 8
     ph = head.get("phase_ms") or {}
-    if address:
+    if address and combined:  # a rank's own first-pass library calls (the exchanges are not in them); every rank writes the whole filter once
+        cm = head.get("call_ms") or {}
+        qms = sum(cm.get(k, 0.0) for k in ("pass1_insert", "combine_export", "combine_merge", "pass1_query"))
+        design = (2 * 0.375 + p["q"] * 16 + 6 * 32) * n_kmers / world + fb
+    elif address:
         qms = sum(ph.get(k, 0.0) for k in ("insert_hash", "insert_apply", "query_hash", "query_apply", "query_verify_finish"))
         design = (2 * 0.375 + p["q"] * 16 + 6 * 32) * n_kmers / world + fb / world
     else:
@@ -1310,7 +1386,8 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload_desc,
                    "kmers": n_kmers, "filter_bytes": fb, "decomposition": "address" if address else "ranges",
-                   "parallelism": ("filter sharded by bit address over %d GPUs; all_to_all of the level-1 regions per pass, per-function survivor probes; " % world) +
+                   "parallelism": (("filter replicated over %d GPUs through set-bit lists combined by bit-address owner (every rank inserts its chunk of the text, only the distinct set bits of every slice travel, the query is local); " % world) if address and combined else
+                                   ("filter sharded by bit address over %d GPUs; all_to_all of the level-1 regions per pass, per-function survivor probes; " % world)) +
                                   ({"records": "text sharded too; exact-filter table sharded by key hash ((key, prev|next) records to the key's owner), all_gather of the junction keys",
                                     "positions": "exact-filter table sharded by key hash (8 B per marked position to the key's owner), all_gather of the junction keys",
                                     "replicated": "OR all-reduce of the candidate mask, replicated second pass"}[pass2] if address else "")
@@ -1321,6 +1398,10 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
                      "peak": 8000.0, "unit": "GB/s", "frac": design / (qms * 1e-3) / 1e9 / 8000.0, "frac_kind": "design bytes (no counter profile of the sharded path)",
                      "traffic": None, "algorithmic_bytes_per_launch": design, "launch_ms": qms} if ctx is not None else None,
         "exchange_bytes_rank0_per_step": head.get("exchange_bytes"),
+        "multi_gpu_exchange": (head.get("combine") or {}).get("mode") if address else None,
+        "combine_rank0": head.get("combine"),
+        "call_ms_rank0_per_step": head.get("call_ms"),
+        "model": head.get("model"),
         "region_bytes_sent_rank0_per_step": head.get("region_bytes_sent"),
         "all_to_all_GBs_rank0": head.get("all_to_all_GBs"),
         "region_exchange": head.get("exchange"),
@@ -1366,7 +1447,7 @@ def _bench_main(args, rank, world, local_rank, backend_factory=None, golden=None
             sent = out["e2e"].get("region_bytes_sent_rank0")
             out["cxx_host"] = {"what": "twopaco --gpus %d (C++ host, one thread per GPU, RCCL send/recv groups), its own TWOPACO_TIMING figures, median run" % world,
                                "rounds_ms": rounds_ms, "kmers_per_sec": (n_kmers / (rounds_ms * 1e-3)) if rounds_ms else None,
-                               "sharded_first_pass_ms_rank0": ph or None, "region_bytes_sent_rank0": sent,
+                               "sharded_first_pass_ms_rank0": ph or None, "region_bytes_sent_rank0": sent, "combined_exchange_rank0": out["e2e"].get("combined_exchange_rank0"),
                                "all_to_all_GBs_rank0": (sent / (a2a_ms * 1e-3) / 1e9) if sent and a2a_ms > 0 else None,
                                "runs": out["e2e"].get("runs")}
         out["e2e_failed"] = "error" in out["e2e"]

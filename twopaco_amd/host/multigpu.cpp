@@ -806,7 +806,8 @@ namespace TwoPaCo
 			uint64_t marks = 0;
 			LibCheck(r.ctx, tpc_pass1_query(r.ctx, lo, hi, &marks), "pass1_query");
 			r.Phase("query (local)");
-			if (r.phaseOn) std::fprintf(stderr, "[timing]     combined exchange: %s, %.1f MB received by rank 0\n", r.combineMode.c_str(), double(r.combineBytesReceived) / 1e6);
+			if (r.phaseOn) std::fprintf(stderr, "[timing]     combined exchange: %s, %.1f MB received by rank 0 (%llu bytes)\n", r.combineMode.c_str(), double(r.combineBytesReceived) / 1e6,
+				(unsigned long long)r.combineBytesReceived);
 			r.PhasePrint("combined first pass");
 		}
 	}
