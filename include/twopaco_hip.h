@@ -109,6 +109,11 @@ int tpc_pass1_split_hist(tpc_ctx *ctx, const uint64_t *rec_start, const uint64_t
 /* First-pass query, CandidateCheckingWorker (VE.h:586-704): sets this round's candidate
  * mask (bit g) and returns the number of marks ("Candidate marks count", VE.h:387). */
 int tpc_pass1_query(tpc_ctx *ctx, uint64_t lo, uint64_t hi, uint64_t *n_marks);
+/* The part of the query that does not read the filter -- level-1 hash and level-2 binning of the first tile batch (the reference's
+ * CandidateCheckingWorker computes its hashes before it touches the filter too, VE.h:633-640) -- enqueued on the context's stream; the
+ * call returns without waiting.  The tpc_pass1_query of the same range that follows continues from there.  Between the two the caller
+ * may move the round's insert between ranks (tpc_combine_merge / _import): the lists travel while the probes are being binned.  Optional. */
+int tpc_pass1_query_begin(tpc_ctx *ctx, uint64_t lo, uint64_t hi);
 
 /* Second-pass exact filter over this round's marks, CandidateFinalFilteringWorker
  * (VE.h:708-829) + TrueBifurcations (VE.h:1228-1256): appends the round's junction keys,

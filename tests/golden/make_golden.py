@@ -243,7 +243,10 @@ def main():
                                     # genome (round 5: address skew, hot exact-filter keys, the stub / separator path at full size)
                                     # -t 1: the stub ids of sequence ends come from a shared counter in the order the worker threads reach them
                                     # (VE.h:945-947) -- with 10 149 records the bytes of a multi-threaded run depend on the scheduling
-                                    ("m2r_small", "m2r", 0.02, 26, 1), ("m2r_full", "m2r", 1.0, None, 1)]:
+                                    ("m2r_small", "m2r", 0.02, 26, 1), ("m2r_full", "m2r", 1.0, None, 1),
+                                    # m2r2 = m2r + minisatellite tracts (units of 7..60 bp over 200..2000 bp): periodic windows beyond the periods the
+                                    # hash kernels skip (round 6)
+                                    ("m2r2_small", "m2r2", 0.02, 26, 1), ("m2r2_full", "m2r2", 1.0, None, 1)]:
         if only is not None and name not in only:
             continue
 

@@ -16,6 +16,23 @@ def test_two_ranks_on_gpu(name, tmp_path):
     check_against_single(case, files, run_world(case, files, 2, tmp_path, use_gpu=True))
 
 
+_SINGLE = {}
+
+
+def _single_gpu_line(base):
+    """The plain single-GPU bench line of the same workload (run once per session: the four decompositions compare with one reference)."""
+    import json
+    import os
+    import subprocess
+    key = tuple(base)
+    if key not in _SINGLE:
+        env1 = {k: v for k, v in os.environ.items() if k != "TPC_FORCE_DIST"}
+        out1 = subprocess.run(list(base), env=env1, capture_output=True, text=True, timeout=600)
+        assert out1.returncode == 0, out1.stderr[-2000:]
+        _SINGLE[key] = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
+    return _SINGLE[key]
+
+
 @pytest.mark.parametrize("decomposition", ["ranges", "address", "address+positions", "address+replicated"])
 def test_bench_single_rank_over_rccl(decomposition):
     """bench.py's distributed path with the real backend ("nccl" = RCCL) and one rank: the collectives
@@ -26,7 +43,7 @@ def test_bench_single_rank_over_rccl(decomposition):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "m1", "--scale", "0.1",
-            "--no-cpu-baseline"]
+            "--no-cpu-baseline", "--e2e-runs", "0"]  # (the end-to-end leg has its own tests: test_gpu_e2e / the whole-line tests below)
     env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     env.pop("TPC_DIST_BACKEND", None)
     if "+" in decomposition:  # the other two forms of the second pass (default: key-sharded, records, text windows)
@@ -34,10 +51,7 @@ def test_bench_single_rank_over_rccl(decomposition):
     out = subprocess.run(base + ["--decomposition", decomposition], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     dist_line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    env1 = {k: v for k, v in os.environ.items() if k != "TPC_FORCE_DIST"}
-    out1 = subprocess.run(base, env=env1, capture_output=True, text=True, timeout=600)
-    assert out1.returncode == 0, out1.stderr[-2000:]
-    single = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
+    single = _single_gpu_line(base)
     assert dist_line["result"]["junctions"] == single["result"]["junctions"] > 0
     assert dist_line["result"]["junction_occurrences"] == single["result"]["junction_occurrences"]
     assert dist_line["result"]["candidate_marks"] == single["result"]["candidate_marks"]
@@ -123,7 +137,9 @@ def test_bench_combined_exchange_whole_line(ranks, tmp_path):
     assert ("all-gather of the exports" if ranks == 2 else "reduce-scatter") in line["multi_gpu_exchange"]
     assert line["exchange_bytes_rank0_per_step"] > 0 and line["combine_rank0"]["export_bytes"] > 0
     m = line["model"]
-    assert m["compute_ms"] > 0 and m["wire_ms_total"] > 0 and abs(m["predicted_ms"] - m["compute_ms"] - m["wire_ms_total"]) < 1e-6
+    assert m["compute_ms"] > 0 and m["wire_ms_total"] > 0 and abs(m["predicted_ms_no_overlap"] - m["compute_ms"] - m["wire_ms_total"]) < 1e-6
+    assert m["predicted_ms"] <= m["predicted_ms_no_overlap"] and m["query_hash_and_binning_ms_under_the_exchange"] > 0
+    assert "pass1_query_begin" in line["call_ms_rank0_per_step"]
     assert {"pass1_insert", "combine_export", "pass1_query"} <= set(line["call_ms_rank0_per_step"])
     assert line["e2e_failed"] is False, line["e2e"]
     cx = line["cxx_host"]
@@ -143,8 +159,8 @@ def test_bench_address_path_full_size_over_rccl():
     case = CASES["m2_full"]
     env = dict(os.environ, TPC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", TPC_MULTIGPU="entries")
     env.pop("TPC_DIST_BACKEND", None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--decomposition", "address"],
-                         env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--decomposition", "address",
+                          "--no-cpu-baseline", "--e2e-runs", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["backend"] == "rccl" and line["config"]["decomposition"] == "address"

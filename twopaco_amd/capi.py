@@ -26,7 +26,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
                "tpc_junction_keys_export", "tpc_junction_keys_import", "tpc_warmup", "tpc_preload", "tpc_reserve", "tpc_shard_chunk", "tpc_emit_stream_partial", "tpc_emit_stream_part",
                "tpc_shard_plan_both", "tpc_shard_hash_begin", "tpc_shard_hash_end", "tpc_shard_apply_inplace", "tpc_shard_survivors_home", "tpc_shard_verify_send", "tpc_shard_finish", "tpc_shard_verify_local", "tpc_shard_periodic_copy",
-               "tpc_combine_info", "tpc_combine_export", "tpc_combine_merge", "tpc_combine_import", "tpc_combine_choose", "tpc_filter_copy_out", "tpc_filter_copy_in"]
+               "tpc_pass1_query_begin", "tpc_combine_info", "tpc_combine_export", "tpc_combine_merge", "tpc_combine_import", "tpc_combine_choose", "tpc_filter_copy_out", "tpc_filter_copy_in"]
 
 _hip = None
 _host = None
@@ -112,6 +112,7 @@ def hip():
         L.tpc_shard_finish.argtypes = [p, p, u64, ci, p, p, p]
         L.tpc_shard_verify_local.argtypes = [p]
         L.tpc_shard_periodic_copy.argtypes = [p]
+        L.tpc_pass1_query_begin.argtypes = [p, u64, u64]
         L.tpc_combine_info.argtypes = [p, u32, p]
         L.tpc_combine_export.argtypes = [p, u32, p, u64, p, p]
         L.tpc_combine_merge.argtypes = [p, u32, p, p, p, p, u64, p, p]
@@ -311,6 +312,9 @@ class Context:
         n = ctypes.c_uint64(0)
         self._ck(hip().tpc_pass1_query(self._h, lo, (1 << self.L) if hi is None else hi, ctypes.byref(n)))
         return n.value
+
+    def pass1_query_begin(self, lo=0, hi=None):
+        self._ck(hip().tpc_pass1_query_begin(self._h, lo, (1 << self.L) if hi is None else hi))
 
     def pass2_filter(self, abundance=(1 << 64) - 1):
         a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)

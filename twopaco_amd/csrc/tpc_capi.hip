@@ -143,6 +143,8 @@ struct tpc_ctx {
     // combined exchange (tpc_combine_*, tpc_combine.hip): option replicate_filter keeps the WHOLE filter on every rank of a sharded
     // context (sh_world > 1); tpc_pass1_insert / tpc_pass1_query then run the one-GPU passes over this rank's chunk of the tiles
     int opt_replicate = 0;
+    bool qb_valid = false;               // tpc_pass1_query_begin enqueued the first batch's hash and binning of the query of [qb_lo, qb_hi]
+    uint64_t qb_lo = 0, qb_hi = 0;
     bool pending_lists = false;          // the pending (deferred) insert lives in imported set-bit lists (cmb_ls), not in level-2 regions
     TpcListSrc cmb_ls;                   // ... these (payload and directories are the caller's device buffers)
     TpcPartPlan cmb_geo;                 // slice geometry of the last deferred insert (tpc_combine_export / _merge / _import agree on it)
@@ -966,12 +968,27 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     return 0;
 }
 
-int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
+namespace {
+int pass1_query_impl(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks, bool begin_only);
+}
+
+int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks) { return pass1_query_impl(c, lo, hi, n_marks, false); }
+
+int tpc_pass1_query_begin(tpc_ctx *c, uint64_t lo, uint64_t hi) { return pass1_query_impl(c, lo, hi, nullptr, true); }
+
+namespace {
+
+// begin_only: the part of the query that does not need the filter -- the level-1 hash and the level-2 binning of the FIRST tile batch --
+// is enqueued and the call returns without waiting (tpc_pass1_query_begin); the tpc_pass1_query of the same range that follows picks
+// up there.  The combined multi-GPU exchange runs between the two: the lists travel while the probes are being binned.
+int pass1_query_impl(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks, bool begin_only)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
     if (c->sh_world > 1 && !c->opt_replicate) return fail(c, -1, "the filter is sharded: use tpc_shard_hash / tpc_shard_apply");
     HIPCHK(c, hipSetDevice(c->device));
     const bool gated = !(lo == 0 && hi >= c->P.lmask);
+    const bool begun = !begin_only && c->qb_valid && c->qb_lo == lo && c->qb_hi == hi;  // the first batch's hash and binning are on the stream already
+    c->qb_valid = false;
     c->marks_valid = false; c->rmask_sums_valid = false;
     ensure_periodic(c);
     TpcQPlan pl;
@@ -980,14 +997,15 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     bool part = plan_query(c, lo, hi, gated, pl);
     if (replicated(c)) {
         if (!part) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned query (q=%d, L=%d, slice_bits=%d)", c->P.q, c->P.L, c->opt_slice_bits);
-        HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));  // the hash kernel rewrites the words of this rank's tiles only
+        if (!begun) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));  // the hash kernel rewrites the words of this rank's tiles only
     }
+    if (begin_only && !part) return 0;  // (the direct kernel needs the filter from its first instruction: nothing to start early)
     if (part)
         for (int i = 0; i < tpc_ctx::NPBUF && part; i++) if (qpart_need(pl, i)) part = ensure_pbuf(c, i, qpart_need(pl, i));  // not enough HBM: direct path
     // deferred apply of this round's insert: the lookup builds the slices (k_apply_lookup) when the geometry still matches
-    const bool fused = c->pending_apply && !c->pending_shard && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
+    const bool fused = !begin_only && c->pending_apply && !c->pending_shard && part && pl.b3 == 0 && pl.slice_bits == c->pending_pl.slice_bits &&
                        pl.b1 == c->pending_pl.b1 && pl.b2 == c->pending_pl.b2 && (pl.fmt == 6 || c->pending_pl.fmt2 == 0);
-    if (!fused) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
+    if (!fused && !begin_only) { int rc0 = materialize_reset(c); if (rc0) return rc0; }
     if (part) {
         pl.buf1 = (uint64_t *)c->pbuf[0]; pl.cnt1 = (uint32_t *)c->pbuf[1]; pl.buf2 = (uint64_t *)c->pbuf[2]; pl.cnt2 = (uint32_t *)c->pbuf[3];
         pl.ovf = (uint64_t *)c->pbuf[4]; pl.ovf_cur = (unsigned long long *)c->pbuf[5];
@@ -1014,14 +1032,27 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                 pl.tile0 = t0;
                 pl.tile0_global = t0;
                 pl.n_tiles = t0 < t_end ? std::min<uint64_t>(per, t_end - t0) : 0;
-                HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
-                HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
+                const bool presplit = begun && t0 == t_begin;
+                if (!presplit) {
+                    HIPCHK(c, hipMemsetAsync(pl.ovf_cur, 0, 32 * sizeof(unsigned long long), c->stream));
+                    HIPCHK(c, hipMemsetAsync(pl.surv_cur, 0, TPC_SURV_CUR_WORDS * sizeof(unsigned long long), c->stream));
+                }
+                if (begin_only) {  // hash + binning of the first batch, then back to the caller without waiting
+                    TpcQPlan p1 = pl;
+                    p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
+                    if (tpc_launch_query_part_hash(make_launch_periodic(c), p1, c->rmask, lo, hi, gated) || tpc_launch_query_part_split(make_launch(c), p1))
+                        return fail(c, -1, "partitioned query launch failed");
+                    HIPCHK(c, hipGetLastError());
+                    c->qb_valid = true; c->qb_lo = lo; c->qb_hi = hi;
+                    return 0;
+                }
                 if (fused && t0 == t_begin) {  // the first batch's lookup kernel also builds and writes the filter slices; later batches read them
                     TpcQPlan p1 = pl;
                     p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
+                    p1.presplit = presplit;
                     c->pending_apply = false;
                     c->stat_fused++;
-                    if (tpc_launch_query_part_hash(make_launch_periodic(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
+                    if (!presplit && tpc_launch_query_part_hash(make_launch_periodic(c), p1, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                     {
                         Timed tf(c, TPC_K_FUSED);
                         TpcLaunch af = make_launch(c);
@@ -1032,6 +1063,11 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
                                                                c->pending_novf && !lists ? c->iovf_off : nullptr, lists ? &c->cmb_ls : nullptr)) return fail(c, -1, "fused lookup launch failed");
                     }
                     if (tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "verify launch failed");
+                } else if (presplit) {  // (not fused after all -- e.g. the dense form of the exchange: lookup against the filter, verification)
+                    TpcQPlan p1 = pl;
+                    p1.rbuf1 = p1.buf1; p1.rcnt1 = p1.cnt1;
+                    p1.presplit = true;
+                    if (tpc_launch_query_part_lookup(make_launch(c), p1) || tpc_launch_query_verify(make_launch(c), p1, c->rmask)) return fail(c, -1, "partitioned query launch failed");
                 } else
                 if (tpc_launch_query_partitioned(make_launch_periodic(c), pl, c->rmask, lo, hi, gated)) return fail(c, -1, "partitioned query launch failed");
                 HIPCHK(c, hipMemcpyAsync(f1, pl.ovf_cur, sizeof f1, hipMemcpyDeviceToHost, c->stream));
@@ -1149,6 +1185,8 @@ int tpc_pass1_query(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks)
     if (n_marks) *n_marks = n;
     return 0;
 }
+
+}  // namespace
 
 namespace {
 int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size,
@@ -2157,7 +2195,8 @@ int tpc_combine_info(tpc_ctx *c, uint32_t n_dest, uint64_t *info)
             e = std::min<uint64_t>(e, (uint64_t)1 << g.slice_bits);
             units[b1 & (n_dest - 1)] += (e + 7) / 8 + n_win;
         }
-    info[0] = 1; info[1] = n_slices; info[2] = n_win; info[3] = *std::max_element(units.begin(), units.end());
+    // (+ the chunks the persistent export claims per workgroup and destination: tpc_combine.hip:CB_CHUNK = 256 units, at most 1024 workgroups)
+    info[0] = 1; info[1] = n_slices; info[2] = n_win; info[3] = *std::max_element(units.begin(), units.end()) + 1024 * 256;
     info[4] = (uint64_t)g.slice_bits; info[5] = (uint64_t)g.b1; info[6] = (uint64_t)g.b2; info[7] = (uint64_t)(n_slices / n_dest) * n_win;
     return 0;
 }

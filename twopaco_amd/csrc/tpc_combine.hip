@@ -18,6 +18,7 @@
 // lookup (tpc_qpart6.h:k_apply_lookup6) builds every slice from the imported lists, so no probe and no survivor ever crosses a link.
 #include "tpc_internal.h"
 #include "tpc_lists.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -133,6 +134,150 @@ k_slice_combine(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__re
     // (the entries behind a list up to its unit's end are never read: readers stop at the count)
 }
 
+// The export of a rank's own insert as ONE LONG-LIVED workgroup per CU (round 6).  k_slice_combine spends a slice's ~10 us waiting for
+// memory three times in a row -- the region's count, its entries, the claim of the output space -- with nothing else on the CU (128 KB of
+// LDS: one workgroup): 2.7 ms for the 65536 slices of a 2^36-bit filter whatever the entries.  Here a workgroup walks the slices
+// blockIdx, blockIdx + grid, ...: the entries of the NEXT slice's first region are in flight (PtStream) while this slice is counted,
+// scanned and listed, that region's count was loaded an iteration before; the output space comes from a chunk of CB_CHUNK units the
+// workgroup claimed for the destination earlier (one global atomic per ~dozen slices; the directory says where every list went, so the
+// unused tail of a chunk is just a few KB that travel for nothing); and listing a word zeroes it for the next slice.
+constexpr uint32_t CB_CHUNK = 256;  // 16-byte units per claim (4 KB)
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+k_slice_export_p(int slice_bits, int log_nb2, uint32_t n_slices, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2,
+                 const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint16_t *__restrict__ out_payload, uint64_t out_cap, unsigned long long *out_cur,
+                 uint64_t *__restrict__ out_dir, uint32_t n_dest, PtPerm perm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t words = 1u << (slice_bits - 5);
+    uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_w = slice + ((words + 3u) & ~3u);   // [THREADS / 64]
+    uint32_t *s_win = s_w + THREADS / 64;           // [CB_MAX_WIN + 1], then [CB_MAX_WIN]
+    uint32_t *s_ctl = s_win + 2 * CB_MAX_WIN + 1;   // [4]
+    uint64_t *s_chunk = reinterpret_cast<uint64_t *>(s_ctl + 4);  // [64] next free unit of this workgroup's chunk per destination, [64] the chunk's end
+    const uint32_t nb2 = 1u << log_nb2, smask = (1u << slice_bits) - 1u;
+    const bool wide = (words & 3u) == 0;
+    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+    else for (uint32_t i = threadIdx.x; i < words; i += THREADS) slice[i] = 0;
+    if (threadIdx.x < 128) s_chunk[threadIdx.x] = 0;
+    const uint32_t n_win = tpc_list_windows(slice_bits), tpw = (uint32_t)THREADS / n_win;
+    const uint32_t win = threadIdx.x / tpw, tl = threadIdx.x % tpw;
+    const uint32_t wwords = min(words, (uint32_t)TPC_LIST_WINDOW_WORDS), wfirst = win * wwords;
+    const uint64_t slices_per_dest = ((uint64_t)1 << perm.F) / n_dest;
+    auto set = [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); };
+    auto region0 = [&](uint32_t sp) { return ((uint64_t)(sp >> log_nb2) * iwpb) * nb2 + (sp & (nb2 - 1u)); };
+    // pipeline registers: the first region of the slice at hand (entries in flight), the count of the one after it
+    PtStream<THREADS, 2, uint32_t> st;
+    uint32_t sp = blockIdx.x;
+    uint32_t c_next = 0;
+    uint64_t o_lo = 0, o_hi = 0;  // this slice's range of the grouped overflow entries (asked for an iteration ahead, like the count)
+    if (iwpb && sp < n_slices) {
+        st.begin(ibuf2 + region0(sp) * icap2, (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[region0(sp)]));
+        if (sp + gridDim.x < n_slices) c_next = icnt2[region0(sp + gridDim.x)];
+    }
+    if (iovf_off && sp < n_slices) { o_lo = iovf_off[sp]; o_hi = iovf_off[sp + 1]; }
+    // 16-byte LDS reads where a window's words divide evenly over its threads (consecutive lanes read consecutive uint4: no bank conflicts)
+    const bool vec4 = wwords % (4u * tpw) == 0;
+    __syncthreads();
+    for (; sp < n_slices; sp += gridDim.x) {
+        const uint32_t b1 = sp >> log_nb2, b2 = sp & (nb2 - 1u);
+        // ---- OR of this slice's entries (the first region's are, or are about to be, in registers)
+        if (iwpb) st.finish(set);
+        for (uint32_t j = 1; j < iwpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
+            pt_stream_region<THREADS, 2>(ibuf2 + r * icap2, (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]), set);
+        }
+        if (iovf_off) for (uint64_t i = o_lo + threadIdx.x; i < o_hi; i += THREADS) set((uint32_t)iovf[i] & smask);
+        // ---- the next slice's first region goes in flight, the count of the one after it is asked for
+        const uint32_t sp1 = sp + gridDim.x, sp2 = sp1 + gridDim.x;
+        if (iwpb && sp1 < n_slices) {
+            st.begin(ibuf2 + region0(sp1) * icap2, (uint32_t)__builtin_amdgcn_readfirstlane((int)c_next));
+            if (sp2 < n_slices) c_next = icnt2[region0(sp2)];
+        }
+        if (iovf_off && sp1 < n_slices) { o_lo = iovf_off[sp1]; o_hi = iovf_off[sp1 + 1]; }
+        __syncthreads();
+        // ---- count, scan, space, list (and zero)
+        uint32_t cnt = 0;
+        if (vec4) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(slice + wfirst);
+            for (uint32_t q = tl; q < wwords / 4u; q += tpw) { const uint4 x = s4[q]; cnt += (uint32_t)(__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w)); }
+        } else
+        for (uint32_t w = tl; w < wwords; w += tpw) cnt += (uint32_t)__popc(slice[wfirst + w]);
+        uint32_t total;
+        const uint32_t off = pt_block_excl_scan<THREADS>(cnt, s_w, total);
+        if (tl == 0) s_win[win] = off;
+        if (threadIdx.x == 0) s_win[n_win] = total;
+        __syncthreads();
+        const uint32_t dest = b1 & (n_dest - 1u);
+        if (threadIdx.x < 64) {  // (first wave) units before every window: a 16-lane prefix sum instead of a serial walk over LDS
+            const uint32_t v = threadIdx.x;
+            uint32_t u = v < n_win ? (s_win[v + 1] - s_win[v] + 7u) >> 3 : 0u, inc = u;
+            for (int o = 1; o < CB_MAX_WIN; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)v >= o) inc += t; }
+            if (v < n_win) s_win[CB_MAX_WIN + 1 + v] = inc - u;
+            const uint32_t units = __shfl(inc, CB_MAX_WIN - 1, 64);  // (lanes behind the last window add nothing)
+          if (v == 0) {
+            uint64_t cur = s_chunk[dest], end = s_chunk[64 + dest];
+            bool ok = true;
+            if (cur + units > end) {  // a new chunk for this destination (what is left of the old one travels unused)
+                const uint64_t claim = units > CB_CHUNK ? units : CB_CHUNK;
+                cur = (uint64_t)atomicAdd(&out_cur[dest], (unsigned long long)claim);
+                end = cur + claim;
+                ok = end <= out_cap;
+                if (!ok) { out_cur[n_dest] = 1ull; end = cur; }
+                s_chunk[64 + dest] = end;
+            }
+            s_chunk[dest] = ok ? cur + units : cur;
+            s_ctl[0] = (uint32_t)cur; s_ctl[1] = (uint32_t)(cur >> 32); s_ctl[2] = ok ? 1u : 0u;
+          }
+        }
+        __syncthreads();
+        const bool ok = s_ctl[2] != 0;
+        const uint64_t base = (uint64_t)s_ctl[0] | ((uint64_t)s_ctl[1] << 32);
+        const uint64_t key = ((uint64_t)(b1 / n_dest) << log_nb2) | b2;
+        uint64_t *dir = out_dir + ((uint64_t)dest * slices_per_dest + key) * n_win;
+        if (threadIdx.x < n_win) {
+            const uint32_t n = s_win[threadIdx.x + 1] - s_win[threadIdx.x];
+            dir[threadIdx.x] = ok ? ((base + s_win[CB_MAX_WIN + 1 + threadIdx.x]) << 24) | (uint64_t)n : 0ull;
+        }
+        uint16_t *dst = out_payload + (((uint64_t)dest * out_cap + base + s_win[CB_MAX_WIN + 1 + win]) << 3) + (off - s_win[win]);
+        if (cnt && vec4) {
+            uint4 *s4 = reinterpret_cast<uint4 *>(slice + wfirst);
+            for (uint32_t q = tl; q < wwords / 4u; q += tpw) {
+                const uint4 x4 = s4[q];
+                if (!(x4.x | x4.y | x4.z | x4.w)) continue;
+                s4[q] = make_uint4(0, 0, 0, 0);  // (the next slice starts from zero)
+                if (!ok) continue;
+                const uint32_t xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    uint32_t x = xs[e];
+                    const uint32_t w = 4u * q + (uint32_t)e;
+                    while (x) {
+                        const uint32_t b = (uint32_t)__ffs((int)x) - 1u;
+                        *dst++ = (uint16_t)((w << 5) | b);
+                        x &= x - 1u;
+                    }
+                }
+            }
+        } else if (cnt) {
+            for (uint32_t w = tl; w < wwords; w += tpw) {
+                uint32_t x = slice[wfirst + w];
+                if (!x) continue;
+                slice[wfirst + w] = 0;  // (the next slice starts from zero)
+                if (ok) {
+                    while (x) {
+                        const uint32_t b = (uint32_t)__ffs((int)x) - 1u;
+                        *dst++ = (uint16_t)((w << 5) | b);
+                        x &= x - 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the slice is zero and s_win / s_ctl are free again
+    }
+}
+
 }  // namespace
 
 // One pass of k_slice_combine.  ipl: the level-2 regions of a deferred insert (or nullptr); iovf / iovf_off: its overflow entries grouped by
@@ -157,6 +302,19 @@ int tpc_launch_slice_combine(const TpcLaunch &a, int slice_bits, int b1, int b2,
     uint32_t parts = 1;
     if (parts_env == 1 || parts_env == 2 || parts_env == 4) parts = (uint32_t)parts_env;
     while (parts > n_win) parts >>= 1;
+    static const bool no_persist = getenv("TPC_COMBINE_NO_PERSIST") != nullptr;  // (measurements: A/B against one workgroup per slice)
+    const uint32_t n_slices = 1u << (b1 + b2);
+    if (out && ipl && !dense && ls.n_src == 0 && world == 1 && parts == 1 && n_slices >= 1024 && !no_persist) {
+        static const int n_cu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+        const size_t words = (size_t)1 << (slice_bits - 5);
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (1024 / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4 + 128 * 8;
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 1024)));  // (two 1024-thread workgroups fill a CU's wave slots)
+        const uint32_t grid_p = std::min<uint32_t>(n_slices, (uint32_t)n_cu * per_cu);
+        (void)hipFuncSetAttribute((const void *)k_slice_export_p<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_slice_export_p<1024>, dim3(grid_p), dim3(1024), lds, a.stream, slice_bits, b2, n_slices, ipl->wpb, ipl->buf2, ipl->cnt2, ipl->cap2, iovf, iovf_off,
+                           out->payload, out->cap, out->cur, out->dir, out->n_dest, perm);
+        return 0;
+    }
     const size_t words = ((size_t)1 << (slice_bits - 5)) / parts;
     const uint32_t threads = 1024u / parts;
     const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (threads / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4;

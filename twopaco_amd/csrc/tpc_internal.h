@@ -143,6 +143,7 @@ struct TpcQPlan {
     // (tpc_binsp.h:PFmt6, tpc_qpart6.h).  buf2 is addressed in 128-byte lines, off2_host counts lines, cnt2 is exact, `bnd` receives
     // n_groups entry counts per level-2 region, and level 1 hashes contiguous blocks of tiles_per_wg tiles per workgroup.
     int fmt = 0;
+    bool presplit = false;  // the level-2 (and 3) binning of this batch has already run (tpc_pass1_query_begin): the lookup launches skip it
     uint32_t tiles_per_wg = 0, n_groups = 0, pb2 = 0;  // pb2: position bits a level-2 entry carries (groups of 2^pb2 positions)
     uint32_t *bnd = nullptr;
 };
@@ -177,6 +178,7 @@ int tpc_launch_region_pack(const TpcLaunch &a, const void *regions, uint64_t cap
 // the owned slices (first-probe survivors into pl.surv; no verification: the caller routes them)
 int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated);
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl);
+int tpc_launch_query_part_split(const TpcLaunch &a, const TpcQPlan &pl);  // the binning levels below the first alone (what the lookup launches start with unless pl.presplit)
 // sharded verification of first-probe survivors (survivor id = edge | position << 3, batch relative)
 int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out);  // 64 sub-lists -> one list (sum of min(surv_cur, surv_cap) entries)
 int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out, int32_t *owner_out,

@@ -1918,12 +1918,26 @@ int tpc_launch_query_part_hash(const TpcLaunch &a, const TpcQPlan &pl, uint32_t 
     return 0;
 }
 
+int tpc_launch_query_part_split(const TpcLaunch &a, const TpcQPlan &pl)
+{   // levels 2 (and 3) of the query's binning alone: the part of the lookup launches below that does not need the filter
+    const PtShard sh{pl.rank, pl.world};
+    QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
+    if (pl.fmt == 6) { launch_qsplit6(a, pl, ovf); return 0; }
+    const int low_bits = pl.slice_bits + pl.b3;
+    launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, low_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2,
+                  ovf, sh, 0u, 0, pl.roff1, (unsigned)(((1u << pl.b1) / pl.world) * pl.wpb), pl.rown1, pl.rowncnt1);
+    if (pl.b3)
+        launch_qsplit(a, false, pl.b1 + pl.b2, pl.b3, pl.slice_bits, pl.loads3, 0u, pl.wpb3, pl.wpb, pl.buf2, pl.cnt2, pl.cap2, pl.buf3, pl.cnt3, pl.off3,
+                      ovf, sh, pl.wpb, pl.b2, nullptr, (unsigned)(((1u << (pl.b1 + pl.b2)) / pl.world) * pl.wpb3));
+    return 0;
+}
+
 int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
 {
     const PtPerm perm{pl.slice_bits, pl.b1 + pl.b2 + pl.b3, pl.perm_mult, pl.perm_inv};
     const PtShard sh{pl.rank, pl.world};
     if (pl.fmt == 6) {
-        launch_qsplit6(a, pl, QOverflow{pl.ovf, pl.ovf_cur, pl.ovf_cap});
+        if (!pl.presplit) launch_qsplit6(a, pl, QOverflow{pl.ovf, pl.ovf_cur, pl.ovf_cap});
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
         (void)hipFuncSetAttribute((const void *)k_q_lookup6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1932,7 +1946,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
         return 0;
     }
-    {
+    if (!pl.presplit) {
         QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
         const int low_bits = pl.slice_bits + pl.b3;  // address bits below this level's bin index
         launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, low_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2,
@@ -1969,7 +1983,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     const PtShard sh{pl.rank, pl.world};
     QOverflow ovf{pl.ovf, pl.ovf_cur, pl.ovf_cap};
     if (pl.fmt == 6) {
-        launch_qsplit6(a, pl, ovf);
+        if (!pl.presplit) launch_qsplit6(a, pl, ovf);
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
 #define TPC_AL6_GO(I3)                                                                                                                                  \
@@ -1987,7 +2001,7 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         return 0;
     }
     if (ipl.fmt2 == 3) return -1;  // the 8-byte lookup reads 32-bit insert entries (the caller plans both passes with the same format switch)
-    {
+    if (!pl.presplit) {
         launch_qsplit(a, pl.world > 1, pl.b1, pl.b2, pl.slice_bits, pl.loads, pl.nwg1, pl.wpb, pl.nwg1 * pl.world, pl.rbuf1, pl.rcnt1, pl.cap1, pl.buf2, pl.cnt2, pl.off2, ovf, sh, 0u, 0,
                       pl.roff1, ((1u << pl.b1) / pl.world) * pl.wpb, pl.rown1, pl.rowncnt1);
     }

@@ -698,6 +698,10 @@ namespace TwoPaCo
 			std::vector<uint64_t> units(W);
 			LibCheck(r.ctx, tpc_combine_export(r.ctx, uint32_t(W), payload, cap, dir, units.data()), "combine_export");
 			r.Phase("insert export");
+			// the query's level-1 hash and level-2 binning do not read the filter: enqueued now, they run while the lists travel
+			// (TWOPACO_COMBINE_OVERLAP=0: not)
+			const char * ov = std::getenv("TWOPACO_COMBINE_OVERLAP");
+			if (!(ov && ov[0] == '0')) LibCheck(r.ctx, tpc_pass1_query_begin(r.ctx, lo, hi), "pass1_query_begin");
 			net.ExchangeHost(r.rank, units.data(), W, all);  // all[s * W + d]: units of rank s for destination d
 			uint64_t total = 0, most = 0, mine = 0;
 			for (int s = 0; s < W; s++)

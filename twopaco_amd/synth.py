@@ -117,6 +117,8 @@ def workload(name, seed=12345, scale=1.0, m2r_features=("families", "tracts", "s
         root = random_genome(n, seed)
         recs = [add_n_runs(substitute(root, 0.001, seed + 4000 + g), 2e-6, seed + 5000 + g) for g in range(7)]
         return recs, dict(k=25, L=38, q=5)
+    if name == "m2r2":  # m2r + minisatellite tracts (period 7..60): the periodic windows k_periodic_build does NOT skip (it stops at 6)
+        return workload("m2r", seed=seed, scale=scale, m2r_features=tuple(m2r_features) + ("minisat",))
     if name == "m2r":
         n = int(5_000_000 * scale)
         root = random_genome(n, seed)
@@ -146,6 +148,16 @@ def workload(name, seed=12345, scale=1.0, m2r_features=("families", "tracts", "s
                 l = min(l, n - a)
                 unit = [[0], [3], [1, 0], [2, 3]][kd]
                 mem[a:a + l] = np.resize(np.array(unit, dtype=np.uint8), l)
+            # (v, m2r2 only) minisatellites: a random unit of 7..60 bp repeated over 200..2000 bp, 24 per genome (scaled)
+            nm = max(1, int(24 * min(1.0, scale * 4))) if "minisat" in m2r_features else 0
+            m_at = _stream(seed + 9700 + g, nm, 24) % np.uint64(max(1, n - 2000))
+            m_len = _stream(seed + 9700 + g, nm, 25) % np.uint64(1801) + np.uint64(200)
+            m_per = _stream(seed + 9700 + g, nm, 26) % np.uint64(54) + np.uint64(7)
+            for j, (a, l, per) in enumerate(zip(m_at, m_len, m_per)):
+                a, l, per = int(a), int(l), int(per)
+                l = min(l, n - a)
+                unit = (_stream(seed + 9800 + g, per, 300 + j) >> np.uint64(62)).astype(np.uint8)
+                mem[a:a + l] = np.resize(unit, l)
             mem = add_n_runs(mem, 2e-5, seed + 3000 + g)
             # (iv) two genomes on the other strand
             if g in (7, 31) and "strands" in m2r_features:
