@@ -62,7 +62,7 @@ def csrc_signature():
 
 
 def golden_case(workload, scale):
-    name = {("m2", 1.0): "m2_full", ("m1", 1.0): "m1_full", ("m2r", 1.0): "m2r_full"}.get((workload, scale))
+    name = {("m2", 1.0): "m2_full", ("m1", 1.0): "m1_full", ("m2r", 1.0): "m2r_full", ("m2r2", 1.0): "m2r2_full"}.get((workload, scale))
     path = os.path.join(ROOT, "tests", "golden", "cases.json")
     if not name or not os.path.exists(path):
         return None
@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="m2", help="m2 (the headline: BASELINE configs[2]), m1, m3, or m2r = m2 with repeat families, low-complexity tracts, "
+    ap.add_argument("--workload", default="m2", help="m2 (the headline: BASELINE configs[2]), m1, m3, m2r2 = m2r + minisatellite tracts (units of 7..60 bp), or m2r = m2 with repeat families, low-complexity tracts, "
                                                       "two reverse-complemented genomes and 50-300 contigs per genome (synth.py)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--test-first", type=int, default=0)

@@ -224,7 +224,7 @@ void tpc_host_free(void *ptr);
  * so none of the routing calls below is needed (reference: CandidateCheckingWorker's remaining probes, vertexenumerator.h:640-660). */
 int tpc_shard_verify_local(tpc_ctx *ctx);
 
-/* Periodic windows under sharding.  A position whose k + 2 characters repeat those of the position 1 .. 6 before it (homopolymers,
+/* Periodic windows under sharding.  A position whose k + 2 characters repeat those of the position 1 .. 63 before it (homopolymers,
  * microsatellites, telomeres) would send the same probes and the same insert as that position (CandidateCheckingWorker / FilterFillerWorker see
  * the same window: vertexenumerator.h:633-674, 1035-1092); the one-GPU passes skip such positions and copy the verdict afterwards.  A host
  * of the sharded calls opts in with tpc_set_option(ctx, "shard_periodic_skip", 1) before tpc_shard_plan -- tpc_shard_hash then skips them

@@ -10,7 +10,7 @@ GOLDEN = os.path.join(HERE, "golden")
 
 
 # full-size synthetic workloads: minutes of work and GiBs of filter each -- dedicated tests, not the parametrised sweeps
-BIG = ("m1_full", "m2_full", "m2_s05_f38", "m3_f38", "m2_x15", "m2r_full")
+BIG = ("m1_full", "m2_full", "m2_s05_f38", "m3_f38", "m2_x15", "m2r_full", "m2r2_full")
 
 
 def golden_cases():

@@ -404,8 +404,10 @@ def _tract_records(rng, n_bases, k):
     """Random sequence with homopolymer / dinucleotide / trinucleotide tracts -- also across the 16384-position tile boundaries, with an N
     inside some, at the very start and end of records -- plus short records."""
     a = rng.integers(0, 4, n_bases).astype(np.uint8)
-    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [2], [3, 3, 0, 2, 2, 2], [0, 1, 2, 3], [1, 1, 0, 3, 2], [0, 1, 2, 3, 0, 2, 1]]  # periods 1..6 copy, 7 does not
-    for t in range(90):
+    units = [[0], [3], [1, 0], [2, 3], [0, 0, 1], [2], [3, 3, 0, 2, 2, 2], [0, 1, 2, 3], [1, 1, 0, 3, 2], [0, 1, 2, 3, 0, 2, 1]]
+    # minisatellite units: periods up to 63 copy (round 6), 64 and 100 do not (every position probes for itself)
+    units += [list(map(int, rng.integers(0, 4, p))) for p in (13, 31, 60, 63, 64, 100)]
+    for t in range(96):
         unit = units[t % len(units)]
         ln = int(rng.integers(k + 3, 900))
         at = int(rng.integers(0, n_bases - ln))
@@ -423,7 +425,7 @@ def _tract_records(rng, n_bases, k):
 
 @pytest.mark.parametrize("k,L,q,budget", [(25, 28, 5, 0), (5, 22, 3, 0), (51, 28, 2, 0), (25, 28, 5, 2 << 20), (31, 34, 5, 0)])
 def test_periodic_windows_are_skipped_and_copied(capi, k, L, q, budget):
-    """Positions whose window repeats the one 1 .. 6 positions earlier (poly-A, (CA)n, microsatellites, the telomere hexamer) send nothing in the partitioned passes: the insert
+    """Positions whose window repeats the one 1 .. 63 positions earlier (poly-A, (CA)n, microsatellites, the telomere hexamer, minisatellite units) send nothing in the partitioned passes: the insert
     drops their out-edge (per_i), the query drops their probes and k_periodic_copy gives them the twin's verdict (tpc_qpartition.hip:
     k_periodic_build).  Filter bitmap, candidate mask and count equal the oracle's -- whole range and two gated half ranges -- and equal the
     run with option periodic_skip = 0; tracts across tile boundaries, with N inside, at record ends, records shorter than k, in batches."""
@@ -868,6 +870,26 @@ def test_m2r_full_size_bytes_equal_reference(capi, tmp_path):
         pytest.skip("golden m2r_full not generated yet (tests/golden/make_golden.py --only m2r_full)")
     case = case[0]
     out = str(tmp_path / "m2r.bin")
+    files = case_files(case, tmp_path)
+    e = capi.Enumerator(files, case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out, seed=case["seed"], threads=64)
+    for f in files:
+        os.unlink(f)
+    assert os.path.getsize(out) == case["bin_bytes"]
+    log = parse_log(e.log)
+    assert log["rounds"] == case["rounds"] and log["true_marks"] == case["true_marks"]
+    assert e.vertices_count() == case["distinct"]
+    assert sha256_file(out) == case["bin_sha256"]
+    os.unlink(out)
+    e.close()
+
+
+def test_m2r2_minisatellites_full_size_bytes_equal_reference(capi, tmp_path):
+    """m2r plus minisatellite tracts -- a random unit of 7..60 bp repeated over 200..2000 bp, 24 per genome: periodic windows BEYOND the
+    periods the hash kernels skipped until round 6 (k_periodic_build stopped at 6: every position of such a tract inserted and probed for
+    itself, + 12 % per k-mer; it now covers periods up to 63) -- against the real reference binary (golden m2r2_full, -t 1):
+    sha256 of de_bruijn.bin and every log counter, the partitioned passes completing on their own."""
+    case = [c for c in CASES if c["name"] == "m2r2_full"][0]
+    out = str(tmp_path / "m2r2.bin")
     files = case_files(case, tmp_path)
     e = capi.Enumerator(files, case["k"], case["L"], q=case["q"], rounds=1, tmpdir=str(tmp_path), out=out, seed=case["seed"], threads=64)
     for f in files:

@@ -29,7 +29,7 @@ struct tpc_ctx {
     uint64_t *bases = nullptr;
     uint32_t *nmask = nullptr;
     uint64_t n_text = 0, n_words = 0, n_words_alloc = 0, n_tiles = 0;
-    // periodic-window masks of the text (tpc_internal.h:TpcLaunch): [5][n_words_alloc] = per_qs, the three bit planes of the copy distance, per_i (at 4 * n_words_alloc); built at the first
+    // periodic-window masks of the text (tpc_internal.h:TpcLaunch): [8][n_words_alloc] = per_qs, the six bit planes of the copy distance, per_i (at 7 * n_words_alloc); built at the first
     // partitioned pass after an upload / a change of k (ensure_periodic), option "periodic_skip" (default on)
     uint32_t *periodic = nullptr;
     bool periodic_valid = false;
@@ -202,13 +202,13 @@ TpcLaunch make_launch_periodic(const tpc_ctx *c)
     TpcLaunch a = make_launch(c);
     if (c->periodic && c->periodic_valid) {
         if (c->periodic_any_q) a.per_qs = c->periodic;
-        if (c->periodic_any_i) a.per_i = c->periodic + 4 * c->n_words_alloc;
+        if (c->periodic_any_i) a.per_i = c->periodic + (size_t)(1 + TPC_PER_PLANES) * c->n_words_alloc;
     }
     return a;
 }
 
 // The periodic-window masks of this text and k, built once: a detection launch first (0.6 ms on the 62-genome text, which has none: nothing
-// is allocated then), the masks themselves only for a text that has such windows: [5][n_words_alloc] = per_qs, the three planes of the
+// is allocated then), the masks themselves only for a text that has such windows: [8][n_words_alloc] = per_qs, the six planes of the
 // copy distance, per_i.  The one-GPU passes use them by default; a sharded context only when its host opted in (option shard_periodic_skip:
 // that host calls tpc_shard_periodic_copy after a round's last batch).  A context that holds a window of the text builds the masks of its
 // window (characters outside count as N: no skipping across its edges).  A failed allocation just leaves the feature off.
@@ -226,10 +226,10 @@ void ensure_periodic(tpc_ctx *c)
     if (hipMemcpyAsync(any, flags, sizeof any, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
     c->periodic_any_q = any[0] != 0; c->periodic_any_i = any[1] != 0;
     if (any[0] || any[1]) {
-        const size_t words = 5 * c->n_words_alloc;
+        const size_t words = (size_t)(2 + TPC_PER_PLANES) * c->n_words_alloc;
         if (!c->periodic && hipMalloc((void **)&c->periodic, words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->periodic = nullptr; return; }
         if (hipMemsetAsync(c->periodic, 0, words * sizeof(uint32_t), c->stream) != hipSuccess) return;
-        tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->n_words_alloc, c->periodic + 4 * c->n_words_alloc, w0, w1, w0 << 5, pos_hi, flags);
+        tpc_launch_periodic_build(a, c->periodic, c->periodic + c->n_words_alloc, c->n_words_alloc, c->periodic + (size_t)(1 + TPC_PER_PLANES) * c->n_words_alloc, w0, w1, w0 << 5, pos_hi, flags);
         if (hipStreamSynchronize(c->stream) != hipSuccess) return;  // (a sharded hash may run on the second stream)
     }
     c->periodic_valid = true;
@@ -936,23 +936,20 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     const uint64_t BINS = 1ull << 24;  // VE.h:471
     c->filter_zero_pending = false;  // the split pass zeroes its scratch filter itself
     c->pending_apply = false;
-    // positions where a (k+1)-mer of 'N'+record+'N' starts, for dispatched records only (VE.h:1177)
-    std::vector<uint32_t> em(c->n_words_alloc, 0u);
-    for (uint32_t r = 0; r < n_rec; r++) {
-        if (rec_len[r] < (uint64_t)c->P.k) continue;
-        const uint64_t a = rec_start[r] - 1, b = rec_start[r] + rec_len[r] - c->P.k;  // inclusive
-        for (uint64_t g = a; g <= b;) {
-            const uint64_t w = g >> 5, o = g & 31;
-            const uint64_t last = std::min<uint64_t>(b, (w << 5) + 31);
-            const uint32_t len = (uint32_t)(last - g + 1);
-            em[w] |= (len == 32 ? ~0u : ((1u << len) - 1u)) << o;
-            g = last + 1;
-        }
-    }
+    // positions where a (k+1)-mer of 'N'+record+'N' starts, for dispatched records only (VE.h:1177): built on the device from the records
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<uint64_t> rs, rl;
+    for (uint32_t r = 0; r < n_rec; r++) if (rec_len[r] >= (uint64_t)c->P.k) { rs.push_back(rec_start[r]); rl.push_back(rec_len[r]); }
     uint32_t *d_em = nullptr, *d_bins = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_em, em.size() * sizeof(uint32_t)));
+    uint64_t *d_rec = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_em, c->n_words_alloc * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&d_bins, BINS * sizeof(uint32_t)));
-    HIPCHK(c, hipMemcpyAsync(d_em, em.data(), em.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMalloc((void **)&d_rec, std::max<size_t>(1, 2 * rs.size()) * sizeof(uint64_t)));
+    if (!rs.empty()) {
+        HIPCHK(c, hipMemcpyAsync(d_rec, rs.data(), rs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_rec + rs.size(), rl.data(), rl.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    }
+    tpc_launch_split_emask(c->stream, d_rec, d_rec + rs.size(), (uint32_t)rs.size(), c->P.k, c->n_words_alloc, d_em);
     HIPCHK(c, hipMemsetAsync(d_bins, 0, BINS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->filter, 0, c->filter_words * sizeof(uint32_t), c->stream));
     const uint64_t real = 1ull << c->P.L;
@@ -965,6 +962,10 @@ int tpc_pass1_split_hist(tpc_ctx *c, const uint64_t *rec_start, const uint64_t *
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(d_em);
     (void)hipFree(d_bins);
+    (void)hipFree(d_rec);
+    if (c->dbg_timing)
+        fprintf(stderr, "[timing]   tpc_pass1_split_hist: %.1f ms in all, the split kernel %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                tpc_kernel_ms(c, TPC_K_SPLIT));
     return 0;
 }
 

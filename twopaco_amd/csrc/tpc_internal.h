@@ -45,12 +45,14 @@ struct TpcLaunch {
     uint32_t *filter;       // device: Bloom filter words
     hipStream_t stream;
     // periodic windows (tpc_qpartition.hip:k_periodic_build; nullptr: off): one bit per position, laid out like nmask.  per_i: the
-    // (k+1)-mer at i equals the one 1..6 positions earlier -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
-    // equal those around i - p -- its candidate verdict is that position's, copied after the verification (p: three bit planes, the copy's business)
+    // (k+1)-mer at i equals the one 1..63 positions earlier -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
+    // equal those around i - p -- its candidate verdict is that position's, copied after the verification (p: six bit planes, the copy's business)
     const uint32_t *per_i = nullptr, *per_qs = nullptr;
     // measurement: recorded around the k_apply_lookup launch of tpc_launch_query_part_fused_lookup when set (TPC_K_LOOKUP)
     hipEvent_t ev_lookup0 = nullptr, ev_lookup1 = nullptr;
 };
+constexpr int TPC_PER_MAXP = 63;    // periods of the periodic windows the first pass skips (tpc_qpartition.hip:k_periodic_build)
+constexpr int TPC_PER_PLANES = 6;   // bit planes of the copy distance; the masks of a text are [2 + TPC_PER_PLANES][n_words_alloc]: per_qs, the planes, per_i
 int tpc_launch_periodic_build(const TpcLaunch &a, uint32_t *qs, uint32_t *qd, uint64_t stride, uint32_t *ins, uint64_t w_begin, uint64_t w_end, uint64_t pos_lo, uint64_t pos_hi,
                               uint32_t *any);
 int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t *qs, const uint32_t *qd, uint64_t stride, uint64_t n_words);
@@ -59,6 +61,7 @@ int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t
 int tpc_launch_insert(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);
 int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks);
 int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size);  // emask is consumed (occurrences still to be counted)
+int tpc_launch_split_emask(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, uint64_t n_words, uint32_t *emask);  // the split pass's positions, from the DISPATCHED records (len >= k) in text order
 int tpc_launch_hash_dump(const TpcLaunch &a, uint64_t g0, uint64_t n, uint64_t *out);
 // more than TPC_KERNEL_MAXQ hash functions (tpc_pass1_anyq.hip): the same three passes with every hash in closed form
 int tpc_launch_insert_anyq(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers);

@@ -188,7 +188,7 @@ k_part_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, cons
              const uint32_t *__restrict__ nmask, uint64_t n_text, uint64_t tile0, uint64_t n_tiles, int pos_per_round, uint64_t lo, uint64_t hi,
              uint32_t *buf1, uint32_t *cnt1, uint64_t cap1, Overflow ovf, PtPerm perm, PtShard sh, unsigned long long *n_kmers, int seed_rows,
              const uint32_t *__restrict__ skip32)
-{   // skip32 (tpc_qpartition.hip:k_periodic_build's per_i, or nullptr): positions whose out-edge repeats the one of the position 1 .. 6
+{   // skip32 (tpc_qpartition.hip:k_periodic_build's per_i, or nullptr): positions whose out-edge repeats the one of the position 1 .. 63
     // before them insert nothing.
     // LHI: L > 32.  Every L-bit value lives in two separate 32-bit registers (LeanV, tpc_lean.h: round 4); for L <= 32 the high
     // halves do not exist.

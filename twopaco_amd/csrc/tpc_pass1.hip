@@ -397,6 +397,40 @@ int tpc_launch_query(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t 
     return 0;
 }
 
+// The positions where a (k+1)-mer of 'N' + record + 'N' starts, dispatched records only (VE.h:1177: at least k bases): bit g for
+// g in [start - 1, start + len - k] of every record.  One thread per mask word; the records are in text order, so the record a
+// word's first position belongs to (or follows) is a binary search away.  (The host used to build this 1-bit-per-position mask in a
+// vector and copy it over: 1.1 GB and ~0.8 s at 9 G positions.)
+__global__ void __launch_bounds__(256) k_split_emask(const uint64_t *__restrict__ rec_start, const uint64_t *__restrict__ rec_len, uint32_t n_rec, int k, uint64_t n_words,
+                                                     uint32_t *__restrict__ emask)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    const uint64_t g0 = w << 5;
+    // the ranges [a_r, b_r] = [start_r - 1, start_r + len_r - k] of the dispatched records are disjoint and ascending: the first one that
+    // ends at or behind this word's first position, then its successors while they begin inside the word
+    uint32_t lo = 0, hi = n_rec;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rec_start[mid] + rec_len[mid] - (uint64_t)k < g0) lo = mid + 1; else hi = mid;
+    }
+    uint32_t m = 0;
+    for (uint32_t r = lo; r < n_rec; r++) {
+        const uint64_t a = rec_start[r] - 1, b = rec_start[r] + rec_len[r] - (uint64_t)k;
+        if (a > g0 + 31) break;
+        const uint64_t x0 = a > g0 ? a : g0, x1 = b < g0 + 31 ? b : g0 + 31;
+        const uint32_t len = (uint32_t)(x1 - x0 + 1);
+        m |= (len == 32 ? ~0u : ((1u << len) - 1u)) << (uint32_t)(x0 - g0);
+    }
+    emask[w] = m;
+}
+
+int tpc_launch_split_emask(hipStream_t s, const uint64_t *d_rec_start, const uint64_t *d_rec_len, uint32_t n_rec, int k, uint64_t n_words, uint32_t *emask)
+{
+    if (n_words) hipLaunchKernelGGL(k_split_emask, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_rec_start, d_rec_len, n_rec, k, n_words, emask);
+    return 0;
+}
+
 int tpc_launch_split(const TpcLaunch &a, uint32_t *emask, uint32_t *bins, uint64_t bin_size)
 {
     if (a.P.q > TPC_KERNEL_MAXQ || tpc_test_force_anyq) return tpc_launch_split_anyq(a, emask, bins, bin_size);

@@ -255,7 +255,7 @@ k_q_hash2(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const u
           uint64_t lo, uint64_t hi, uint64_t *buf1, uint32_t *cnt1, uint64_t cap1, QOverflow ovf, PtPerm perm, PtShard sh,
           uint64_t gbase, uint32_t *__restrict__ rmask, uint32_t tiles_per_wg, const uint16_t *__restrict__ skip16)
 {   // LHI: L > 32; L-bit values on two separate 32-bit registers (LeanV, tpc_lean.h: round 4)
-    // skip16 (k_periodic_build's per_qs, or nullptr): positions whose k + 2 characters repeat those of the position 1 .. 6 before
+    // skip16 (k_periodic_build's per_qs, or nullptr): positions whose k + 2 characters repeat those of the position 1 .. 63 before
     // them send no probes -- k_periodic_copy gives them that position's verdict after the verification
     // tiles_per_wg > 0: workgroup w takes the tiles [w T, (w + 1) T) of the batch instead of w, w + nwg, ...: its regions then hold
     // ascending positions, which the 6-byte level-2 entries rely on (k_q_split<.., P6>)
@@ -1539,57 +1539,80 @@ void launch_qhash(const TpcLaunch &a, const TpcQPlan &pl, bool gated, uint64_t l
 // text, cost the two split kernels 2.4 ms (DESIGN_HISTORY.md, round 5; four attempts to make the overflow path cheap enough failed).  They
 // are removed at the source instead.  Both passes are functions of a window of the text: the first-pass verdict of the vertex at i of the
 // k + 2 characters T[i - 1 .. i + k] (VE.h:633-674), the insert of its out-edge of T[i .. i + k] (VE.h:1035-1092).  When such a window
-// equals the one p positions earlier (p = 1 .. 6: every microsatellite unit, the telomere hexamer), character for character and all of them
+// equals the one p positions earlier (p = 1 .. 63: homopolymers, every microsatellite unit, the telomere hexamer, minisatellite units up to 63 bp), character for character and all of them
 // definite, the position repeats that one's work: its insert is dropped (per_i; OR is idempotent), and its probes are dropped (per_qs) and
-// its mark copied from position i - p once the verification is done (k_periodic_copy; p in three bit planes).  The masks depend on the text
+// its mark copied from position i - p once the verification is done (k_periodic_copy; p in six bit planes).  The masks depend on the text
 // and k alone: built once per upload -- a first launch without outputs only says whether there is anything to skip at all.
 // Thread = one word of 32 positions.  c_p(j) = length of the run of j' <= j with T[j'] == T[j' - p], both definite; window ending at j = i + k.
-constexpr int PER_MAXP = 6;
+constexpr int PER_MAXP = TPC_PER_MAXP;      // periods 1 .. 63 (round 6; 6 until then: minisatellite units of 7 .. 60 bp cost the 62-genome text + 12 %, profiles/r06_m2r2.txt)
+constexpr int PER_PLANES = TPC_PER_PLANES;  // the distance p of a copying position in six bit planes
+constexpr int PER_CBITS = 10;               // bit-sliced run counters: runs up to 1023 >= k + 2 for every supported k (<= 603)
+// All 63 periods at once, bit-sliced over a 64-bit word (bit p - 1 = period p): H0 / H1 / HN hold the two code bits and the N flag of the
+// 63 characters before j, E = the periods whose character p back equals T[j] (both definite), C[b] = bit b of every period's run counter
+// (incremented where E, cleared where not, saturating), and "run >= k + 2" is a bit-sliced comparison: ~130 word operations per
+// character for all periods, where a counter per period took 5 per period.
 __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
                                                         uint32_t *__restrict__ qd, uint64_t stride, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo,
-                                                        uint64_t pos_hi, uint32_t *__restrict__ any)
+                                                        uint64_t pos_hi, uint32_t *any)
 {   // words [w_begin, n_words); characters outside [pos_lo, pos_hi) -- a context that holds only its window of the text -- count as N
     // qs == nullptr: detection only.  any[0] / any[1]: set when some position copies its verdict / drops its insert
-    // qd: the distance p of a copying position in three bit planes (qd, qd + stride, qd + 2 stride)
+    // qd: the distance p of a copying position in PER_PLANES bit planes (qd + b * stride)
     const uint64_t w = w_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= n_words) return;
-    uint32_t oqs = 0, od0 = 0, od1 = 0, od2 = 0, oin = 0;
+    uint32_t oqs = 0, oin = 0, od[PER_PLANES];
+#pragma unroll
+    for (int b = 0; b < PER_PLANES; b++) od[b] = 0;
     const int64_t first = (int64_t)(w << 5);
     if ((uint64_t)first < n_text) {
         auto ch_at = [&](int64_t j) { return j >= (int64_t)pos_lo && (uint64_t)j < pos_hi && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
         const int64_t j0 = first - 2;  // (run lengths only matter up to k + 2: starting k + 2 characters before the first window's end is exact)
-        int hist[PER_MAXP], c[PER_MAXP];
+        const uint64_t pmask = (1ull << PER_MAXP) - 1ull;
+        uint64_t H0 = 0, H1 = 0, HN = 0, C[PER_CBITS];
 #pragma unroll
-        for (int p = 0; p < PER_MAXP; p++) { hist[p] = ch_at(j0 - 1 - p); c[p] = 0; }
+        for (int b = 0; b < PER_CBITS; b++) C[b] = 0;
+        for (int p = PER_MAXP; p >= 1; p--) {  // bit p - 1 = the character p before j0
+            const int ch = ch_at(j0 - p);
+            H0 = (H0 << 1) | (uint64_t)(ch & 1); H1 = (H1 << 1) | (uint64_t)((ch >> 1) & 1); HN = (HN << 1) | (uint64_t)(ch >= 4);
+        }
+        // (the loop above shifted the NEAREST character in last: bit 0 = one back ... bit 62 = 63 back)
+        const uint32_t T2 = (uint32_t)(k + 2), T1 = (uint32_t)(k + 1);
         for (int64_t j = j0; j <= first + 31 + k; j++) {
             const int ch = ch_at(j);
+            const uint64_t c0 = (uint64_t)(ch & 1), c1 = (uint64_t)((ch >> 1) & 1), n = (uint64_t)(ch >= 4);
+            const uint64_t E = n ? 0ull : (~(H0 ^ (0ull - c0)) & ~(H1 ^ (0ull - c1)) & ~HN & pmask);
+            uint64_t sat = ~0ull;
 #pragma unroll
-            for (int p = 0; p < PER_MAXP; p++) c[p] = ch < 4 && ch == hist[p] ? c[p] + 1 : 0;
+            for (int b = 0; b < PER_CBITS; b++) sat &= C[b];
+            uint64_t carry = E & ~sat;  // (a saturated counter stays where it is while its run goes on)
 #pragma unroll
-            for (int p = PER_MAXP - 1; p > 0; p--) hist[p] = hist[p - 1];
-            hist[0] = ch;
+            for (int b = 0; b < PER_CBITS; b++) { const uint64_t t = C[b] & carry; C[b] = ((C[b] ^ carry) | (C[b] & sat)) & E; carry = t; }
+            H0 = ((H0 << 1) | c0) & pmask; H1 = ((H1 << 1) | c1) & pmask; HN = ((HN << 1) | n) & pmask;
             const int64_t i = j - k;
             if (i < first) continue;
-            const uint32_t bit = 1u << (uint32_t)(i - first);
-            int d = 0;
-            bool in = false;
+            uint64_t G2 = ~0ull, G1 = ~0ull;  // periods whose run reaches k + 2 / k + 1
 #pragma unroll
-            for (int p = PER_MAXP - 1; p >= 0; p--) {
-                if (c[p] >= k + 2) d = p + 1;  // (the smallest period wins)
-                in = in || c[p] >= k + 1;
+            for (int b = 0; b < PER_CBITS; b++) {
+                G2 = ((T2 >> b) & 1u) ? (C[b] & G2) : (C[b] | G2);
+                G1 = ((T1 >> b) & 1u) ? (C[b] & G1) : (C[b] | G1);
             }
-            if (in) oin |= bit;
+            G2 &= pmask; G1 &= pmask;
+            const uint32_t bit = 1u << (uint32_t)(i - first);
+            if (G1) oin |= bit;
             // the position it copies from lies in the same 512-word tile, and the first PER_MAXP positions of a tile always probe: a run of
             // copying positions never crosses a tile (batches and ranks are made of tiles) and k_periodic_copy's walks end there
-            if (d && ((uint32_t)i & (uint32_t)(PT_THREADS * TPC_RUN - 1)) >= (uint32_t)PER_MAXP) {
+            if (G2 && ((uint32_t)i & (uint32_t)(PT_THREADS * TPC_RUN - 1)) >= (uint32_t)PER_MAXP) {
+                const uint32_t d = (uint32_t)__ffsll((long long)G2);  // (the smallest period wins)
                 oqs |= bit;
-                if (d & 1) od0 |= bit;
-                if (d & 2) od1 |= bit;
-                if (d & 4) od2 |= bit;
+#pragma unroll
+                for (int b = 0; b < PER_PLANES; b++) if ((d >> b) & 1u) od[b] |= bit;
             }
         }
     }
-    if (qs) { qs[w] = oqs; qd[w] = od0; qd[w + stride] = od1; qd[w + 2 * stride] = od2; ins[w] = oin; }
+    if (qs) {
+        qs[w] = oqs; ins[w] = oin;
+#pragma unroll
+        for (int b = 0; b < PER_PLANES; b++) qd[w + (uint64_t)b * stride] = od[b];
+    }
     if (oqs) any[0] = 1u;
     if (oin) any[1] = 1u;
 }
@@ -1603,42 +1626,51 @@ __global__ void __launch_bounds__(256) k_periodic_copy(uint32_t *__restrict__ rm
     if (w >= n_words) return;
     const uint32_t S = qs[w];
     if (S == 0u) return;
-    const uint32_t Sp = w ? qs[w - 1] : 0u;
-    uint32_t before = 0;
-#pragma unroll
-    for (int t = 1; t <= PER_MAXP; t++) before |= (S << t) | (Sp >> (32 - t));
-    uint32_t starts = S & ~before;
+    // the copying positions among the 64 before this word (bit t = position 32 w - 64 + t)
+    const uint64_t prev = (w ? (uint64_t)qs[w - 1] << 32 : 0ull) | (w > 1 ? (uint64_t)qs[w - 2] : 0ull);
+    uint32_t starts = 0;
+    for (uint32_t m = S; m; m &= m - 1u) {
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+        // any copying position among the PER_MAXP = 63 before 32 w + b: those of this word below b, those of `prev` from bit b + 1 up
+        const bool before = (S & ((1u << b) - 1u)) != 0u || (prev >> (b + 1u)) != 0ull;
+        if (!before) starts |= 1u << b;
+    }
     while (starts) {
         const uint32_t b = (uint32_t)__ffs((int)starts) - 1u;
         starts &= starts - 1u;
         uint64_t i = (w << 5) + b;  // (>= PER_MAXP: the first positions of a tile never copy)
-        uint32_t mh = 0;            // bit t - 1 = mark(i - t)
-#pragma unroll
-        for (int t = 1; t <= PER_MAXP; t++) mh |= ((rmask[(i - t) >> 5] >> ((i - t) & 31u)) & 1u) << (t - 1);
+        uint64_t mh = 0;            // bit t - 1 = mark(i - t)
+        for (int t = 1; t <= PER_MAXP; t++) mh |= (uint64_t)((rmask[(i - t) >> 5] >> ((i - t) & 31u)) & 1u) << (t - 1);
         // the walk keeps the words of the 32 positions at hand in registers (a 500-position tract is 16 word fetches, not 2500 loads one
         // after the other: the kernel lasts as long as its longest walk)
         uint64_t cw = i >> 5;
-        uint32_t sw = S, d0 = qd[cw], d1 = qd[cw + stride], d2 = qd[cw + 2 * stride], rw = rmask[cw], add = 0;
+        uint32_t sw = S, dpl[PER_PLANES], rw = rmask[cw], add = 0;
+#pragma unroll
+        for (int q = 0; q < PER_PLANES; q++) dpl[q] = qd[cw + (uint64_t)q * stride];
         for (int zeros = 0;; i++) {
             if ((i >> 5) != cw) {
                 if (add) atomicOr(&rmask[cw], add);
                 cw = i >> 5;
                 add = 0;
                 if (cw >= n_words) break;
-                sw = qs[cw]; d0 = qd[cw]; d1 = qd[cw + stride]; d2 = qd[cw + 2 * stride]; rw = rmask[cw];
+                sw = qs[cw]; rw = rmask[cw];
+#pragma unroll
+                for (int q = 0; q < PER_PLANES; q++) dpl[q] = qd[cw + (uint64_t)q * stride];
             }
             const uint32_t bi = (uint32_t)i & 31u;
             uint32_t m;
             if ((sw >> bi) & 1u) {
                 zeros = 0;
-                const uint32_t d = ((d0 >> bi) & 1u) | (((d1 >> bi) & 1u) << 1) | (((d2 >> bi) & 1u) << 2);
-                m = (mh >> (d - 1u)) & 1u;
+                uint32_t d = 0;
+#pragma unroll
+                for (int q = 0; q < PER_PLANES; q++) d |= ((dpl[q] >> bi) & 1u) << q;
+                m = (uint32_t)(mh >> (d - 1u)) & 1u;
                 add |= m << bi;
             } else {
                 if (++zeros == PER_MAXP) break;
                 m = (rw >> bi) & 1u;  // (a probing position: its mark is final, and no walk ever sets it)
             }
-            mh = ((mh << 1) | m) & ((1u << PER_MAXP) - 1u);
+            mh = ((mh << 1) | (uint64_t)m) & ((1ull << PER_MAXP) - 1ull);
         }
         if (add) atomicOr(&rmask[cw], add);
     }

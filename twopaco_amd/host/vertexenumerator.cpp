@@ -207,7 +207,27 @@ namespace TwoPaCo
 				// so: whatever keeps filter + buffers inside those first 48 GiB, between 20 and 40 GiB (measured on the 1.12 Gbp / f = 38
 				// workload: 16 / 20 / 28 GiB -> 0.82 / 0.76 / 0.83 s)
 				const double filterGb = std::ldexp(1.0, int(filterSize) - 33);
-				const double autoGb = std::max(20.0, std::min(40.0, 48.0 - filterGb));
+				double autoGb = std::max(20.0, std::min(40.0, 48.0 - filterGb));
+				// A large filter turns that around (round 6, profiles/r06_e2e_big.txt): every tile batch of the insert reads and rewrites the
+				// whole filter (2 x 2^L / 8 bytes at ~5 TB/s: 55 ms at f = 40) in every round, and what looked like a price per allocated GiB
+				// was the driver clearing the memory of the process that ran just before (tools/malloc_bench.hip: 0.04 ms per GiB on clean
+				// memory, 20-90 after another process's exit) -- at configs[4]'s shape 20 GiB meant 17 batches and 1.0 s per round's insert,
+				// against 0.36 s in 4.  From 16 GiB of filter on: room for the insert's entries in about four batches (q x 4 bytes x 2.8 per
+				// position, one position per input byte), within 55 % of what the device has left beside the filter and the text.
+				if (filterGb >= 16.0)
+				{
+					double inputGb = 0;
+					for (const std::string & fn : fileName)
+					{
+						struct stat st;
+						if (::stat(fn.c_str(), &st) == 0) inputGb += double(st.st_size) / double(1ull << 30);
+					}
+
+					const double entriesGb = inputGb * double(hashFunctions) * 4.0 * 2.8;
+					const double roomGb = 0.55 * std::max(0.0, 280.0 - filterGb - inputGb * 0.75);
+					autoGb = std::max(autoGb, std::min(roomGb, entriesGb / 4.0));
+				}
+
 				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : autoGb) * double(1ull << 30));
 				// More than 16 hash functions run on the closed-form first-pass kernels (csrc/tpc_pass1_anyq.hip), which exist for the
 				// whole filter only: such a run takes one GPU whatever --gpus says (and says so).
@@ -495,6 +515,7 @@ namespace TwoPaCo
 					}
 					else if (!nothing) Check(tpc_pass1_split_hist(ctx_, dispStart.data(), dispLength.data(), uint32_t(dispStart.size()), binCounter.data()), "split_hist");
 					roundSize = double(std::accumulate(binCounter.begin(), binCounter.begin() + BINS_COUNT, size_t(0))) / rounds;
+					timer.Lap("split pass (vertex-hash histogram)");
 				}
 
 				logStream << std::string(80, '-') << std::endl;
