@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 static double now_ms()
@@ -103,8 +104,51 @@ static double t_vmm(size_t bytes)
     return t1 - t0;
 }
 
+// Back-to-back processes (a run started right after another one's exit waits seconds in its first large allocation):
+//   malloc_bench dirty N          allocate N GiB, write all of it, exit (the driver then clears it in the background)
+//   malloc_bench probe N [B]      right after that: [B GiB of ballast allocated first and never touched,] then N GiB allocated and touched
+//                                 at both ends -- hipMalloc and the first touch timed apart
+static int back_to_back(int argc, char **argv)
+{
+    const size_t n = (size_t)atoll(argv[2]) << 30;
+    const double t0 = now_ms();
+    (void)hipSetDevice(0);
+    (void)hipFree(nullptr);
+    const double t1 = now_ms();
+    if (argv[1][0] == 'd') {
+        void *p = nullptr;
+        if (hipMalloc(&p, n) != hipSuccess) { std::printf("dirty: hipMalloc failed\n"); return 1; }
+        (void)hipMemset(p, 0x5A, n);
+        (void)hipDeviceSynchronize();
+        std::printf("dirty: %zu GiB written, exiting without freeing (init %.0f ms, alloc + fill %.0f ms)\n", n >> 30, t1 - t0, now_ms() - t1);
+        return 0;
+    }
+    const size_t ballast = argc > 3 ? (size_t)atoll(argv[3]) << 30 : 0;
+    const bool threaded = argc > 4;  // probe N B t: the ballast is allocated by a SECOND thread, this one waits 50 ms and goes on
+    void *b = nullptr, *p = nullptr;
+    double tb = 0;
+    std::thread side;
+    if (ballast && threaded) {
+        side = std::thread([&]() { (void)hipSetDevice(0); const double a0 = now_ms(); if (hipMalloc(&b, ballast) != hipSuccess) std::printf("probe: ballast failed\n"); tb = now_ms() - a0; });
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    } else if (ballast) { const double a0 = now_ms(); if (hipMalloc(&b, ballast) != hipSuccess) std::printf("probe: ballast failed\n"); tb = now_ms() - a0; }
+    const double a0 = now_ms();
+    if (hipMalloc(&p, n) != hipSuccess) { std::printf("probe: hipMalloc failed\n"); return 1; }
+    const double a1 = now_ms();
+    touch(p, n);
+    const double a2 = now_ms();
+    (void)hipMemset(p, 0, n);
+    (void)hipDeviceSynchronize();
+    const double a3 = now_ms();
+    if (side.joinable()) side.join();
+    std::printf("probe: init %.0f ms; ballast %zu GiB%s hipMalloc %.1f ms; %zu GiB: hipMalloc %.1f ms, first touch (2 MiB) %.1f ms, memset of all of it %.1f ms\n", t1 - t0, ballast >> 30,
+                threaded ? " (second thread)" : "", tb, n >> 30, a1 - a0, a2 - a1, a3 - a2);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 2 && (argv[1][0] == 'd' || argv[1][0] == 'p')) return back_to_back(argc, argv);
     std::vector<size_t> sizes;
     for (int i = 1; i < argc; i++) sizes.push_back((size_t)atoll(argv[i]));
     if (sizes.empty()) sizes = {8, 32, 64, 128};
