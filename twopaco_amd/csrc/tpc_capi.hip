@@ -2196,8 +2196,8 @@ int tpc_combine_info(tpc_ctx *c, uint32_t n_dest, uint64_t *info)
             e = std::min<uint64_t>(e, (uint64_t)1 << g.slice_bits);
             units[b1 & (n_dest - 1)] += (e + 7) / 8 + n_win;
         }
-    // (+ the chunks the persistent export claims per workgroup and destination: tpc_combine.hip:CB_CHUNK = 256 units, at most 1024 workgroups)
-    info[0] = 1; info[1] = n_slices; info[2] = n_win; info[3] = *std::max_element(units.begin(), units.end()) + 1024 * 256;
+    // (+ the chunks the persistent export claims per workgroup and destination: tpc_combine.hip:CB_CHUNK = 512 units, at most 1024 workgroups)
+    info[0] = 1; info[1] = n_slices; info[2] = n_win; info[3] = *std::max_element(units.begin(), units.end()) + 1024 * 512;
     info[4] = (uint64_t)g.slice_bits; info[5] = (uint64_t)g.b1; info[6] = (uint64_t)g.b2; info[7] = (uint64_t)(n_slices / n_dest) * n_win;
     return 0;
 }

@@ -141,7 +141,7 @@ k_slice_combine(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__re
 // scanned and listed, that region's count was loaded an iteration before; the output space comes from a chunk of CB_CHUNK units the
 // workgroup claimed for the destination earlier (one global atomic per ~dozen slices; the directory says where every list went, so the
 // unused tail of a chunk is just a few KB that travel for nothing); and listing a word zeroes it for the next slice.
-constexpr uint32_t CB_CHUNK = 256;  // 16-byte units per claim (4 KB)
+constexpr uint32_t CB_CHUNK = 512;  // 16-byte units per claim (8 KB): what a workgroup leaves unused is at most one window's list per chunk and half a chunk per destination at the end
 
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
@@ -156,6 +156,7 @@ k_slice_export_p(int slice_bits, int log_nb2, uint32_t n_slices, uint32_t iwpb, 
     uint32_t *s_win = s_w + THREADS / 64;           // [CB_MAX_WIN + 1], then [CB_MAX_WIN]
     uint32_t *s_ctl = s_win + 2 * CB_MAX_WIN + 1;   // [4]
     uint64_t *s_chunk = reinterpret_cast<uint64_t *>(s_ctl + 4);  // [64] next free unit of this workgroup's chunk per destination, [64] the chunk's end
+    uint64_t *s_base = s_chunk + 128;                             // [CB_MAX_WIN] first unit of every window's list of the slice at hand
     const uint32_t nb2 = 1u << log_nb2, smask = (1u << slice_bits) - 1u;
     const bool wide = (words & 3u) == 0;
     if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
@@ -210,37 +211,42 @@ k_slice_export_p(int slice_bits, int log_nb2, uint32_t n_slices, uint32_t iwpb, 
         if (threadIdx.x == 0) s_win[n_win] = total;
         __syncthreads();
         const uint32_t dest = b1 & (n_dest - 1u);
-        if (threadIdx.x < 64) {  // (first wave) units before every window: a 16-lane prefix sum instead of a serial walk over LDS
+        if (threadIdx.x < 64) {  // (first wave) every window's list gets its units from this workgroup's chunk for the destination, window by window
             const uint32_t v = threadIdx.x;
-            uint32_t u = v < n_win ? (s_win[v + 1] - s_win[v] + 7u) >> 3 : 0u, inc = u;
-            for (int o = 1; o < CB_MAX_WIN; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)v >= o) inc += t; }
-            if (v < n_win) s_win[CB_MAX_WIN + 1 + v] = inc - u;
-            const uint32_t units = __shfl(inc, CB_MAX_WIN - 1, 64);  // (lanes behind the last window add nothing)
-          if (v == 0) {
+            const uint32_t u = v < n_win ? (s_win[v + 1] - s_win[v] + 7u) >> 3 : 0u;
             uint64_t cur = s_chunk[dest], end = s_chunk[64 + dest];
             bool ok = true;
-            if (cur + units > end) {  // a new chunk for this destination (what is left of the old one travels unused)
-                const uint64_t claim = units > CB_CHUNK ? units : CB_CHUNK;
-                cur = (uint64_t)atomicAdd(&out_cur[dest], (unsigned long long)claim);
-                end = cur + claim;
-                ok = end <= out_cap;
-                if (!ok) { out_cur[n_dest] = 1ull; end = cur; }
-                s_chunk[64 + dest] = end;
+            uint32_t inc = u;  // the usual case: the whole slice fits what is left of the chunk -- a 16-lane prefix sum places its windows
+            for (int o = 1; o < CB_MAX_WIN; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)v >= o) inc += t; }
+            const uint32_t units = (uint32_t)__shfl((int)inc, CB_MAX_WIN - 1, 64);
+            if (cur + units <= end) {
+                if (v < n_win) s_base[v] = cur + (inc - u);
+                cur += units;
+            } else
+            for (uint32_t x = 0; x < n_win; x++) {  // (uniform over the wave: every lane walks the same sixteen sizes)
+                const uint32_t ux = (uint32_t)__shfl((int)u, (int)x, 64);
+                if (cur + ux > end) {  // a new chunk (what is left of the old one, less than a window's list, travels unused)
+                    const uint64_t claim = ux > CB_CHUNK ? ux : CB_CHUNK;
+                    unsigned long long got = 0;
+                    if (v == 0) got = atomicAdd(&out_cur[dest], (unsigned long long)claim);
+                    cur = (uint64_t)__shfl((long long)got, 0, 64);
+                    end = cur + claim;
+                    if (end > out_cap) { ok = false; end = cur; if (v == 0) out_cur[n_dest] = 1ull; }
+                }
+                if (v == x) s_base[x] = cur;
+                if (end > cur) cur += ux;
             }
-            s_chunk[dest] = ok ? cur + units : cur;
-            s_ctl[0] = (uint32_t)cur; s_ctl[1] = (uint32_t)(cur >> 32); s_ctl[2] = ok ? 1u : 0u;
-          }
+            if (v == 0) { s_chunk[dest] = cur; s_chunk[64 + dest] = end; s_ctl[2] = ok ? 1u : 0u; }
         }
         __syncthreads();
         const bool ok = s_ctl[2] != 0;
-        const uint64_t base = (uint64_t)s_ctl[0] | ((uint64_t)s_ctl[1] << 32);
         const uint64_t key = ((uint64_t)(b1 / n_dest) << log_nb2) | b2;
         uint64_t *dir = out_dir + ((uint64_t)dest * slices_per_dest + key) * n_win;
         if (threadIdx.x < n_win) {
             const uint32_t n = s_win[threadIdx.x + 1] - s_win[threadIdx.x];
-            dir[threadIdx.x] = ok ? ((base + s_win[CB_MAX_WIN + 1 + threadIdx.x]) << 24) | (uint64_t)n : 0ull;
+            dir[threadIdx.x] = ok ? (s_base[threadIdx.x] << 24) | (uint64_t)n : 0ull;
         }
-        uint16_t *dst = out_payload + (((uint64_t)dest * out_cap + base + s_win[CB_MAX_WIN + 1 + win]) << 3) + (off - s_win[win]);
+        uint16_t *dst = out_payload + (((uint64_t)dest * out_cap + s_base[win]) << 3) + (off - s_win[win]);
         if (cnt && vec4) {
             uint4 *s4 = reinterpret_cast<uint4 *>(slice + wfirst);
             for (uint32_t q = tl; q < wwords / 4u; q += tpw) {
@@ -304,10 +310,11 @@ int tpc_launch_slice_combine(const TpcLaunch &a, int slice_bits, int b1, int b2,
     while (parts > n_win) parts >>= 1;
     static const bool no_persist = getenv("TPC_COMBINE_NO_PERSIST") != nullptr;  // (measurements: A/B against one workgroup per slice)
     const uint32_t n_slices = 1u << (b1 + b2);
-    if (out && ipl && !dense && ls.n_src == 0 && world == 1 && parts == 1 && n_slices >= 1024 && !no_persist) {
+    // (from 16384 slices on: a long-lived workgroup leaves up to a chunk unused per destination, which only a large export makes small)
+    if (out && ipl && !dense && ls.n_src == 0 && world == 1 && parts == 1 && n_slices >= 16384 && !no_persist) {
         static const int n_cu = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
         const size_t words = (size_t)1 << (slice_bits - 5);
-        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (1024 / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4 + 128 * 8;
+        const size_t lds = ((words + 3) & ~(size_t)3) * 4 + (1024 / 64 + 2 * CB_MAX_WIN + 1 + 4) * 4 + (128 + CB_MAX_WIN) * 8;
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ((size_t)160 * 1024) / (lds + 1024)));  // (two 1024-thread workgroups fill a CU's wave slots)
         const uint32_t grid_p = std::min<uint32_t>(n_slices, (uint32_t)n_cu * per_cu);
         (void)hipFuncSetAttribute((const void *)k_slice_export_p<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
