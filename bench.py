@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 G_BYTES = 64           # HBM access granule of a scattered 4-byte access (SURVEY 8d planning value)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s
 GOLDEN_SEED = 20240229  # tests/golden/make_golden.py: the seed the reference goldens were made with
-PMC_PROFILE = "r05_pmc_traffic.json"
+PMC_PROFILE = "r06_pmc_traffic.json"
 
 
 def launch_ranks(args, script=None):

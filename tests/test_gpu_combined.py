@@ -162,6 +162,15 @@ def test_combined_low_complexity_input(world, mode, tmp_path):
     check(spec, o, run(spec, world, tmp_path), world)
 
 
+@pytest.mark.parametrize("name,world", [("rand6_k9_q20", 2), ("rand6_k9_q20_fp_r2", 4)])
+def test_combined_more_than_16_hash_functions(name, world, tmp_path):
+    """-q 20 (the reference takes any -q, constructor.cpp:83-90): beyond the rolling kernels' 16 functions every rank runs the closed-form
+    kernels (csrc/tpc_pass1_anyq.hip) over ITS chunk of the positions, the ranks' dense filters are OR-reduced, the query is local --
+    no one-GPU fallback."""
+    spec, o = golden_spec(name, 12, tmp_path)
+    check(spec, o, run(spec, world, tmp_path), world, "dense")
+
+
 def test_combined_more_ranks_than_tiles(tmp_path):
     """example.fa is one tile: seven of eight ranks hash nothing and still build the whole filter from the one export."""
     spec, o = golden_spec("example_k15_dbg", 8, tmp_path, mode="scatter")

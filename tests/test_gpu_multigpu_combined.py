@@ -37,7 +37,9 @@ def _check(case, e, out):
 @pytest.mark.parametrize("name,ranks,mode", [("rand6_k9_L33", 2, None), ("rand6_k9_L33", 4, None), ("c2_k51_r2", 2, "scatter"), ("edge_k5", 2, "gather"), ("rand6_k25_q3", 8, None),
                                              ("rand6_k9_a3", 4, "dense"), ("c2_k125", 2, None), ("m1_small", 4, None), ("m2_small", 8, None), ("m2_small", 2, None),
                                              ("rand6_k9_q12", 2, "scatter"), ("m2r_small", 4, None), ("tr_k25_L28", 2, None), ("tr_k31_L30_q3", 4, "gather"),
-                                             ("rand6_k9_L24_r4", 2, None), ("example_k15_r3", 8, None)])
+                                             ("rand6_k9_L24_r4", 2, None), ("example_k15_r3", 8, None),
+                                             # more than 16 hash functions: every rank runs the closed-form kernels over its chunk, the dense filters are OR-reduced
+                                             ("rand6_k9_q20", 2, None), ("rand6_k9_q20_fp_r2", 4, None)])
 def test_emulated_ranks_write_reference_bytes(capi, tmp_path, name, ranks, mode, monkeypatch):
     if mode:
         monkeypatch.setenv("TWOPACO_COMBINE", mode)

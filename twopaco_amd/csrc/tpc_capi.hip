@@ -746,7 +746,9 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     uint64_t batches = 1;
     bool defer = false;
     bool part = ((c->opt_insert_mode != 1 && !(c->opt_insert_mode == 0 && c->P.L < 28)) || replicated(c)) && part_hash_supported(c);  // small filters: the direct kernel is as fast
-    if (replicated(c) && !part) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned hash kernels (q=%d, L=%d, slice_bits=%d are outside what they cover)", c->P.q, c->P.L, c->opt_slice_bits);
+    // (more than 16 hash functions: the closed-form direct kernels take a rank's chunk as a range of positions; the ranks' dense filters are OR-reduced)
+    if (replicated(c) && !part && c->P.q <= TPC_KERNEL_MAXQ)
+        return fail(c, -1, "a replicated multi-GPU pass needs the partitioned hash kernels (q=%d, L=%d, slice_bits=%d are outside what they cover)", c->P.q, c->P.L, c->opt_slice_bits);
     if (part) {
         // as few batches of tiles as the buffer budget allows
         const int64_t budget = part_budget(c);
@@ -871,7 +873,9 @@ int tpc_pass1_insert(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_kmers)
     if (!part) { c->stat_path[0] = 1; c->stat_batches[0] = 1; }
     {
         Timed t(c, TPC_K_INSERT);
-        if (tpc_launch_insert(make_launch(c), lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
+        TpcLaunch ad = make_launch(c);
+        if (replicated(c)) { ad.g_begin = t_begin * 512ull * TPC_RUN; ad.g_end = t_end * 512ull * TPC_RUN; }  // (q > 16 only: see above)
+        if (tpc_launch_insert(ad, lo, hi, gated, c->opt_test_first != 0, n_kmers ? c->counters : nullptr))
             return fail(c, -1, "insert launch failed");
     }
     HIPCHK(c, hipGetLastError());
@@ -997,7 +1001,7 @@ int pass1_query_impl(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks, bo
     pass_tiles(c, t_begin, t_end);  // every tile, or this rank's chunk (option replicate_filter on a sharded context: the marks of the chunk only)
     bool part = plan_query(c, lo, hi, gated, pl);
     if (replicated(c)) {
-        if (!part) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned query (q=%d, L=%d, slice_bits=%d)", c->P.q, c->P.L, c->opt_slice_bits);
+        if (!part && c->P.q <= TPC_KERNEL_MAXQ) return fail(c, -1, "a replicated multi-GPU pass needs the partitioned query (q=%d, L=%d, slice_bits=%d)", c->P.q, c->P.L, c->opt_slice_bits);
         if (!begun) HIPCHK(c, hipMemsetAsync(c->rmask, 0, c->n_words_alloc * sizeof(uint32_t), c->stream));  // the hash kernel rewrites the words of this rank's tiles only
     }
     if (begin_only && !part) return 0;  // (the direct kernel needs the filter from its first instruction: nothing to start early)
@@ -1177,7 +1181,9 @@ int pass1_query_impl(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks, bo
     HIPCHK(c, hipMemsetAsync(c->counters + 1, 0, sizeof(unsigned long long), c->stream));
     {
         Timed t(c, TPC_K_QUERY);
-        if (tpc_launch_query(make_launch(c), c->rmask, lo, hi, gated, c->counters + 1)) return fail(c, -1, "query launch failed");
+        TpcLaunch ad = make_launch(c);
+        if (replicated(c)) { ad.g_begin = t_begin * 512ull * TPC_RUN; ad.g_end = t_end * 512ull * TPC_RUN; }  // (q > 16: the closed-form kernel over this rank's chunk)
+        if (tpc_launch_query(ad, c->rmask, lo, hi, gated, c->counters + 1)) return fail(c, -1, "query launch failed");
     }
     HIPCHK(c, hipGetLastError());
     uint64_t n = 0;

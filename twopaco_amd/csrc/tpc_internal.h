@@ -48,6 +48,8 @@ struct TpcLaunch {
     // (k+1)-mer at i equals the one 1..63 positions earlier -- its insert adds nothing; per_qs: the k + 2 characters around the vertex at i
     // equal those around i - p -- its candidate verdict is that position's, copied after the verification (p: six bit planes, the copy's business)
     const uint32_t *per_i = nullptr, *per_qs = nullptr;
+    // the closed-form kernels of tpc_pass1_anyq.hip (q = 17..64) over a range of positions only: a rank's chunk of a replicated multi-GPU pass
+    uint64_t g_begin = 0, g_end = ~0ull;
     // measurement: recorded around the k_apply_lookup launch of tpc_launch_query_part_fused_lookup when set (TPC_K_LOOKUP)
     hipEvent_t ev_lookup0 = nullptr, ev_lookup1 = nullptr;
 };

@@ -14,6 +14,7 @@
 // fast kernels by construction (tests: golden rand6_k9_q20 from the real reference, and q <= 16 forced through this file).
 #include "tpc_device.h"
 #include "tpc_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -88,9 +89,9 @@ __device__ __forceinline__ void insert_edge(const HashCtx &H, const Edge &e, int
 template <bool TEST>
 __global__ void __launch_bounds__(256)
 k_insert_anyq(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text,
-              uint32_t *filter, uint64_t lo, uint64_t hi, int gated, unsigned long long *n_kmers)
-{
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+              uint32_t *filter, uint64_t lo, uint64_t hi, int gated, unsigned long long *n_kmers, uint64_t g_begin)
+{   // n_text: the end of the positions this launch covers (the text's, or a rank's chunk's); g_begin: their start
+    const uint64_t g = g_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const HashCtx H{tab, P.L, P.q, P.lmask};
     const int k = P.k;
     bool vertex = false;
@@ -124,9 +125,9 @@ __device__ __forceinline__ bool edge_present(const HashCtx &H, const Edge &e, in
 
 __global__ void __launch_bounds__(256)
 k_query_anyq(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text,
-             const uint32_t *__restrict__ filter, uint32_t *__restrict__ rmask, uint64_t n_words, uint64_t lo, uint64_t hi, int gated, unsigned long long *n_marks)
-{   // one lane per position, one wave per 64 positions = two mask words
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+             const uint32_t *__restrict__ filter, uint32_t *__restrict__ rmask, uint64_t n_words, uint64_t lo, uint64_t hi, int gated, unsigned long long *n_marks, uint64_t g_begin)
+{   // one lane per position, one wave per 64 positions = two mask words; g_begin (a multiple of 64): the first position of this launch
+    const uint64_t g = g_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const HashCtx H{tab, P.L, P.q, P.lmask};
     const int k = P.k;
     bool mark = false;
@@ -177,18 +178,22 @@ k_split_anyq(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *
 
 int tpc_launch_insert_anyq(const TpcLaunch &a, uint64_t lo, uint64_t hi, bool gated, bool test, unsigned long long *n_kmers)
 {
-    const dim3 grid((unsigned)((a.n_text + 255) / 256));
-    if (test) hipLaunchKernelGGL(k_insert_anyq<true>, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, a.n_text, a.filter, lo, hi, gated ? 1 : 0, n_kmers);
-    else hipLaunchKernelGGL(k_insert_anyq<false>, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, a.n_text, a.filter, lo, hi, gated ? 1 : 0, n_kmers);
+    const uint64_t g0 = std::min(a.g_begin, a.n_text), g1 = std::min(a.g_end, a.n_text);  // (a.g_begin / g_end: a rank's chunk; by default the whole text)
+    if (g1 <= g0) return 0;
+    const dim3 grid((unsigned)((g1 - g0 + 255) / 256));
+    if (test) hipLaunchKernelGGL(k_insert_anyq<true>, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, g1, a.filter, lo, hi, gated ? 1 : 0, n_kmers, g0);
+    else hipLaunchKernelGGL(k_insert_anyq<false>, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, g1, a.filter, lo, hi, gated ? 1 : 0, n_kmers, g0);
     return 0;
 }
 
 int tpc_launch_query_anyq(const TpcLaunch &a, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated, unsigned long long *n_marks)
 {
     const uint64_t n_words = (a.n_text >> 5) + 1;
-    // whole waves: the grid covers every position of the mask words [0, n_words)
-    const dim3 grid((unsigned)((n_words * 32 + 255) / 256));
-    hipLaunchKernelGGL(k_query_anyq, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, a.n_text, a.filter, rmask, n_words, lo, hi, gated ? 1 : 0, n_marks);
+    // whole waves: the grid covers every position of the mask words [0, n_words) -- or of a rank's chunk [g_begin, g_end) (whole tiles: multiples of 64)
+    const uint64_t g0 = std::min(a.g_begin, n_words * 32), g1 = std::min(a.g_end, n_words * 32);
+    if (g1 <= g0) return 0;
+    const dim3 grid((unsigned)((g1 - g0 + 255) / 256));
+    hipLaunchKernelGGL(k_query_anyq, grid, dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, std::min(a.n_text, g1), a.filter, rmask, n_words, lo, hi, gated ? 1 : 0, n_marks, g0);
     return 0;
 }
 

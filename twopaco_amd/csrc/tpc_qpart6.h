@@ -88,7 +88,11 @@ k_q_lookup6(int slice_bits, int log_nb2, uint32_t wpb, const unsigned char *__re
 // Fused k_part_apply + k_q_lookup6 (deferred apply, tpc_partition.hip): the workgroup of a slice ORs the insert's level-2 entries
 // (blocked lines of 40 x 24 bits: PFmt3; or 32-bit entries when I3 is false) into the zeroed LDS slice, writes the slice out and
 // tests the query's entries against the slice it still holds.
-template <bool I3>
+// LISTS (the combined multi-GPU exchange): the slices are built from imported set-bit lists ALONE (tpc_lists.h; no regions, no overflow
+// entries of this rank's own: they are in the lists), and everything whose address depends on the workgroup's index only -- the lists'
+// directory entries and first loads, the zone table, the first query region's count, offset and first lines -- is asked for before the
+// slice is zeroed: with a rank's share of the probes a workgroup lives ~12 us, most of it waiting for one of these after the other.
+template <bool I3, bool LISTS = false>
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2_lines, int fresh,
                 const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const unsigned char *__restrict__ qbuf2,
@@ -105,8 +109,14 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
     const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
     uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
     const bool wide = (words & 3u) == 0;
-    TpcListReader<PT_APPLY_THREADS> lists;  // (their first loads go out before the slice is zeroed)
-    if (ls.n_src) lists.begin(ls, b1, b2, log_nb2, blockIdx.x, slice_bits);
+    TpcListReader<PT_APPLY_THREADS> lists;
+    PlStream<PFmt6, PT_APPLY_THREADS, 1> q0;
+    const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
+    if constexpr (LISTS) {
+        lists.begin(ls, b1, b2, log_nb2, blockIdx.x, slice_bits);
+        if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
+        q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+    }
     // ---- apply
     if (fresh) {
         if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
@@ -117,6 +127,8 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
     }
     if (threadIdx.x == 0) st.ctl[0] = 0;
     __syncthreads();
+    if constexpr (LISTS) lists.finish(ls, slice);
+    else
     for (uint32_t j = 0; j < iwpb; j++) {
         const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
@@ -129,20 +141,17 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
         }
     }
     // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
-    if (iovf_off) {
+    if (!LISTS && iovf_off) {
         const uint64_t o0 = iovf_off[blockIdx.x], o1 = iovf_off[blockIdx.x + 1];
         for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
             const uint64_t a = iovf[i];
             atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
         }
     }
-    if (ls.n_src) lists.finish(ls, slice);
-    const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
-    if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
+    if (!LISTS && threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
     __syncthreads();
     // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
-    PlStream<PFmt6, PT_APPLY_THREADS, 1> q0;
-    q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+    if constexpr (!LISTS) q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
     if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
     else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
     // ---- lookup against the slice still in LDS

@@ -2026,7 +2026,13 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
                            pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls);   \
     } while (0)
         if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
-        if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
+        if (ls.n_src && (ipl.wpb != 0 || iovf_off)) return -1;  // (lists come alone: tpc_combine_import leaves no regions of this rank's own)
+        if (ls.n_src) {  // lists alone (the combined exchange): its own instantiation, loads asked for up front
+            (void)hipFuncSetAttribute((const void *)k_apply_lookup6<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_apply_lookup6<false, true>), dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, 0u, (const unsigned char *)nullptr,
+                               (const uint32_t *)nullptr, (uint64_t)0, fresh ? 1 : 0, (const uint64_t *)nullptr, (const uint64_t *)nullptr, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2,
+                               pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls);
+        } else if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
         if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
 #undef TPC_AL6_GO
         hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);

@@ -231,7 +231,11 @@ namespace TwoPaCo
 				const int64_t partBudget = int64_t((budgetGb ? std::atof(budgetGb) : autoGb) * double(1ull << 30));
 				// More than 16 hash functions run on the closed-form first-pass kernels (csrc/tpc_pass1_anyq.hip), which exist for the
 				// whole filter only: such a run takes one GPU whatever --gpus says (and says so).
-				const bool tooManyFunctionsToShard = hashFunctions > 16 && (options.gpus > 1 || options.forceSharded);
+				// (... unless the filter is replicated -- the combined exchange, decided below from the same inputs: every rank then runs the
+				//  closed-form kernels over its chunk of the text and the ranks' dense filters are OR-reduced)
+				const char * multiGpuEnvEarly = std::getenv("TWOPACO_MULTIGPU");
+				const bool combinedPossible = filterSize <= 38 && !(multiGpuEnvEarly && std::string(multiGpuEnvEarly) == "entries");
+				const bool tooManyFunctionsToShard = hashFunctions > 16 && (options.gpus > 1 || options.forceSharded) && !combinedPossible;
 				if (tooManyFunctionsToShard) logStream << "Hash functions = " << hashFunctions << " > 16: the Bloom filter is not sharded, running on one GPU" << std::endl;
 				const int gpus = tooManyFunctionsToShard ? 1 : std::max(1, options.gpus);
 				const bool sharded = !tooManyFunctionsToShard && (gpus > 1 || options.forceSharded);
