@@ -141,6 +141,17 @@ int tpc_pass2_filter_positions(tpc_ctx *ctx, const uint64_t *pos_dev, uint64_t n
 int tpc_pass2_mark_records(tpc_ctx *ctx, uint32_t world, uint64_t *records_dev, int32_t *owner_dev);
 int tpc_pass2_filter_records(tpc_ctx *ctx, const uint64_t *records_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false,
                              uint64_t *table_size);
+/* Combine before routing, second pass: tpc_pass2_aggregate_records runs the exact filter over this rank's OWN marks first (into its
+ * table: CandidateFinalFilteringWorker's map per rank, VE.h:708-829) and writes one record per DISTINCT key -- the key and, in the last
+ * word, bit 63 | the letter sets of prev / next, "seen at least twice" and the occurrence count its marks add up to -- with the key's
+ * owner; *n_records of them (<= the rank's marks: size the buffers for those).  On many-genome inputs a key is marked dozens of times, so
+ * far fewer rows travel (M2 at two ranks: 22 M marks -> ~1 M records per rank).  The rows are routed as before and
+ * tpc_pass2_filter_aggregated merges what a rank received: sets OR-ed, counts added, the reference's verdict (isBif, abundance cut) on
+ * the sums.  Occurrences are counted whenever `abundance` is a real cut (< 2^40) -- pass the same value to both calls on every rank.
+ * tpc_pass2_filter_records takes aggregated and per-position records alike; what differs is how the table is sized and that rule. */
+int tpc_pass2_aggregate_records(tpc_ctx *ctx, uint32_t world, uint64_t abundance, uint64_t *records_dev, int32_t *owner_dev, uint64_t *n_records);
+int tpc_pass2_filter_aggregated(tpc_ctx *ctx, const uint64_t *records_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false,
+                                uint64_t *table_size);
 int tpc_shard_permute_rows(tpc_ctx *ctx, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, int row_words, uint64_t *dst_dev);
 
 /* BifurcationStorage::Init (bifurcationstorage.h:27-66): sort all junction keys in

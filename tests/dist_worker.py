@@ -188,7 +188,7 @@ def combined_worker(rank, world, port, spec, result_path):
         st = tdist.address_sharded_step(sh, sp["abundance"], fetch=True, sharded_pass2=sp.get("sharded_pass2", False))
         lo_hi = ctx.shard_chunk() if hasattr(ctx, "shard_chunk") else None
         out.update(g=st["g"], ids=st["ids"], junctions=st["junctions"], true=st["true"], step_marks=st["marks"], moved=sh.comm.bytes_moved, chunk=lo_hi,
-                   combine=dict(sh.stats["combine"]))
+                   combine=dict(sh.stats["combine"]), pass2_records_sent=sh.stats.get("pass2_records_sent"))
         gathered = [None] * world
         dist.all_gather_object(gathered, out)
         results.append(gathered)

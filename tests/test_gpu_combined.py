@@ -100,10 +100,15 @@ def test_combined_lists_applied_without_a_lookup(name, slice_bits, world, mode, 
     check(spec, o, run(spec, world, tmp_path), world, MODES[mode])
 
 
-@pytest.mark.parametrize("name,slice_bits,world", [("rand6_k9_fp", 8, 2), ("c2_k51_r2", 16, 2), ("rand6_k9_a3", 8, 4), ("edge_k5", 7, 4)])
-def test_combined_text_free_pass2(name, slice_bits, world, tmp_path):
+@pytest.mark.parametrize("name,slice_bits,world,aggregate", [("rand6_k9_fp", 8, 2, True), ("c2_k51_r2", 16, 2, True), ("rand6_k9_a3", 8, 4, True), ("edge_k5", 7, 4, True),
+                                                             ("c2_k125", 14, 2, True), ("rand6_k9_a3", 8, 2, False), ("c2_k51_r2", 16, 4, False)])
+def test_combined_text_free_pass2(name, slice_bits, world, aggregate, tmp_path, monkeypatch):
     """The whole enumeration with the text sharded as well (option text_window): the marks stay on the rank that hashed them, the exact
-    filter's table is sharded by key hash ((key, prev | next) records travel), every rank looks up the ids of its own positions."""
+    filter's table is sharded by key hash, every rank looks up the ids of its own positions.  What travels to the key owners: one record
+    per DISTINCT key of a rank's marks with the letter sets and count they add up to (tpc_pass2_aggregate_records: the rank's own exact
+    filter first -- an abundance cut, two-word and four-word keys, N runs), or, aggregate = False, a (key, prev | next) record per mark."""
+    if not aggregate:
+        monkeypatch.setenv("TPC_PASS2_AGGREGATE", "0")
     case = CASES[name]
     spec, o = golden_spec(name, slice_bits, tmp_path, sharded_pass2="records", text_window=True)
     spec["ranges"] = [(0, 1 << case["L"])]
@@ -134,6 +139,11 @@ def test_combined_synthetic(world, slice_bits, mode, tmp_path):
     # what travelled is far below 4 bytes per insert address: 2 bytes per DISTINCT bit of a chunk
     n_addr = 5 * 8 * 50000
     assert 0 < c["export_bytes"] * world < 3 * n_addr, c
+    # second pass: a rank sends every distinct key of its marks once (eight genomes: a key is marked up to eight times)
+    for g in gathered:
+        assert g["pass2_records_sent"] <= g["step_marks"]
+    if world <= 2:  # (at eight ranks a rank holds ONE genome: every key of its marks is already distinct)
+        assert sum(g["pass2_records_sent"] for g in gathered) < 0.7 * sum(g["step_marks"] for g in gathered)
 
 
 @pytest.mark.parametrize("world,budget", [(2, 3 << 20), (4, 3 << 20)])

@@ -20,7 +20,7 @@ HIP_SYMBOLS = ["tpc_ctx_create", "tpc_ctx_destroy", "tpc_last_error", "tpc_set_p
                "tpc_hash_dump", "tpc_kernel_ms", "tpc_set_option",
                "tpc_shard_config", "tpc_shard_plan", "tpc_shard_hash", "tpc_shard_overflow_get", "tpc_shard_overflow_set", "tpc_shard_apply",
                "tpc_shard_pack", "tpc_shard_apply_packed", "tpc_pass2_marks", "tpc_pass2_mark_owners", "tpc_pass2_filter_positions",
-               "tpc_pass2_mark_records", "tpc_pass2_filter_records", "tpc_shard_permute_rows", "tpc_emit_export", "tpc_emit_import",
+               "tpc_pass2_mark_records", "tpc_pass2_filter_records", "tpc_pass2_aggregate_records", "tpc_pass2_filter_aggregated", "tpc_shard_permute_rows", "tpc_emit_export", "tpc_emit_import",
                "tpc_shard_survivors", "tpc_shard_survivor_sources", "tpc_shard_verify_addrs", "tpc_shard_probe", "tpc_shard_mark", "tpc_mask_export", "tpc_mask_merge",
                "tpc_shard_route", "tpc_shard_permute64", "tpc_shard_select", "tpc_mask_export_padded", "tpc_mask_or_blocks", "tpc_mask_import",
                "tpc_emit_stream", "tpc_emit_stream_fetch", "tpc_host_alloc", "tpc_host_free", "tpc_get_stat", "tpc_filter_upload",
@@ -103,6 +103,8 @@ def hip():
         L.tpc_pass2_filter_positions.argtypes = [p, p, u64, u64, p, p, p]
         L.tpc_pass2_mark_records.argtypes = [p, u32, p, p]
         L.tpc_pass2_filter_records.argtypes = [p, p, u64, u64, p, p, p]
+        L.tpc_pass2_aggregate_records.argtypes = [p, u32, u64, p, p, p]
+        L.tpc_pass2_filter_aggregated.argtypes = [p, p, u64, u64, p, p, p]
         L.tpc_shard_permute_rows.argtypes = [p, p, p, u64, ci, p]
         L.tpc_shard_pack.argtypes = [p, ci, p, p, p, p]
         L.tpc_shard_apply_packed.argtypes = [p, ci, u64, p, p, p]
@@ -341,6 +343,16 @@ class Context:
     def pass2_filter_records(self, rec_ptr, n, abundance=(1 << 64) - 1):
         a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._ck(hip().tpc_pass2_filter_records(self._h, rec_ptr, n, abundance, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"true": a.value, "false": b.value, "table": c.value}
+
+    def pass2_aggregate_records(self, world, rec_ptr, owner_ptr, abundance=(1 << 64) - 1):
+        n = ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass2_aggregate_records(self._h, world, abundance, rec_ptr, owner_ptr, ctypes.byref(n)))
+        return n.value
+
+    def pass2_filter_aggregated(self, rec_ptr, n, abundance=(1 << 64) - 1):
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._ck(hip().tpc_pass2_filter_aggregated(self._h, rec_ptr, n, abundance, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return {"true": a.value, "false": b.value, "table": c.value}
 
     def shard_permute_rows(self, src_ptr, perm_ptr, n, row_words, dst_ptr):

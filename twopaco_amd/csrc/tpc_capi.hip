@@ -1197,7 +1197,10 @@ int pass1_query_impl(tpc_ctx *c, uint64_t lo, uint64_t hi, uint64_t *n_marks, bo
 
 namespace {
 int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size,
-                      bool records = false);
+                      bool records = false, bool aggregated = false);
+// aggregated records (tpc_pass2_aggregate_records): whether occurrences are counted cannot depend on how many records a rank happens to
+// hold, so it depends on the cut alone -- any abundance a key could exceed counts
+inline bool aggregated_counted(uint64_t abundance) { return abundance < (1ull << 40); }
 }
 
 int tpc_pass2_filter(tpc_ctx *c, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
@@ -1252,6 +1255,57 @@ int tpc_pass2_filter_records(tpc_ctx *c, const uint64_t *records_dev, uint64_t n
     return pass2_filter_impl(c, records_dev, n, true, abundance, n_true, n_false, table_size, true);
 }
 
+int tpc_pass2_aggregate_records(tpc_ctx *c, uint32_t world, uint64_t abundance, uint64_t *records_dev, int32_t *owner_dev, uint64_t *n_records)
+{
+    if (!c || !c->marks_valid || world == 0 || !n_records || (c->n_marks && (!records_dev || !owner_dev))) return fail(c, -1, "tpc_pass2_marks first");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_records = 0;
+    if (c->n_marks == 0) return 0;
+    const size_t sb = tpc_table_slot_bytes(c->C);
+    TpcLaunch a = make_launch(c);
+    const bool counted = aggregated_counted(abundance);
+    if (!c->scan_blocks) HIPCHK(c, hipMalloc((void **)&c->scan_blocks, 2 * TPC_SCAN2_BLOCKS * sizeof(uint64_t)));
+    uint64_t full = 1024;
+    while (full < 2 * c->n_marks + 2) full <<= 1;
+    uint64_t cap = 1024;
+    while (cap < c->n_marks / 4 + 2) cap <<= 1;
+    for (;;) {  // as pass2_filter_impl: sized for the usual ratio of marks to distinct keys, repeated at full size when a probe sequence says so
+        if (cap > c->table_alloc) {
+            if (c->table) (void)hipFree(c->table);
+            c->table = nullptr;
+            c->table_alloc = 0;
+            HIPCHK(c, dev_malloc(c, &c->table, cap * sb));
+            c->table_alloc = cap;
+        }
+        HIPCHK(c, hipMemsetAsync(c->counters + 6, 0, sizeof(unsigned long long), c->stream));
+        Timed t(c, TPC_K_FILTER2);
+        tpc_launch_table_init(c->stream, c->table, cap);
+        if (tpc_launch_filter2(a, c->C, c->marks, c->n_marks, c->table, cap, counted, c->counters + 6)) return fail(c, -1, "filter2 launch failed");
+        if (tpc_launch_scan2_count(a, c->table, cap, abundance, counted, c->scan_blocks, c->scan_blocks + TPC_SCAN2_BLOCKS, c->counters + 4))
+            return fail(c, -1, "scan2 launch failed");
+        unsigned long long three[3] = {0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(three, c->counters + 4, sizeof three, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!three[2]) {
+            *n_records = three[1];
+            if (tpc_launch_table_records(a, c->C, c->marks, c->table, cap, c->scan_blocks + TPC_SCAN2_BLOCKS, world, records_dev, owner_dev))
+                return fail(c, -1, "record launch failed");
+            break;
+        }
+        if (cap >= full) return fail(c, -1, "exact-filter table overflow at full size");
+        cap = full;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tpc_pass2_filter_aggregated(tpc_ctx *c, const uint64_t *records_dev, uint64_t n, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size)
+{
+    if (n && !records_dev) return fail(c, -1, "bad arguments");
+    return pass2_filter_impl(c, records_dev, n, true, abundance, n_true, n_false, table_size, true, true);
+}
+
 int tpc_shard_permute_rows(tpc_ctx *c, const uint64_t *src_dev, const uint32_t *perm_dev, uint64_t n, int row_words, uint64_t *dst_dev)
 {
     if (!c || row_words < 1 || (n && (!src_dev || !perm_dev || !dst_dev))) return fail(c, -1, "bad arguments");
@@ -1269,7 +1323,7 @@ namespace {
 // were compacted by tpc_pass2_marks).  Either way the round's mask is then merged into the run-wide one.
 // records: the external list holds records of C + 1 words (tpc_pass2_mark_records) instead of positions: no text access at all.
 int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, bool external, uint64_t abundance, uint64_t *n_true, uint64_t *n_false, uint64_t *table_size,
-                      bool records)
+                      bool records, bool aggregated)
 {
     if (!c || !c->have_params || !c->bases) return fail(c, -1, "set_params and seq_upload first");
     if (c->text_windowed && !records) return fail(c, -1, "this context holds only its window of the text (option text_window): the second pass needs all of it");
@@ -1287,12 +1341,13 @@ int pass2_filter_impl(tpc_ctx *c, const uint64_t *fmarks, uint64_t n_fmarks, boo
     // is repeated with 2 x marks slots, which always suffices.
     const size_t sb = tpc_table_slot_bytes(c->C);
     TpcLaunch a = make_launch(c);
-    const bool counted = abundance < n_marks;  // otherwise no key can exceed the abundance cut
+    const bool counted = aggregated ? aggregated_counted(abundance) : abundance < n_marks;  // otherwise no key can exceed the abundance cut
     if (!c->scan_blocks) HIPCHK(c, hipMalloc((void **)&c->scan_blocks, 2 * TPC_SCAN2_BLOCKS * sizeof(uint64_t)));
     uint64_t full = 1024;
     while (full < 2 * n_marks + 2) full <<= 1;
     uint64_t cap = 1024;
     while (cap < n_marks / 4 + 2) cap <<= 1;  // (marks / 8 and / 16 measured the same on M2: k_filter2 0.946 -> 0.943 / 0.944 ms)
+    if (aggregated) cap = full;               // a rank sends a key once: the records are distinct up to the number of ranks
     uint64_t tp = 0, used = 0;
     c->stat_filter2_retries = 0;
     for (;;) {

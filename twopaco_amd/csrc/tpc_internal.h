@@ -249,6 +249,8 @@ int tpc_launch_table_init(hipStream_t s, void *table, uint64_t cap);
 int tpc_launch_mark_owner(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, int32_t *owner);  // key-hash owner of every mark
 // text-free variant: records of C + 1 words (canonical key, prev | next << 3) instead of positions
 int tpc_launch_mark_records(const TpcLaunch &a, int C, const uint64_t *marks, uint64_t n_marks, uint32_t world, uint64_t *records, int32_t *owner);
+int tpc_launch_table_records(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, const uint64_t *block_off, uint32_t world,
+                             uint64_t *records, int32_t *owner);  // every used slot of a k_filter2 table as an aggregated record (block_off: scan of the used counts)
 int tpc_launch_filter2_rec(const TpcLaunch &a, int C, const uint64_t *records, uint64_t n, void *table, uint64_t cap, bool counted, unsigned long long *overflow);
 int tpc_launch_scan2_write_rec(const TpcLaunch &a, int C, const uint64_t *records, const void *table, uint64_t cap, uint64_t abundance, bool counted,
                                const uint64_t *block_off, uint64_t *keys_out);

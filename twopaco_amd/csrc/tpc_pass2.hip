@@ -406,6 +406,7 @@ k_filter2_rec(const uint64_t *__restrict__ records, uint64_t n, Slot *table, uin
 #pragma unroll
     for (int w = 0; w < C; w++) ck[w] = records[idx * (C + 1) + w];
     const uint64_t pn = records[idx * (C + 1) + C];
+    const bool agg = (pn >> 63) != 0;  // a rank's whole verdict on the key so far (k_table_records): letter sets, "seen twice", count
     const int prev = (int)(pn & 7), next = (int)((pn >> 3) & 7);
     const uint64_t mask = cap - 1;
     uint64_t slot = key_hash<C>(ck) & mask;
@@ -432,10 +433,10 @@ k_filter2_rec(const uint64_t *__restrict__ records, uint64_t n, Slot *table, uin
         slot = (slot + 1) & mask;
     }
     unsigned long long *meta = (unsigned long long *)&table[slot].meta;
-    uint64_t want = (1ull << prev) | (1ull << (META_NEXT_SHIFT + next));
-    if (!COUNTED && !claimed) want |= META_MULTI;
+    uint64_t want = agg ? (pn & ((1ull << (2 * META_NEXT_SHIFT)) - 1)) : (1ull << prev) | (1ull << (META_NEXT_SHIFT + next));
+    if (!COUNTED && (!claimed || (agg && (pn & META_MULTI)))) want |= META_MULTI;
     if ((seen_meta & want) != want) atomicOr(meta, (unsigned long long)want);
-    if (COUNTED) atomicAdd(meta, 1ull << META_COUNT_SHIFT);
+    if (COUNTED) atomicAdd(meta, agg ? (pn & ~(1ull << 63)) >> META_COUNT_SHIFT << META_COUNT_SHIFT : 1ull << META_COUNT_SHIFT);
 }
 
 __device__ __forceinline__ bool slot_is_junction(const Slot &sl, uint64_t abundance, bool counted);
@@ -546,6 +547,57 @@ k_scan2_write(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t 
 #pragma unroll
                 for (int w = 0; w < C; w++) keys_out[o * C + w] = fwd ? fw[w] : rc[w];
             }
+        }
+        base += total;
+    }
+}
+
+// Combine before routing, second pass (multi-GPU, table sharded by key hash): a rank first runs k_filter2 over ITS marks into its own
+// table and sends every DISTINCT key once, with the letter sets / "seen twice" / count its occurrences add up to (the slot's meta word,
+// bit 63 set: an aggregated record for k_filter2_rec), instead of one record per marked position -- on many-genome inputs a key is marked
+// dozens of times.  Walks the table as k_scan2_write does; block_off = exclusive scan of k_scan2_count's used slots per chunk.
+template <int C>
+__global__ void __launch_bounds__(256)
+k_table_records(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__restrict__ bases, const uint64_t *__restrict__ marks,
+                const Slot *__restrict__ table, uint64_t cap, uint64_t chunk, const uint64_t *__restrict__ block_off, uint32_t world,
+                uint64_t *__restrict__ records, int32_t *__restrict__ owner)
+{
+    __shared__ uint64_t s_h0[4];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint4 s_ct[C == 1 ? CANON_TAB : 1];
+    if (threadIdx.x < 4) s_h0[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    if (C == 1) { canon_tab_build(s_ct, s_h0, P.k, P.L, P.lmask); __syncthreads(); }
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(cap, lo + chunk);
+    uint64_t base = block_off[blockIdx.x];
+    for (uint64_t s0 = lo; s0 < hi; s0 += 256) {
+        const uint64_t s = s0 + threadIdx.x;
+        Slot sl;
+        sl.key = EMPTY; sl.meta = 0;
+        if (s < hi) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(&table[s]);
+            sl.key = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+            sl.meta = (uint64_t)raw.z | ((uint64_t)raw.w << 32);
+        }
+        const bool used = sl.key != EMPTY;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan256(used ? 1u : 0u, s_w, total);
+        if (used) {
+            const uint64_t o = base + ex;
+            uint64_t ck[C];
+            if (C == 1) ck[0] = sl.key;
+            else {
+                uint64_t fw[C], rc[C];
+                load_kmer<C>(bases, marks[sl.key], P.k, fw);
+                revcomp_kmer<C>(fw, P.k, rc);
+                const bool fwd = forward_is_canonical<C>(fw, rc, P.k, s_h0, P.L, P.lmask, s_ct);
+#pragma unroll
+                for (int w = 0; w < C; w++) ck[w] = fwd ? fw[w] : rc[w];
+            }
+#pragma unroll
+            for (int w = 0; w < C; w++) records[o * (C + 1) + w] = ck[w];
+            records[o * (C + 1) + C] = sl.meta | (1ull << 63);
+            owner[o] = (int32_t)((key_hash<C>(ck) >> 40) % world);
         }
         base += total;
     }
@@ -790,6 +842,22 @@ int TPC_PASS2_FN(tpc_launch_mark_records)(const TpcLaunch &a, int C, const uint6
     if (C > 2) return tpc_launch_mark_records_long(a, C, marks, n_marks, world, records, owner);
 #endif
 #define CALL(C_) hipLaunchKernelGGL((k_mark_records<C_>), dim3(nblk(n_marks, 256)), dim3(256), 0, a.stream, a.P, a.tab, a.bases, a.nmask, marks, n_marks, world, records, owner)
+    TPC_DISPATCH_C(C, CALL)
+#undef CALL
+    return 0;
+}
+
+int tpc_launch_table_records_long(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, const uint64_t *block_off, uint32_t world,
+                                  uint64_t *records, int32_t *owner);
+uint64_t TPC_PASS2_FN(tpc_scan2_chunk)(uint64_t cap);
+int TPC_PASS2_FN(tpc_launch_table_records)(const TpcLaunch &a, int C, const uint64_t *marks, const void *table, uint64_t cap, const uint64_t *block_off, uint32_t world,
+                                           uint64_t *records, int32_t *owner)
+{
+#if TPC_PASS2_PART == 0
+    if (C > 2) return tpc_launch_table_records_long(a, C, marks, table, cap, block_off, world, records, owner);
+#endif
+    const uint64_t chunk = TPC_PASS2_FN(tpc_scan2_chunk)(cap);
+#define CALL(C_) hipLaunchKernelGGL((k_table_records<C_>), dim3(TPC_SCAN2_BLOCKS), dim3(256), 0, a.stream, a.P, a.tab, a.bases, marks, (const Slot *)table, cap, chunk, block_off, world, records, owner)
     TPC_DISPATCH_C(C, CALL)
 #undef CALL
     return 0;

@@ -874,16 +874,23 @@ class AddressSharded:
             rw = ctx.key_words() + 1
             rec = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
             owner = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            self._try(ctx.pass2_mark_records, W, rec.data_ptr(), owner.data_ptr())
-            perm = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-            counts = self._try(ctx.shard_route, owner.data_ptr(), n, perm.data_ptr(), W, default=zeros)
-            send = torch.empty(max(n, 1) * rw, dtype=torch.int64, device=self.device)
-            self._try(ctx.shard_permute_rows, rec.data_ptr(), perm.data_ptr(), n, rw, send.data_ptr())
-            recv, rcl = self.comm.a2a_var(send[:n * rw].contiguous(), [c * rw for c in counts])
+            # combine before routing: one record per DISTINCT key of this rank's marks (its own exact filter first), not one per mark
+            agg = os.environ.get("TPC_PASS2_AGGREGATE", "1") != "0"
+            nr = n
+            if agg:
+                nr = self._try(ctx.pass2_aggregate_records, W, rec.data_ptr(), owner.data_ptr(), abundance, default=0)
+            else:
+                self._try(ctx.pass2_mark_records, W, rec.data_ptr(), owner.data_ptr())
+            perm = torch.empty(max(nr, 1), dtype=torch.int32, device=self.device)
+            counts = self._try(ctx.shard_route, owner.data_ptr(), nr, perm.data_ptr(), W, default=zeros)
+            send = torch.empty(max(nr, 1) * rw, dtype=torch.int64, device=self.device)
+            self._try(ctx.shard_permute_rows, rec.data_ptr(), perm.data_ptr(), nr, rw, send.data_ptr())
+            recv, rcl = self.comm.a2a_var(send[:nr * rw].contiguous(), [c * rw for c in counts])
             recv = recv.contiguous()
             self.comm.sync()
             self.stats["pass2_recv_bytes_busiest_peer"] = 8 * max([c for r, c in enumerate(rcl) if r != self.rank] or [0])
-            st = self._try(ctx.pass2_filter_records, recv.data_ptr(), recv.numel() // rw, abundance, default=dict(none))
+            self.stats["pass2_records_sent"] = nr
+            st = self._try(ctx.pass2_filter_aggregated if agg else ctx.pass2_filter_records, recv.data_ptr(), recv.numel() // rw, abundance, default=dict(none))
             st["marks"] = n
             self.stats["pass2_positions_received"] = recv.numel() // rw
             self._tick("pass2_sharded", t0)

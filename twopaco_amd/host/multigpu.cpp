@@ -944,12 +944,17 @@ namespace TwoPaCo
 		const size_t rowBytes = size_t(rowWords) * 8;
 		uint64_t * records = static_cast<uint64_t*>(r.Ensure(REC, std::max<uint64_t>(n, 1) * rowBytes));
 		int32_t * owner = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(n, 1) * 4));
-		LibCheck(r.ctx, tpc_pass2_mark_records(r.ctx, uint32_t(W), records, owner), "pass2_mark_records");
-		uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(n, 1) * 4));
+		// combine before routing: the rank's own exact filter first, then one record per DISTINCT key (sets, "seen twice", count) instead
+		// of one per marked position (TWOPACO_PASS2_AGGREGATE=0: the per-position records of rounds 3-5)
+		static const bool aggregate = !(std::getenv("TWOPACO_PASS2_AGGREGATE") && std::getenv("TWOPACO_PASS2_AGGREGATE")[0] == '0');
+		uint64_t rows = n;
+		if (aggregate) LibCheck(r.ctx, tpc_pass2_aggregate_records(r.ctx, uint32_t(W), abundance, records, owner, &rows), "pass2_aggregate_records");
+		else LibCheck(r.ctx, tpc_pass2_mark_records(r.ctx, uint32_t(W), records, owner), "pass2_mark_records");
+		uint32_t * perm = static_cast<uint32_t*>(r.Ensure(MISC_A, std::max<uint64_t>(rows, 1) * 4));
 		uint64_t counts[64];
-		LibCheck(r.ctx, tpc_shard_route(r.ctx, owner, n, perm, counts), "shard_route");
-		uint64_t * send = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(n, 1) * rowBytes));
-		LibCheck(r.ctx, tpc_shard_permute_rows(r.ctx, records, perm, n, rowWords, send), "shard_permute_rows");
+		LibCheck(r.ctx, tpc_shard_route(r.ctx, owner, rows, perm, counts), "shard_route");
+		uint64_t * send = static_cast<uint64_t*>(r.Ensure(MISC_B, std::max<uint64_t>(rows, 1) * rowBytes));
+		LibCheck(r.ctx, tpc_shard_permute_rows(r.ctx, records, perm, rows, rowWords, send), "shard_permute_rows");
 		std::vector<uint64_t> all;
 		net.ExchangeHost(r.rank, counts, W, all);
 		std::vector<uint64_t> recvCounts(W);
@@ -963,7 +968,8 @@ namespace TwoPaCo
 		uint64_t * mine = static_cast<uint64_t*>(r.Ensure(REC2, std::max<uint64_t>(arriving, 1) * rowBytes));
 		net.AllToAllV(r.rank, send, counts, mine, recvCounts.data(), rowBytes);
 		uint64_t truePositives = 0, falsePositives = 0, tableSize = 0;
-		LibCheck(r.ctx, tpc_pass2_filter_records(r.ctx, mine, arriving, abundance, &truePositives, &falsePositives, &tableSize), "pass2_filter_records");
+		if (aggregate) LibCheck(r.ctx, tpc_pass2_filter_aggregated(r.ctx, mine, arriving, abundance, &truePositives, &falsePositives, &tableSize), "pass2_filter_aggregated");
+		else LibCheck(r.ctx, tpc_pass2_filter_records(r.ctx, mine, arriving, abundance, &truePositives, &falsePositives, &tableSize), "pass2_filter_records");
 		counters[0] = truePositives; counters[1] = falsePositives; counters[2] = tableSize; counters[3] = n;
 	}
 
