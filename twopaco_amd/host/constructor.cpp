@@ -61,7 +61,7 @@ namespace
 			<< "               [--seed <integer>] [--device <integer>] [--test-first] [--gpus <power of two>] [--no-rccl]" << std::endl
 			<< "               [--save-filter <file>] [--load-filter <file>]" << std::endl
 			<< "               <fasta files with genomes> ..." << std::endl
-			<< "       -q: 1..64 hash functions (the reference takes any number; more than 16 run on slower closed-form kernels, one GPU)" << std::endl;
+			<< "       -q: 1..64 hash functions (the reference takes any number; more than 16 run on slower closed-form kernels)" << std::endl;
 	}
 }
 
