@@ -1,6 +1,7 @@
 // tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi.hip) and the kernels.
 #pragma once
 #include "tpc_device.h"
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -10,6 +11,7 @@
 struct TpcEnv {
     bool no_lean, rb_hash, verify_eager, gated_full;
     int ppr_insert, gated_loads, split_loads9;  // 0: not set
+    int slice_grid;  // workgroups of a one-slice-at-a-time kernel (tpc_slice_grid); 0: one per slice
     static const TpcEnv &get()
     {
         static const TpcEnv e = [] {
@@ -24,11 +26,25 @@ struct TpcEnv {
             v.gated_loads = g ? atoi(g) : 0;
             const char *s9 = getenv("TPC_SPLIT_LOADS9");  // (measurements: entries per thread and round of k_part_split at 512 bins)
             v.split_loads9 = s9 ? atoi(s9) : 0;
+            // two long-lived workgroups per CU (one resident beside a 128 KB slice, one queued) unless TPC_LOOKUP_GRID says otherwise
+            const char *lg = getenv("TPC_LOOKUP_GRID");
+            int n_cu = 0, dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) { (void)hipGetLastError(); n_cu = 256; }
+            v.slice_grid = lg ? atoi(lg) : 2 * n_cu;
             return v;
         }();
         return e;
     }
 };
+
+// Grid of a kernel that builds or reads one filter slice at a time in LDS: a few long-lived workgroups, each taking every grid-th slice
+// (round 6, same-box A/B on the 62-genome step: k_apply_lookup6 5.83 ms as 65536 workgroups, 5.48 as 512 -- the dispatch of a workgroup
+// per 22 us of work was not free after all; profiles/r06_lookup_grid_ab.txt).
+inline uint32_t tpc_slice_grid(uint32_t n_slices)
+{
+    const int g = TpcEnv::get().slice_grid;
+    return g > 0 ? std::min<uint32_t>(n_slices, (uint32_t)g) : n_slices;
+}
 
 #define TPC_TAB_MAXQ 64                // = TPC_MAX_Q (include/twopaco_hip.h)
 #define TPC_KERNEL_MAXQ 16             // the rolling kernels are instantiated for 1..16 functions; beyond that tpc_pass1_anyq.hip

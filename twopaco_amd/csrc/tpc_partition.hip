@@ -531,37 +531,41 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
 template <bool P3>  // the regions are blocked lines of 40 x 24-bit entries (see k_part_split)
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-             uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm, PtShard sh)
+             uint64_t cap2, uint32_t *__restrict__ filter, int fresh, PtPerm perm, PtShard sh, uint32_t n_slices)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *slice = reinterpret_cast<uint32_t *>(smem);
     const uint32_t words = 1u << (slice_bits - 5);
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);  // local bucket, sub-bucket
-    // whole filter: natural slice position of permuted slice blockIdx; shard: compact [local bucket][b2]
-    uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
-    const bool wide = (words & 3u) == 0;  // 16-byte accesses whenever the slice allows
-    if (fresh) {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
-    } else {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
+    // a long-lived workgroup takes every gridDim.x-th slice (tpc_internal.h:tpc_slice_grid)
+    for (uint32_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+        const uint32_t b1 = sl >> log_nb2, b2 = sl & (nb2 - 1);  // local bucket, sub-bucket
+        // whole filter: natural slice position of permuted slice blockIdx; shard: compact [local bucket][b2]
+        uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(sl) : sl) * words;
+        const bool wide = (words & 3u) == 0;  // 16-byte accesses whenever the slice allows
+        if (fresh) {
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
+        } else {
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < wpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+            if constexpr (P3) {
+                PlStream<PFmt3, PT_APPLY_THREADS, 1> is;
+                is.begin(reinterpret_cast<const unsigned char *>(buf2) + r * (cap2 / PFmt3::GROUP) * PT_LINE, n);
+                is.finish([slice](uint32_t v, uint32_t) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+            } else
+            pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + r * cap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+        }
+        __syncthreads();
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t j = 0; j < wpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
-        if constexpr (P3) {
-            PlStream<PFmt3, PT_APPLY_THREADS, 1> is;
-            is.begin(reinterpret_cast<const unsigned char *>(buf2) + r * (cap2 / PFmt3::GROUP) * PT_LINE, n);
-            is.finish([slice](uint32_t v, uint32_t) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
-        } else
-        pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + r * cap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
-    }
-    __syncthreads();
-    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
-    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
 }
 
 // ------------------------------------------------------------------------------------------ level 4
@@ -927,16 +931,16 @@ int tpc_launch_insert_part_apply_only(const TpcLaunch &a, const TpcPartPlan &pl,
     const PtShard sh{pl.rank, pl.world};
     if (pl.fmt2 == 3) {  // planar 24-bit regions (two levels, one rank)
         (void)hipFuncSetAttribute((const void *)k_part_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_part_apply<true>, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                           pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+        hipLaunchKernelGGL(k_part_apply<true>, dim3(tpc_slice_grid((1u << (pl.b1 + pl.b2)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                           pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh, (uint32_t)((1u << (pl.b1 + pl.b2)) / pl.world));
     } else {
         (void)hipFuncSetAttribute((const void *)k_part_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (pl.b3)  // regions of the third level: [(b1, b2)][j][b3]
-            hipLaunchKernelGGL(k_part_apply<false>, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
-                               pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh);
+            hipLaunchKernelGGL(k_part_apply<false>, dim3(tpc_slice_grid((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+                               pl.cnt3, pl.cap3, a.filter, fresh ? 1 : 0, perm, sh, (uint32_t)((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world));
         else
-            hipLaunchKernelGGL(k_part_apply<false>, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                               pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh);
+            hipLaunchKernelGGL(k_part_apply<false>, dim3(tpc_slice_grid((1u << (pl.b1 + pl.b2)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                               pl.buf2, pl.cnt2, pl.cap2, a.filter, fresh ? 1 : 0, perm, sh, (uint32_t)((1u << (pl.b1 + pl.b2)) / pl.world));
     }
     hipLaunchKernelGGL(k_part_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, perm, sh, pl.b2 + pl.b3);
     return 0;

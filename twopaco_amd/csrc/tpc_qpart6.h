@@ -46,7 +46,7 @@ struct Q6Res {
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup6(int slice_bits, int log_nb2, uint32_t wpb, const unsigned char *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
             const uint64_t *__restrict__ off2, const uint32_t *__restrict__ bnd, uint32_t n_groups, uint32_t pb2, const uint32_t *__restrict__ filter, uint64_t *surv,
-            unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group)
+            unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, uint32_t n_slices)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
@@ -55,34 +55,38 @@ k_q_lookup6(int slice_bits, int log_nb2, uint32_t wpb, const unsigned char *__re
     uint32_t *s_bnd = reinterpret_cast<uint32_t *>(st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits));
     st.group = group;
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    const uint32_t *src_slice = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
-    if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
-    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
-    if (threadIdx.x == 0) st.ctl[0] = 0;
-    const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
-    st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
-    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
-    const Q6Res res{s_bnd, n_groups, pb2};
-    for (uint32_t j = 0; j < wpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        if (j) st.flush(res);  // what is staged belongs to the previous region's boundaries
-        __syncthreads();       // (first time round: the slice is loaded)
-        if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r * 2u * n_groups + threadIdx.x];
+    // a long-lived workgroup takes every gridDim.x-th slice (tpc_internal.h:tpc_slice_grid)
+    for (uint32_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+        const uint32_t b1 = sl >> log_nb2, b2 = sl & (nb2 - 1);
+        const uint32_t *src_slice = filter + (uint64_t)perm.slice_of(sl) * words;
+        if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
+        if (threadIdx.x == 0) st.ctl[0] = 0;
+        const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
+        st.list = sl % QS_LISTS;
+        st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
+        st.surv_cur = surv_cur; st.surv_cap = surv_cap;
+        const Q6Res res{s_bnd, n_groups, pb2};
+        for (uint32_t j = 0; j < wpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
+            if (j) st.flush(res);  // what is staged belongs to the previous region's boundaries
+            __syncthreads();       // (first time round: the slice is loaded)
+            if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r * 2u * n_groups + threadIdx.x];
+            __syncthreads();
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+            auto probe = [&](uint64_t v, uint32_t idx) {
+                const uint32_t a = (uint32_t)v & slice_mask;
+                if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(res.raw(v, S, idx), a, res);
+            };
+            PlStream<PFmt6, PT_APPLY_THREADS, 1> q;
+            q.begin(buf2 + off2[r] * PT_LINE, n);
+            if (n > QL_LONG_REGION) q.finish_with(probe, [&]() { st.maybe_flush(res); });  // (uniform; see k_q_lookup)
+            else q.finish(probe);
+            st.maybe_flush(res);
+        }
+        st.flush(res);
         __syncthreads();
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
-        auto probe = [&](uint64_t v, uint32_t idx) {
-            const uint32_t a = (uint32_t)v & slice_mask;
-            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(res.raw(v, S, idx), a, res);
-        };
-        PlStream<PFmt6, PT_APPLY_THREADS, 1> q;
-        q.begin(buf2 + off2[r] * PT_LINE, n);
-        if (n > QL_LONG_REGION) q.finish_with(probe, [&]() { st.maybe_flush(res); });  // (uniform; see k_q_lookup)
-        else q.finish(probe);
-        st.maybe_flush(res);
     }
-    st.flush(res);
 }
 
 // Fused k_part_apply + k_q_lookup6 (deferred apply, tpc_partition.hip): the workgroup of a slice ORs the insert's level-2 entries
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2_lines, int fresh,
                 const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const unsigned char *__restrict__ qbuf2,
                 const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2, const uint32_t *__restrict__ bnd, uint32_t n_groups, uint32_t pb2,
-                uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, TpcListSrc ls)
+                uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, TpcListSrc ls, uint32_t n_slices)
 {   // ls (ls.n_src > 0: the combined multi-GPU exchange, tpc_lists.h): set-bit lists of the slice, from this and the other ranks' inserts
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
@@ -106,81 +110,89 @@ k_apply_lookup6(int slice_bits, int log_nb2, uint32_t iwpb, const unsigned char 
     uint32_t *s_bnd = reinterpret_cast<uint32_t *>(st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits));
     st.group = group;
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    uint32_t *out = filter + (uint64_t)perm.slice_of(blockIdx.x) * words;
-    const bool wide = (words & 3u) == 0;
-    TpcListReader<PT_APPLY_THREADS> lists;
-    PlStream<PFmt6, PT_APPLY_THREADS, 1> q0;
-    const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
-    if constexpr (LISTS) {
-        lists.begin(ls, b1, b2, log_nb2, blockIdx.x, slice_bits);
-        if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
-        q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
-    }
-    // ---- apply
-    if (fresh) {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
-    } else {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
-    }
-    if (threadIdx.x == 0) st.ctl[0] = 0;
-    __syncthreads();
-    if constexpr (LISTS) lists.finish(ls, slice);
-    else
-    for (uint32_t j = 0; j < iwpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
-        if constexpr (I3) {
-            PlStream<PFmt3, PT_APPLY_THREADS, 1> is;
-            is.begin(ibuf2 + r * icap2_lines * PT_LINE, n);
-            is.finish([slice](uint32_t v, uint32_t) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+    // a long-lived workgroup takes every gridDim.x-th slice (tpc_internal.h:tpc_slice_grid).  Not the LISTS and I3 instantiations: the
+    // loop's live values cost them 40 / 19 spilled registers of the 128 a 1024-thread workgroup has, and the lists' ~12 us per slice are
+    // round trips that only separate workgroups overlap (4.6 against 2.9 ms per rank at eight ranks): launched one workgroup per slice.
+    constexpr bool LONG_LIVED = !LISTS && !I3;
+    for (uint32_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+        const uint32_t b1 = sl >> log_nb2, b2 = sl & (nb2 - 1);
+        uint32_t *out = filter + (uint64_t)perm.slice_of(sl) * words;
+        const bool wide = (words & 3u) == 0;
+        TpcListReader<PT_APPLY_THREADS> lists;
+        PlStream<PFmt6, PT_APPLY_THREADS, 1> q0;
+        const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
+        if constexpr (LISTS) {
+            lists.begin(ls, b1, b2, log_nb2, sl, slice_bits);
+            if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
+            q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+        }
+        // ---- apply
+        if (fresh) {
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
         } else {
-            pt_stream_region<PT_APPLY_THREADS, 2>(reinterpret_cast<const uint32_t *>(ibuf2) + r * icap2_lines * 32u, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
         }
-    }
-    // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
-    if (!LISTS && iovf_off) {
-        const uint64_t o0 = iovf_off[blockIdx.x], o1 = iovf_off[blockIdx.x + 1];
-        for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
-            const uint64_t a = iovf[i];
-            atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+        if (threadIdx.x == 0) st.ctl[0] = 0;
+        __syncthreads();
+        if constexpr (LISTS) lists.finish(ls, slice);
+        else
+        for (uint32_t j = 0; j < iwpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
+            if constexpr (I3) {
+                PlStream<PFmt3, PT_APPLY_THREADS, 1> is;
+                is.begin(ibuf2 + r * icap2_lines * PT_LINE, n);
+                is.finish([slice](uint32_t v, uint32_t) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+            } else {
+                pt_stream_region<PT_APPLY_THREADS, 2>(reinterpret_cast<const uint32_t *>(ibuf2) + r * icap2_lines * 32u, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+            }
         }
-    }
-    if (!LISTS && threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
-    __syncthreads();
-    // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
-    if constexpr (!LISTS) q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
-    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
-    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
-    // ---- lookup against the slice still in LDS
-    const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
-    st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
-    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
-    const Q6Res res{s_bnd, n_groups, pb2};
-    auto probe = [&](uint64_t v, uint32_t idx) {
-        const uint32_t a = (uint32_t)v & slice_mask;
-        if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(res.raw(v, S, idx), a, res);
-    };
-    for (uint32_t j = 0; j < qwpb; j++) {
-        const uint64_t r = r0 + (uint64_t)j * nb2;
-        if (j == 0) {
-            if (q0.n > QL_LONG_REGION) q0.finish_with(probe, [&]() { st.maybe_flush(res); });  // (uniform; see k_q_lookup)
-            else q0.finish(probe);
-        } else {
-            st.flush(res);  // what is staged belongs to the previous region's boundaries
-            __syncthreads();
-            if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r * 2u * n_groups + threadIdx.x];
-            __syncthreads();
-            const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
-            PlStream<PFmt6, PT_APPLY_THREADS, 1> q;
-            q.begin(qbuf2 + qoff2[r] * PT_LINE, nq);
-            if (nq > QL_LONG_REGION) q.finish_with(probe, [&]() { st.maybe_flush(res); });
-            else q.finish(probe);
+        // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
+        if (!LISTS && iovf_off) {
+            const uint64_t o0 = iovf_off[sl], o1 = iovf_off[sl + 1];
+            for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
+                const uint64_t a = iovf[i];
+                atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+            }
         }
-        st.maybe_flush(res);
+        if (!LISTS && threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r0 * 2u * n_groups + threadIdx.x];
+        __syncthreads();
+        // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
+        if constexpr (!LISTS) q0.begin(qbuf2 + qoff2[r0] * PT_LINE, (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
+        // ---- lookup against the slice still in LDS
+        const uint32_t slice_mask = (1u << slice_bits) - 1u, S = (uint32_t)slice_bits;
+        st.list = sl % QS_LISTS;
+        st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
+        st.surv_cur = surv_cur; st.surv_cap = surv_cap;
+        const Q6Res res{s_bnd, n_groups, pb2};
+        auto probe = [&](uint64_t v, uint32_t idx) {
+            const uint32_t a = (uint32_t)v & slice_mask;
+            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(res.raw(v, S, idx), a, res);
+        };
+        for (uint32_t j = 0; j < qwpb; j++) {
+            const uint64_t r = r0 + (uint64_t)j * nb2;
+            if (j == 0) {
+                if (q0.n > QL_LONG_REGION) q0.finish_with(probe, [&]() { st.maybe_flush(res); });  // (uniform; see k_q_lookup)
+                else q0.finish(probe);
+            } else {
+                st.flush(res);  // what is staged belongs to the previous region's boundaries
+                __syncthreads();
+                if (threadIdx.x < 2u * n_groups) s_bnd[threadIdx.x] = bnd[r * 2u * n_groups + threadIdx.x];
+                __syncthreads();
+                const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
+                PlStream<PFmt6, PT_APPLY_THREADS, 1> q;
+                q.begin(qbuf2 + qoff2[r] * PT_LINE, nq);
+                if (nq > QL_LONG_REGION) q.finish_with(probe, [&]() { st.maybe_flush(res); });
+                else q.finish(probe);
+            }
+            st.maybe_flush(res);
+        }
+        st.flush(res);
+        if constexpr (!LONG_LIVED) break;
+        __syncthreads();
     }
-    st.flush(res);
 }

@@ -738,7 +738,7 @@ struct SurvStage {
 
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
-           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh, int group)
+           const uint64_t *__restrict__ off2, const uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, PtShard sh, int group, uint32_t n_slices)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t words = 1u << (slice_bits - 5);
@@ -747,33 +747,37 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
     st.carve(reinterpret_cast<unsigned char *>(slice + ((words + 3u) & ~3u)), slice_bits);
     st.group = group;
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    // whole filter: natural position of permuted slice blockIdx; shard: compact [local bucket][b2]
-    const uint32_t *src_slice = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
-    if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
-    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
-    if (threadIdx.x == 0) st.ctl[0] = 0;
-    __syncthreads();
-    const uint32_t slice_mask = (1u << slice_bits) - 1u;
-    st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
-    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
-    for (uint32_t j = 0; j < wpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
-        auto probe = [&](uint64_t v) {
-            const uint32_t a = (uint32_t)v & slice_mask;
-            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
-        };
-        // A long region (a small filter under a large batch: 200 K entries per slice at f = 34 with 0.56 G positions) would fill the
-        // 3072-entry staging area many times over before its end, and every survivor beyond it costs a same-address global atomic
-        // (75 ms per lookup there instead of 8): such a region flushes the staging area every 8192 entries.  (Not the short ones: two
-        // barriers per 8192 entries would be ~5 % of a 28 K-entry slice of the 62-genome workload.)
-        if (n > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe, [&]() { st.maybe_flush(); });
-        else pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe);
-        st.maybe_flush();
+    // a long-lived workgroup takes every gridDim.x-th slice (tpc_internal.h:tpc_slice_grid)
+    for (uint32_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+        const uint32_t b1 = sl >> log_nb2, b2 = sl & (nb2 - 1);
+        // whole filter: natural position of permuted slice blockIdx; shard: compact [local bucket][b2]
+        const uint32_t *src_slice = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(sl) : sl) * words;
+        if ((words & 3u) == 0) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(src_slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = src_slice[i];
+        if (threadIdx.x == 0) st.ctl[0] = 0;
+        __syncthreads();
+        const uint32_t slice_mask = (1u << slice_bits) - 1u;
+        st.list = sl % QS_LISTS;
+        st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
+        st.surv_cur = surv_cur; st.surv_cap = surv_cap;
+        for (uint32_t j = 0; j < wpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * wpb + j) * nb2 + b2;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt2[r]);
+            auto probe = [&](uint64_t v) {
+                const uint32_t a = (uint32_t)v & slice_mask;
+                if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
+            };
+            // A long region (a small filter under a large batch: 200 K entries per slice at f = 34 with 0.56 G positions) would fill the
+            // 3072-entry staging area many times over before its end, and every survivor beyond it costs a same-address global atomic
+            // (75 ms per lookup there instead of 8): such a region flushes the staging area every 8192 entries.  (Not the short ones: two
+            // barriers per 8192 entries would be ~5 % of a 28 K-entry slice of the 62-genome workload.)
+            if (n > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe, [&]() { st.maybe_flush(); });
+            else pt_stream_region<PT_APPLY_THREADS, 2>(buf2 + off2[r], n, probe);
+            st.maybe_flush();
+        }
+        st.flush();
+        __syncthreads();
     }
-    st.flush();
 }
 
 // ------------------------------------------------------------------------------------------ C'
@@ -788,7 +792,7 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__restrict__ ibuf2, const uint32_t *__restrict__ icnt2, uint64_t icap2, int fresh,
                const uint64_t *__restrict__ iovf, const uint64_t *__restrict__ iovf_off, uint32_t qwpb, const uint64_t *__restrict__ qbuf2, const uint32_t *__restrict__ qcnt2, const uint64_t *__restrict__ qoff2,
-               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, PtShard sh, TpcListSrc ls)
+               uint32_t *__restrict__ filter, uint64_t *surv, unsigned long long *surv_cur, uint64_t surv_cap, PtPerm perm, int group, PtShard sh, TpcListSrc ls, uint32_t n_slices)
 {   // ls (ls.n_src > 0, sh.world == 1: the combined multi-GPU exchange, tpc_lists.h): set-bit lists of the slice, from this and the other ranks' inserts
     // sh.world > 1 (round 5): the owned slices of a sharded filter, compact layout [local bucket][b2] as k_part_apply / k_q_lookup write and read it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -799,66 +803,70 @@ k_apply_lookup(int slice_bits, int log_nb2, uint32_t iwpb, const uint32_t *__res
     st.group = group;
     uint32_t *s_ctl = st.ctl;
     const uint32_t nb2 = 1u << log_nb2;
-    const uint32_t b1 = blockIdx.x >> log_nb2, b2 = blockIdx.x & (nb2 - 1);
-    uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(blockIdx.x) : blockIdx.x) * words;
-    const bool wide = (words & 3u) == 0;
-    TpcListReader<PT_APPLY_THREADS> lists;  // (their first loads go out before the slice is zeroed)
-    if (ls.n_src) lists.begin(ls, b1, b2, log_nb2, blockIdx.x, slice_bits);
-    // ---- apply (k_part_apply)
-    if (fresh) {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
-    } else {
-        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
-        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
-    }
-    if (threadIdx.x == 0) s_ctl[0] = 0;
-    __syncthreads();
-    for (uint32_t j = 0; j < iwpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
-        pt_stream_region<PT_APPLY_THREADS, 2>(ibuf2 + r * icap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
-    }
-    // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
-    if (iovf_off) {
-        const uint64_t o0 = iovf_off[blockIdx.x], o1 = iovf_off[blockIdx.x + 1];
-        for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
-            const uint64_t a = iovf[i];
-            atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
-        }
-    }
-    if (ls.n_src) lists.finish(ls, slice);
-    __syncthreads();
-    // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
-    PtStream<PT_APPLY_THREADS, 2, uint64_t> q0;
-    {
-        const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
-        q0.begin(qbuf2 + qoff2[r0], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
-    }
-    if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
-    else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
-    // ---- lookup (k_q_lookup) against the slice still in LDS
-    const uint32_t slice_mask = (1u << slice_bits) - 1u;
-    st.list = blockIdx.x % QS_LISTS;
-    st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
-    st.surv_cur = surv_cur; st.surv_cap = surv_cap;
-    for (uint32_t j = 0; j < qwpb; j++) {
-        const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
-        auto probe = [&](uint64_t v) {
-            const uint32_t a = (uint32_t)v & slice_mask;
-            if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
-        };
-        if (j == 0) {
-            if (q0.n > QL_LONG_REGION) q0.finish_with(probe, [&]() { st.maybe_flush(); });  // (uniform; see k_q_lookup)
-            else q0.finish(probe);
+    // a long-lived workgroup takes every gridDim.x-th slice (tpc_internal.h:tpc_slice_grid)
+    for (uint32_t sl = blockIdx.x; sl < n_slices; sl += gridDim.x) {
+        const uint32_t b1 = sl >> log_nb2, b2 = sl & (nb2 - 1);
+        uint32_t *out = filter + (uint64_t)(sh.world == 1 ? perm.slice_of(sl) : sl) * words;
+        const bool wide = (words & 3u) == 0;
+        TpcListReader<PT_APPLY_THREADS> lists;  // (their first loads go out before the slice is zeroed)
+        if (ls.n_src) lists.begin(ls, b1, b2, log_nb2, sl, slice_bits);
+        // ---- apply (k_part_apply)
+        if (fresh) {
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = make_uint4(0, 0, 0, 0);
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = 0;
         } else {
-            const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
-            if (nq > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe, [&]() { st.maybe_flush(); });
-            else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe);
+            if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(slice)[i] = reinterpret_cast<const uint4 *>(out)[i];
+            else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) slice[i] = out[i];
         }
-        st.maybe_flush();
+        if (threadIdx.x == 0) s_ctl[0] = 0;
+        __syncthreads();
+        for (uint32_t j = 0; j < iwpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * iwpb + j) * nb2 + b2;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)icnt2[r]);
+            pt_stream_region<PT_APPLY_THREADS, 2>(ibuf2 + r * icap2, n, [slice](uint32_t v) { atomicOr(&slice[v >> 5], 1u << (v & 31u)); });
+        }
+        // the insert's overflow entries (permuted addresses that found a ring or region full), grouped by slice beforehand
+        if (iovf_off) {
+            const uint64_t o0 = iovf_off[sl], o1 = iovf_off[sl + 1];
+            for (uint64_t i = o0 + threadIdx.x; i < o1; i += PT_APPLY_THREADS) {
+                const uint64_t a = iovf[i];
+                atomicOr(&slice[((uint32_t)a & ((1u << slice_bits) - 1u)) >> 5], 1u << ((uint32_t)a & 31u));
+            }
+        }
+        if (ls.n_src) lists.finish(ls, slice);
+        __syncthreads();
+        // the first query region's loads go out before the slice's stores: the 128 KB write-out then drains under them
+        PtStream<PT_APPLY_THREADS, 2, uint64_t> q0;
+        {
+            const uint64_t r0 = ((uint64_t)b1 * qwpb) * nb2 + b2;
+            q0.begin(qbuf2 + qoff2[r0], (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r0]));
+        }
+        if (wide) for (uint32_t i = threadIdx.x; i < words / 4; i += PT_APPLY_THREADS) reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(slice)[i];
+        else for (uint32_t i = threadIdx.x; i < words; i += PT_APPLY_THREADS) out[i] = slice[i];
+        // ---- lookup (k_q_lookup) against the slice still in LDS
+        const uint32_t slice_mask = (1u << slice_bits) - 1u;
+        st.list = sl % QS_LISTS;
+        st.my_list = surv + (uint64_t)st.list * surv_cap; st.surv0 = surv;
+        st.surv_cur = surv_cur; st.surv_cap = surv_cap;
+        for (uint32_t j = 0; j < qwpb; j++) {
+            const uint64_t r = ((uint64_t)b1 * qwpb + j) * nb2 + b2;
+            auto probe = [&](uint64_t v) {
+                const uint32_t a = (uint32_t)v & slice_mask;
+                if ((slice[a >> 5] >> (a & 31u)) & 1u) st.push(v >> QE_E_SHIFT, a);
+            };
+            if (j == 0) {
+                if (q0.n > QL_LONG_REGION) q0.finish_with(probe, [&]() { st.maybe_flush(); });  // (uniform; see k_q_lookup)
+                else q0.finish(probe);
+            } else {
+                const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcnt2[r]);
+                if (nq > QL_LONG_REGION) pt_stream_region_with<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe, [&]() { st.maybe_flush(); });
+                else pt_stream_region<PT_APPLY_THREADS, 2>(qbuf2 + qoff2[r], nq, probe);
+            }
+            st.maybe_flush();
+        }
+        st.flush();
+        __syncthreads();
     }
-    st.flush();
 }
 
 // Region-overflow entries: first probe straight from the filter; hits join sub-list 0.
@@ -1973,8 +1981,8 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
         (void)hipFuncSetAttribute((const void *)k_q_lookup6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_q_lookup6, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, (const unsigned char *)pl.buf2,
-                           pl.cnt2, pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0);
+        hipLaunchKernelGGL(k_q_lookup6, dim3(tpc_slice_grid(1u << (pl.b1 + pl.b2))), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb, (const unsigned char *)pl.buf2,
+                           pl.cnt2, pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, (uint32_t)(1u << (pl.b1 + pl.b2)));
         hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
         return 0;
     }
@@ -1992,11 +2000,11 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_q_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (pl.b3)
-            hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
-                               pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0);
+            hipLaunchKernelGGL(k_q_lookup, dim3(tpc_slice_grid((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b3, pl.wpb3, pl.buf3,
+                               pl.cnt3, pl.off3, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0, (uint32_t)((1u << (pl.b1 + pl.b2 + pl.b3)) / pl.world));
         else
-            hipLaunchKernelGGL(k_q_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
-                               pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0);
+            hipLaunchKernelGGL(k_q_lookup, dim3(tpc_slice_grid((1u << (pl.b1 + pl.b2)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, pl.wpb,
+                               pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.group_survivors ? 1 : 0, (uint32_t)((1u << (pl.b1 + pl.b2)) / pl.world));
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm,
                        sh, pl.b2 + pl.b3);
@@ -2018,20 +2026,23 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         if (!pl.presplit) launch_qsplit6(a, pl, ovf);
         const size_t words = (size_t)1 << (pl.slice_bits - 5);
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL6_LDS;
+        const uint32_t al6_slices = 1u << (pl.b1 + pl.b2), al6_grid = tpc_slice_grid(al6_slices);  // long-lived workgroups, each taking every al6_grid-th slice
 #define TPC_AL6_GO(I3)                                                                                                                                  \
     do {                                                                                                                                                \
         (void)hipFuncSetAttribute((const void *)k_apply_lookup6<I3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
-        hipLaunchKernelGGL(k_apply_lookup6<I3>, dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, (const unsigned char *)ipl.buf2, \
+        hipLaunchKernelGGL(k_apply_lookup6<I3>, dim3(I3 ? al6_slices : al6_grid), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, (const unsigned char *)ipl.buf2, \
                            ipl.cnt2, (uint64_t)(I3 ? ipl.cap2 / PFmt3::GROUP : ipl.cap2 / 32), fresh ? 1 : 0, iovf, iovf_off, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2, \
-                           pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls);   \
+                           pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls, al6_slices);   \
     } while (0)
         if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
         if (ls.n_src && (ipl.wpb != 0 || iovf_off)) return -1;  // (lists come alone: tpc_combine_import leaves no regions of this rank's own)
-        if (ls.n_src) {  // lists alone (the combined exchange): its own instantiation, loads asked for up front
+        if (ls.n_src) {  // lists alone (the combined exchange): its own instantiation, loads asked for up front; one short workgroup per slice
+            // (as long-lived workgroups a rank's query took 4.14 instead of 3.51 ms at eight ranks: its ~12 us per slice are round trips,
+            // and the end of one workgroup overlaps the start of the next only when they are separate workgroups)
             (void)hipFuncSetAttribute((const void *)k_apply_lookup6<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_apply_lookup6<false, true>), dim3(1u << (pl.b1 + pl.b2)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, 0u, (const unsigned char *)nullptr,
+            hipLaunchKernelGGL((k_apply_lookup6<false, true>), dim3(al6_slices), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, 0u, (const unsigned char *)nullptr,
                                (const uint32_t *)nullptr, (uint64_t)0, fresh ? 1 : 0, (const uint64_t *)nullptr, (const uint64_t *)nullptr, pl.wpb, (const unsigned char *)pl.buf2, pl.cnt2,
-                               pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls);
+                               pl.off2, pl.bnd, pl.n_groups, pl.pb2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, ls, al6_slices);
         } else if (ipl.fmt2 == 3) TPC_AL6_GO(true); else TPC_AL6_GO(false);
         if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
 #undef TPC_AL6_GO
@@ -2048,8 +2059,8 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
         const size_t lds = ((words + 3) & ~(size_t)3) * 4 + QL_LDS;
         (void)hipFuncSetAttribute((const void *)k_apply_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (a.ev_lookup0) (void)hipEventRecord(a.ev_lookup0, a.stream);
-        hipLaunchKernelGGL(k_apply_lookup, dim3((1u << (pl.b1 + pl.b2)) / pl.world), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
-                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh, ls);
+        hipLaunchKernelGGL(k_apply_lookup, dim3(ls.n_src ? (1u << (pl.b1 + pl.b2)) / pl.world : tpc_slice_grid((1u << (pl.b1 + pl.b2)) / pl.world)), dim3(PT_APPLY_THREADS), lds, a.stream, pl.slice_bits, pl.b2, ipl.wpb, ipl.buf2, ipl.cnt2,
+                           ipl.cap2, fresh ? 1 : 0, iovf, iovf_off, pl.wpb, pl.buf2, pl.cnt2, pl.off2, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, pl.group_survivors ? 1 : 0, sh, ls, (uint32_t)((1u << (pl.b1 + pl.b2)) / pl.world));
         if (a.ev_lookup1) (void)hipEventRecord(a.ev_lookup1, a.stream);
     }
     hipLaunchKernelGGL(k_q_ovf, dim3(1024), dim3(256), 0, a.stream, pl.ovf, pl.ovf_cur, pl.ovf_cap, a.filter, pl.surv, pl.surv_cur, pl.surv_cap, perm, sh, pl.b2);
