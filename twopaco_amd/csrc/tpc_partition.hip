@@ -12,7 +12,7 @@
 //                          groups of 32 entries are flushed to the workgroup's private region
 //                          of bucket b1 (coalesced, aligned, no global atomics)
 //   level 2  k_part_split  streams bucket b1, bins by the next B2 bits, flushes the same way
-//   level 3  k_part_apply  one workgroup per slice: slice in LDS (zeroed, or loaded when the
+//   level 3  k_part_apply  a workgroup takes one slice at a time (long-lived: tpc_slice_grid): slice in LDS (zeroed, or loaded when the
 //                          filter already holds bits), ds_or every entry, one coalesced write-out
 //   level 4  k_part_ovf    entries that did not fit a region (adversarial skew) are applied with
 //                          plain atomicOr; if even that list overflows the host re-runs the
@@ -527,7 +527,7 @@ k_part_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, uint32_t nwg1, uin
 }
 
 // ------------------------------------------------------------------------------------------ level 3
-// One workgroup per 2^slice_bits-bit slice of the filter.
+// One 2^slice_bits-bit slice of the filter at a time per workgroup (every gridDim.x-th slice: tpc_internal.h:tpc_slice_grid).
 template <bool P3>  // the regions are blocked lines of 40 x 24-bit entries (see k_part_split)
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_part_apply(int slice_bits, int log_nb2, uint32_t wpb, const uint32_t *__restrict__ buf2, const uint32_t *__restrict__ cnt2,

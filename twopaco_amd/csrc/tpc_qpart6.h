@@ -42,7 +42,7 @@ struct Q6Res {
     }
 };
 
-// One workgroup per slice (k_q_lookup on blocked lines): the slice of the filter in LDS, every entry tests its bit there.
+// One slice at a time per workgroup (k_q_lookup on blocked lines): the slice of the filter in LDS, every entry tests its bit there.
 __global__ void __launch_bounds__(PT_APPLY_THREADS)
 k_q_lookup6(int slice_bits, int log_nb2, uint32_t wpb, const unsigned char *__restrict__ buf2, const uint32_t *__restrict__ cnt2,
             const uint64_t *__restrict__ off2, const uint32_t *__restrict__ bnd, uint32_t n_groups, uint32_t pb2, const uint32_t *__restrict__ filter, uint64_t *surv,

@@ -12,7 +12,7 @@
 //                  gets its canonical strand and first address a0 -> entry {a0 remainder, edge,
 //                  position} binned by the top B1 bits of a0 (uint64 entries, 16 per 128-B line)
 //   B  k_q_split   second-level binning by the next B2 bits
-//   C  k_q_lookup  one workgroup per slice: slice of the filter loaded into LDS once, every entry
+//   C  k_q_lookup  a workgroup takes one slice at a time (long-lived: tpc_slice_grid): slice of the filter loaded into LDS once, every entry
 //                  tests its bit there; survivors (first probe hit: Bloom false positives ~ fill
 //                  rate, plus true second edges) are appended to 64 survivor sub-lists
 //   D  k_q_verify  one thread per survivor: recomputes the vertex hashes from the text, probes
@@ -612,7 +612,7 @@ k_q_split(int LOG_NB1, int LOG_NB2, int L, int slice_bits, int loads, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------ C
-// One workgroup per slice.  Survivors (entry >> 31 = edge | position << 3) are staged in LDS and
+// One slice at a time per workgroup.  Survivors (entry >> 31 = edge | position << 3) are staged in LDS and
 // appended to sub-list (blockIdx % QS_LISTS) with one global atomic per flush.
 constexpr int QL_STAGE = 3072;
 constexpr int QL_BUCKETS = 1024;  // = PT_APPLY_THREADS: one counting-sort bucket per thread
@@ -785,7 +785,10 @@ k_q_lookup(int slice_bits, int log_nb2, uint32_t wpb, const uint64_t *__restrict
 //  slice's insert loads before it sorts and appends the survivors of the one at hand, so that no CU waits out a launch, a region
 //  count and a first round trip per 450 KB slice: 11.16 ms for k_q_split + this kernel against 11.0 as one short workgroup per
 //  slice.  The hardware already overlaps the end of one workgroup with the start of the next; the kernel runs at what HBM gives
-//  a two-reads-to-one-write mix.)
+//  a two-reads-to-one-write mix.  Round 6 measured the PLAIN form of the same idea on the 6-byte kernel -- 512 workgroups, each taking
+//  every 512th slice, nothing prefetched across slices -- and that one pays: 5.83 -> 5.48 ms there, 36.9 -> 35.4 ms per step at f = 38
+//  through this kernel (profiles/r06_lookup_grid_ab.txt); asking for the next slice's counts a slice ahead made it slower again.
+//  All one-slice-at-a-time kernels are launched that way now: tpc_internal.h:tpc_slice_grid.)
 // Fused k_part_apply + k_q_lookup (tpc_partition.hip: deferred apply).  When the insert and the query of a round both
 // fit one tile batch, the workgroup that builds a filter slice in LDS from the insert's level-2 entries writes it out
 // AND tests the query's entries of that slice on the spot: the 2^L / 8 bytes of the filter are not read back.
