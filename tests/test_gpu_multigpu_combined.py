@@ -70,6 +70,21 @@ def test_replicated_second_pass_and_gathered_output(capi, tmp_path, name, ranks,
     e.close()
 
 
+@pytest.mark.parametrize("name,ranks", [("rand6_k9_a3", 2), ("c2_k125", 4)])
+def test_per_position_records_in_the_second_pass(capi, tmp_path, name, ranks, monkeypatch):
+    """TWOPACO_PASS2_AGGREGATE=0: a (key, prev | next) record per marked position travels to the key's owner (rounds 3-5) instead of one
+    aggregated record per distinct key of a rank's marks (tpc_pass2_aggregate_records, the default): same bytes, same counters -- with
+    an abundance cut and with four-word keys."""
+    monkeypatch.setenv("TWOPACO_PASS2_AGGREGATE", "0")
+    case = CASES[name]
+    out = str(tmp_path / "mg.bin")
+    e = capi.Enumerator(case_files(case, tmp_path), case["k"], case["L"], q=case["q"], rounds=case["n_rounds"],
+                        abundance=case["abundance"] if case["abundance"] is not None else MAXU, tmpdir=str(tmp_path), out=out,
+                        seed=case["seed"], gpus=ranks, emulate_ranks=True)
+    _check(case, e, out)
+    e.close()
+
+
 def test_m1_full_four_emulated_ranks(capi, tmp_path):
     """BASELINE configs[1] at its full size (8 x 5 Mbp, f = 32) on four emulated ranks: sha256 and counters of the real reference."""
     case = CASES["m1_full"]

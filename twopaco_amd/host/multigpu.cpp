@@ -946,7 +946,7 @@ namespace TwoPaCo
 		int32_t * owner = static_cast<int32_t*>(r.Ensure(OWNER, std::max<uint64_t>(n, 1) * 4));
 		// combine before routing: the rank's own exact filter first, then one record per DISTINCT key (sets, "seen twice", count) instead
 		// of one per marked position (TWOPACO_PASS2_AGGREGATE=0: the per-position records of rounds 3-5)
-		static const bool aggregate = !(std::getenv("TWOPACO_PASS2_AGGREGATE") && std::getenv("TWOPACO_PASS2_AGGREGATE")[0] == '0');
+		const bool aggregate = !(std::getenv("TWOPACO_PASS2_AGGREGATE") && std::getenv("TWOPACO_PASS2_AGGREGATE")[0] == '0');
 		uint64_t rows = n;
 		if (aggregate) LibCheck(r.ctx, tpc_pass2_aggregate_records(r.ctx, uint32_t(W), abundance, records, owner, &rows), "pass2_aggregate_records");
 		else LibCheck(r.ctx, tpc_pass2_mark_records(r.ctx, uint32_t(W), records, owner), "pass2_mark_records");
