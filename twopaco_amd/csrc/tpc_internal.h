@@ -1,4 +1,4 @@
-// tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi.hip) and the kernels.
+// tpc_internal.h -- host-side launch interface between the C-ABI (tpc_capi*.hip, tpc_ctx.h) and the kernels.
 #pragma once
 #include "tpc_device.h"
 #include <algorithm>

@@ -2014,7 +2014,7 @@ int tpc_launch_query_part_lookup(const TpcLaunch &a, const TpcQPlan &pl)
     return 0;
 }
 
-// Fused tail of the query when the insert's apply was deferred (see tpc_capi.hip:flush_pending_apply): level-2 binning of
+// Fused tail of the query when the insert's apply was deferred (see tpc_capi.hip:flush_pending_apply; tpc_ctx.h): level-2 binning of
 // the query, then k_apply_lookup over the insert's and the query's level-2 regions, then the overflow probes.
 int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, const TpcPartPlan &ipl, bool fresh, const uint64_t *iovf, const uint64_t *iovf_off, const TpcListSrc *lists)
 {   // lists: set-bit lists to OR into every slice as well (the combined exchange; ipl.wpb may then be 0: no regions of its own)
