@@ -21,6 +21,9 @@
 // mark(g) <=> some unknown edge is present: with prev and next definite the known in- and out-edge
 // count 1 each, so "inCount > 1 || outCount > 1" (VE.h:656) holds exactly when one more edge passes
 // all q probes.  The mask is bit-identical to k_query's (tests/test_gpu_parity.py).
+#ifndef TPC_QPARTITION_PART
+#define TPC_QPARTITION_PART 0  // csrc/Makefile compiles this file twice: 1 -> tpc_qpartition_x.o, the rarely used kernels (verification for q != 5, the sharded path's routing)
+#endif
 #include "tpc_rbins.h"
 #include "tpc_bins3.h"
 #include "tpc_binsp.h"
@@ -33,7 +36,9 @@
 #include <cstdlib>
 #include <cmath>
 
+#if TPC_QPARTITION_PART == 0
 int tpc_test_q6_pb2 = 0;  // option "test_q6_pb2" (tests)
+#endif
 
 namespace {
 
@@ -68,6 +73,13 @@ __device__ __forceinline__ bool within(uint64_t v, uint64_t lo, uint64_t hi) { r
 constexpr int QH_THREADS = 1024;  // two threads per packed word: 16 positions each
 constexpr int QH_RUN = 16;
 
+__device__ __forceinline__ uint64_t q_rotl_n(uint64_t x, int L, int r)
+{   // fastleftshiftn (cyclichash.h:42-44 applied r times)
+    if (r == 0) return x;
+    return ((x & ((1ull << (L - r)) - 1ull)) << r) | (x >> (L - r));
+}
+
+#if TPC_QPARTITION_PART == 0
 // RB: barrier-free rings (tpc_rbins.h) instead of the flush-per-round bins.  At 512 bins a ring of the latter holds 32 uint64
 // entries, rounds have to be split over thread subsets and the kernel runs at half the rate of the 256-bin geometry; the
 // barrier-free rings do not care (tools/bins_bench.hip: 5.1 against 28 ms for 1.86 G entries).  Their pushes must be made by
@@ -229,12 +241,6 @@ k_q_hash(int LOG_NB, TpcHashParams P, const uint64_t *__restrict__ tab, const ui
 // 16-byte pairs, and the bins are Bins3.  Used whenever the geometry allows (launch_qhash); entries, masks and overflow
 // entries are those of k_q_hash (order inside a region differs: nothing downstream depends on it).
 constexpr int QT_MAXK = 64;  // seed table: k x 5 letters x 16 bytes
-
-__device__ __forceinline__ uint64_t q_rotl_n(uint64_t x, int L, int r)
-{   // fastleftshiftn (cyclichash.h:42-44 applied r times)
-    if (r == 0) return x;
-    return ((x & ((1ull << (L - r)) - 1ull)) << r) | (x >> (L - r));
-}
 
 // every mask bit doubled: bit i -> bits 2i, 2i+1
 __device__ __forceinline__ uint64_t q_spread2(uint32_t m)
@@ -894,6 +900,7 @@ __global__ void k_q_ovf(const uint64_t *__restrict__ list, const unsigned long l
     }
 }
 
+#endif  // part 0 only
 // ------------------------------------------------------------------------------------------ D
 template <int Q>
 __global__ void __launch_bounds__(256)
@@ -1149,7 +1156,9 @@ k_q_verify2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *_
     }
 }
 
+#if TPC_QPARTITION_PART == 0
 #include "tpc_qpart6.h"
+#endif
 
 // ------------------------------------------------------------------------------------------ sharded verification
 constexpr int RT_CHUNK = 4096, RT_MAXW = 64;  // owner routing: items per workgroup round, most ranks
@@ -1294,6 +1303,7 @@ k_v_addrs2(TpcHashParams P, const uint64_t *__restrict__ tab, const uint64_t *__
     }
 }
 
+#if TPC_QPARTITION_PART == 1
 // the 64 survivor sub-lists as one contiguous list
 __global__ void k_surv_gather(const uint64_t *__restrict__ surv, const unsigned long long *__restrict__ surv_cur, uint64_t surv_cap, uint64_t *__restrict__ out)
 {
@@ -1493,6 +1503,8 @@ k_route_count64(const uint64_t *__restrict__ v, uint64_t n, int shift, uint32_t 
     if (threadIdx.x < RT_MAXW && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+#endif  // part 1 only
+#if TPC_QPARTITION_PART == 0
 // 512 bins per level (f = 37, 38 at the default slice size): the barrier-free rings (k_q_hash / k_q_split<.., RB = true>)
 inline bool q_use_rbins(int log_nb) { return log_nb >= 9; }
 
@@ -1562,6 +1574,40 @@ constexpr int PER_CBITS = 10;               // bit-sliced run counters: runs up 
 // 63 characters before j, E = the periods whose character p back equals T[j] (both definite), C[b] = bit b of every period's run counter
 // (incremented where E, cleared where not, saturating), and "run >= k + 2" is a bit-sliced comparison: ~130 word operations per
 // character for all periods, where a counter per period took 5 per period.
+// A cheap NECESSARY condition for a word of 32 positions to hold any periodic one (round 6: the detector below costs ~16 K word operations
+// per 32 positions and nearly every word of a genome fails this test in ~2 K).  A position i is flagged only if text[t] == text[t - p] for
+// all t in [i, i + k] and some p <= 63 (k + 1 definite characters, none of text[i - p .. i + k] an N).  Tile the line with blocks of
+// B = min(16, (k + 2) / 2) characters from s0: every stretch of k + 1 >= 2B - 1 characters that starts at or after s0 contains a whole block,
+// so a flagged position implies a block [a, a + B) with text[a .. a + B) == text[a - p .. a + B - p).  The blocks tested: those inside
+// [first, first + 31 + k], the union of the word's windows -- or, when k >= 31 + 2B - 1, inside [first + 31, first + k], which every one of
+// them contains.  Anything doubtful (an N or the end of what this context holds within 63 characters, k < 18) passes: the detector decides.
+__device__ __forceinline__ bool periodic_may_flag(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int k, int64_t first, int64_t lo, int64_t hi)
+{
+    const int B = min(16, (k + 2) / 2);
+    if (B < 10) return true;
+    int64_t s0 = first, s1 = first + 31 + k;
+    if (k >= 31 + 2 * B - 1) { s0 = first + 31; s1 = first + k; }
+    const uint32_t M = B == 16 ? 0xFFFFFFFFu : (1u << (2 * B)) - 1u;
+    for (int64_t a = s0; a + B - 1 <= s1; a += B) {
+        if (a - 63 < lo || a + B > hi) return true;
+        const int64_t wl = (a - 63) >> 5;
+        const uint32_t off = (uint32_t)((a - 63) & 31), sh = 2u * off;
+        const bool four = off + 63u + (uint32_t)B > 96u;  // the block's last character lies in a fourth word (never read beyond it: a context may hold a window of the text)
+        const uint64_t b0 = bases[wl], b1 = bases[wl + 1], b2 = bases[wl + 2], b3 = four ? bases[wl + 3] : 0ull;
+        const uint64_t nlo = (uint64_t)nmask[wl] | ((uint64_t)nmask[wl + 1] << 32), nhi = (uint64_t)nmask[wl + 2] | ((uint64_t)(four ? nmask[wl + 3] : 0u) << 32);
+        // characters a - 63 .. a + B - 1 as bits 0 .. 2 (63 + B) - 1 of R2:R1:R0; their N flags as bits 0 .. 62 + B of n1:n0
+        uint64_t R0 = sh ? (b0 >> sh) | (b1 << (64u - sh)) : b0, R1 = sh ? (b1 >> sh) | (b2 << (64u - sh)) : b1, R2 = sh ? (b2 >> sh) | (b3 << (64u - sh)) : b2;
+        const uint64_t n0 = off ? (nlo >> off) | (nhi << (64u - off)) : nlo, n1 = nhi >> off;
+        if (n0 | (n1 & ((1ull << (B - 1)) - 1ull))) return true;
+        const uint32_t X = (uint32_t)((R1 >> 62) | (R2 << 2)) & M;  // the block itself: characters 63 .. 62 + B
+        for (int p = PER_MAXP; p >= 1; p--) {                         // R0's low bits: the block p characters back
+            if (((uint32_t)R0 & M) == X) return true;
+            R0 = (R0 >> 2) | (R1 << 62); R1 = (R1 >> 2) | (R2 << 62); R2 >>= 2;
+        }
+    }
+    return false;
+}
+
 __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restrict__ bases, const uint32_t *__restrict__ nmask, uint64_t n_text, int k, uint32_t *__restrict__ qs,
                                                         uint32_t *__restrict__ qd, uint64_t stride, uint32_t *__restrict__ ins, uint64_t w_begin, uint64_t n_words, uint64_t pos_lo,
                                                         uint64_t pos_hi, uint32_t *any)
@@ -1574,7 +1620,7 @@ __global__ void __launch_bounds__(256) k_periodic_build(const uint64_t *__restri
 #pragma unroll
     for (int b = 0; b < PER_PLANES; b++) od[b] = 0;
     const int64_t first = (int64_t)(w << 5);
-    if ((uint64_t)first < n_text) {
+    if ((uint64_t)first < n_text && periodic_may_flag(bases, nmask, k, first, (int64_t)pos_lo, (int64_t)(pos_hi < n_text ? pos_hi : n_text))) {
         auto ch_at = [&](int64_t j) { return j >= (int64_t)pos_lo && (uint64_t)j < pos_hi && (uint64_t)j < n_text ? tpc_text_char(bases, nmask, (uint64_t)j) : 4; };
         const int64_t j0 = first - 2;  // (run lengths only matter up to k + 2: starting k + 2 characters before the first window's end is exact)
         const uint64_t pmask = (1ull << PER_MAXP) - 1ull;
@@ -1723,6 +1769,7 @@ void launch_qsplit6(const TpcLaunch &a, const TpcQPlan &pl, QOverflow ovf)
                        pl.bnd, pl.n_groups, pl.tiles_per_wg, (uint32_t)pl.n_tiles, pl.pb2);
 }
 
+#endif  // part 0 only
 template <int Q>
 void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
@@ -1746,6 +1793,7 @@ void launch_qverify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 
 }  // namespace
 
+#if TPC_QPARTITION_PART == 0
 bool tpc_qpart_plan(int L, int slice_bits, uint64_t n_tiles, double frac, TpcQPlan &pl, int levels)
 {
     return tpc_qpart_plan_sharded(L, slice_bits, n_tiles, frac, 0, 1, pl, levels, false, true);
@@ -2070,14 +2118,38 @@ int tpc_launch_query_part_fused_lookup(const TpcLaunch &a, const TpcQPlan &pl, c
     return 0;
 }
 
+#endif  // part 0 only
+// The verification kernels are instantiated per number of hash functions: q = 5, the default every run of the CLI without -q uses, lives in
+// this code object; the other fifteen in the second one (tpc_qpartition_x.o), which the runtime loads only when such a run happens.
+int tpc_launch_query_verify_other(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask);
+#if TPC_QPARTITION_PART == 0
 int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
+{
+    if (a.P.q == 5) { launch_qverify<5>(a, pl, rmask); return 0; }
+    return tpc_launch_query_verify_other(a, pl, rmask);
+}
+
+// Launches A-D on the stream (one rank, whole filter).  The caller zeroes ovf_cur / surv_cur first and
+// reads both flags back afterwards: surv_cur[QS_LISTS] != 0 or ovf_cur[1] != 0 means a list overflowed and
+// the mask is incomplete (re-run the direct kernel).
+int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
+{
+    TpcQPlan pl = pl0;
+    pl.rbuf1 = pl.buf1;
+    pl.rcnt1 = pl.cnt1;
+    int rc = tpc_launch_query_part_hash(a, pl, rmask, lo, hi, gated);
+    if (rc) return rc;
+    if ((rc = tpc_launch_query_part_lookup(a, pl))) return rc;
+    return tpc_launch_query_verify(a, pl, rmask);
+}
+#else
+int tpc_launch_query_verify_other(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rmask)
 {
     switch (a.P.q) {
     case 1: launch_qverify<1>(a, pl, rmask); break;
     case 2: launch_qverify<2>(a, pl, rmask); break;
     case 3: launch_qverify<3>(a, pl, rmask); break;
     case 4: launch_qverify<4>(a, pl, rmask); break;
-    case 5: launch_qverify<5>(a, pl, rmask); break;
     case 6: launch_qverify<6>(a, pl, rmask); break;
     case 7: launch_qverify<7>(a, pl, rmask); break;
     case 8: launch_qverify<8>(a, pl, rmask); break;
@@ -2093,32 +2165,8 @@ int tpc_launch_query_verify(const TpcLaunch &a, const TpcQPlan &pl, uint32_t *rm
     }
     return 0;
 }
-
-// Launches A-D on the stream (one rank, whole filter).  The caller zeroes ovf_cur / surv_cur first and
-// reads both flags back afterwards: surv_cur[QS_LISTS] != 0 or ovf_cur[1] != 0 means a list overflowed and
-// the mask is incomplete (re-run the direct kernel).
-int tpc_launch_query_partitioned(const TpcLaunch &a, const TpcQPlan &pl0, uint32_t *rmask, uint64_t lo, uint64_t hi, bool gated)
-{
-    TpcQPlan pl = pl0;
-    pl.rbuf1 = pl.buf1;
-    pl.rcnt1 = pl.cnt1;
-    int rc = tpc_launch_query_part_hash(a, pl, rmask, lo, hi, gated);
-    if (rc) return rc;
-    if ((rc = tpc_launch_query_part_lookup(a, pl))) return rc;
-    switch (a.P.q) {
-    case 1: launch_qverify<1>(a, pl, rmask); break;
-    case 2: launch_qverify<2>(a, pl, rmask); break;
-    case 3: launch_qverify<3>(a, pl, rmask); break;
-    case 4: launch_qverify<4>(a, pl, rmask); break;
-    case 5: launch_qverify<5>(a, pl, rmask); break;
-    case 6: launch_qverify<6>(a, pl, rmask); break;
-    case 7: launch_qverify<7>(a, pl, rmask); break;
-    case 8: launch_qverify<8>(a, pl, rmask); break;
-    default: return tpc_launch_query_verify(a, pl, rmask);
-    }
-    return 0;
-}
-
+#endif
+#if TPC_QPARTITION_PART == 1
 int tpc_launch_verify_addrs(const TpcLaunch &a, const TpcQPlan &pl, int fn, int fn_count, const uint64_t *sid, uint64_t n, uint64_t *addr_out,
                             int32_t *owner_out, unsigned long long *owner_counts)
 {   // owner_out == nullptr: tagged addresses (owner << V_OWNER_SHIFT) and, when owner_counts is given, the probes per owner
@@ -2229,6 +2277,8 @@ int tpc_launch_surv_gather(const TpcLaunch &a, const TpcQPlan &pl, uint64_t *out
     return 0;
 }
 
+#endif  // part 1 only
+#if TPC_QPARTITION_PART == 0
 // tpc_preload: the first use of any kernel of this translation unit makes the runtime load its code object
 __global__ void k_warm_qpartition() {}
 int tpc_warm_qpartition() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_warm_qpartition)) == hipSuccess ? 0 : -1; }
@@ -2247,3 +2297,5 @@ int tpc_launch_periodic_copy(hipStream_t stream, uint32_t *rmask, const uint32_t
     if (n_words) hipLaunchKernelGGL(k_periodic_copy, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, rmask, qs, qd, stride, n_words);
     return 0;
 }
+
+#endif  // part 0 only
